@@ -1,0 +1,246 @@
+/*
+ * vs_stab.h - C ABI of libvideo-stab (MI355X / gfx950 build).
+ *
+ * This is the drop-in boundary for the per-frame stabilization hot path of
+ * OmerMersin/video-stab: everything `vs::Stabilizer::stabilize(frame)` does
+ * (reference: include/video/Stabilizer.h:177-198, src/Stabilizer.cpp:258-1172).
+ * The reference has no FFI of its own (it is a C++ class over cv::Mat); the
+ * binding a maintainer adds is the thin C++ class in include/video/Stabilizer.h
+ * of this repo, which forwards to the entry points below.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch/OpenCV types cross this ABI;
+ *  - every function returns a vs_status; nothing throws across the ABI;
+ *  - images are 8-bit, row-major, with an explicit row stride in BYTES;
+ *  - `*_dev` entry points take DEVICE pointers and are asynchronous on the
+ *    instance's HIP stream; the host-pointer forms copy in/out and synchronise;
+ *  - there is no CPU fallback: if no gfx950 device is usable every compute
+ *    entry point fails with VS_ERR_NO_DEVICE.
+ */
+#ifndef VS_STAB_H
+#define VS_STAB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_STAB_ABI_VERSION 1
+
+typedef enum vs_status {
+    VS_OK = 0,
+    VS_ERR_INVALID_ARG = 1,
+    VS_ERR_NO_DEVICE = 2,     /* no HIP device / kernels cannot run          */
+    VS_ERR_HIP = 3,           /* a HIP runtime call failed (see last_error)   */
+    VS_ERR_UNSUPPORTED = 4,   /* parameter combination outside the hot path   */
+    VS_ERR_SIZE_CHANGED = 5,  /* frame size differs from the instance's       */
+    VS_ERR_CAPACITY = 6       /* a device-side capacity was exceeded          */
+} vs_status;
+
+typedef enum vs_pixfmt {
+    VS_FMT_BGR8 = 0,          /* interleaved B,G,R  (cv::Mat CV_8UC3)         */
+    VS_FMT_NV12 = 1,          /* Y plane (h rows) followed by UV plane (h/2)  */
+    VS_FMT_GRAY8 = 2
+} vs_pixfmt;
+
+/* Stabilizer.cpp:31-38 mapBorderMode() */
+typedef enum vs_border {
+    VS_BORDER_BLACK = 0,
+    VS_BORDER_REFLECT = 1,
+    VS_BORDER_REFLECT_101 = 2,
+    VS_BORDER_REPLICATE = 3,
+    VS_BORDER_WRAP = 4,
+    VS_BORDER_FADE = 5
+} vs_border;
+
+/* Stabilizer.cpp:797-823 */
+typedef enum vs_smoothing {
+    VS_SMOOTH_BOX = 0,
+    VS_SMOOTH_GAUSSIAN = 1,
+    VS_SMOOTH_KALMAN = 2
+} vs_smoothing;
+
+/*
+ * Flat POD mirror of vs::Stabilizer::Parameters (Stabilizer.h:76-175).
+ * Only the fields the live hot path reads are present;
+ * strings became enums.  Fill with vs_params_default() first.
+ */
+typedef struct vs_params_c {
+    int32_t struct_size;          /* = sizeof(vs_params_c), ABI check          */
+    int32_t logging;              /* Stabilizer.h:79                           */
+    int32_t smoothing_radius;     /* :81  default 30                           */
+    int32_t max_corners;          /* :82  default 200                          */
+    double  quality_level;        /* :83  default 0.01                         */
+    double  min_distance;         /* :84  default 30.0                         */
+    int32_t block_size;           /* :85  default 3                            */
+    int32_t border_type;          /* :87  vs_border, default BLACK             */
+    int32_t border_size;          /* :88  default 0                            */
+    int32_t crop_n_zoom;          /* :89  default 0                            */
+    int32_t smoothing_method;     /* :92  vs_smoothing, default BOX            */
+    int32_t horizon_lock;         /* :95  default 0                            */
+    double  gaussian_sigma;       /* :93  default 2.0                          */
+    int32_t adaptive_smoothing;   /* :114 default 0                            */
+    int32_t min_smoothing_radius; /* :115 default 5                            */
+    int32_t max_smoothing_radius; /* :116 default 50                           */
+    float   fade_alpha;           /* :128 default 0.1                          */
+    int32_t fade_duration;        /* :129 default 30                           */
+    int32_t enable_virtual_canvas;/* :154 default 0 (VS_ERR_UNSUPPORTED if 1)  */
+    int32_t drone_high_freq_mode; /* :165 default 0                            */
+    float   hf_shake_px;          /* :166 default 1.5                          */
+    int32_t hf_analysis_max_width;/* :167 default 960                          */
+    float   hf_rot_lp_alpha;      /* :168 default 0.2                          */
+    int32_t enable_conditional_clahe; /* :169 default 1                        */
+    float   hf_dead_zone_threshold;   /* :172 default 2.0                      */
+    int32_t hf_freeze_duration;       /* :173 default 10                       */
+    float   hf_motion_accumulator_decay; /* :174 default 0.9                   */
+    /* --- extensions: constants hard-coded in Stabilizer.cpp:611-619 --------- */
+    int32_t lk_win_size;          /* 15  (Stabilizer_legacy.cpp:218 uses 21)   */
+    int32_t lk_max_level;         /* 2   (3 pyramid levels)                    */
+    int32_t lk_max_iters;         /* 20                                        */
+    double  lk_epsilon;           /* 0.03                                      */
+    int32_t ransac_max_iters;     /* 500 (Stabilizer.cpp:649)                  */
+    double  ransac_threshold;     /* 5.0                                       */
+    int32_t reserved[8];
+} vs_params_c;
+
+/* Throughput / health counters ("Metrics"). */
+typedef struct vs_counters {
+    uint64_t frames_in;
+    uint64_t frames_out;
+    uint64_t detections;          /* goodFeaturesToTrack runs                  */
+    int32_t  last_features;       /* points handed to LK on the last frame     */
+    int32_t  last_tracked;        /* status != 0                               */
+    int32_t  last_inliers;        /* RANSAC inliers of the chosen model        */
+    int32_t  last_candidates;     /* GFTT local maxima above the threshold     */
+    int32_t  gftt_overflow;       /* !=0: candidate list was truncated         */
+    int32_t  reserved[7];
+} vs_counters;
+
+/* Per-frame device results, for parity tests and diagnostics. */
+typedef struct vs_debug_frame {
+    int32_t n_prev;               /* keypoints handed to LK                    */
+    int32_t n_valid;              /* pairs after status compaction             */
+    int32_t ransac_best_iter;     /* hypothesis index kept (-1: none)          */
+    int32_t ransac_iters_run;     /* final niters                              */
+    int32_t n_inliers;
+    int32_t detected;             /* 1 if GFTT ran on this frame               */
+    int32_t n_detected;
+    int32_t box_radius;           /* S1 radius actually used (0 if not box)    */
+    int32_t intent;               /* MotionIntent chosen for the output frame  */
+    int32_t out_index;            /* index of the frame that was warped, or -1 */
+    float   transform[3];         /* (dx,dy,da) measured for this frame        */
+    float   smoothed[3];          /* smoothed path at out_index                */
+    float   warp_matrix[6];       /* T handed to the warp                      */
+    double  model[6];             /* refined 2x3 model (double)                */
+} vs_debug_frame;
+
+typedef struct vs_stab vs_stab;   /* opaque instance (one video stream)        */
+
+/* ---- library ------------------------------------------------------------- */
+int          vs_abi_version(void);
+const char*  vs_build_info(void);          /* arch, compiler, feature string  */
+int          vs_device_count(void);        /* 0 when no usable GPU            */
+void         vs_params_default(vs_params_c* p);
+const char*  vs_status_string(int status);
+
+/* ---- vs::Stabilizer (Stabilizer.h:177-198) ------------------------------- */
+/* Stabilizer(const Parameters&) - Stabilizer.cpp:50-164 */
+int vs_stab_create(const vs_params_c* params, int device, vs_stab** out);
+/* ~Stabilizer() - Stabilizer.cpp:216-219 */
+void vs_stab_destroy(vs_stab* s);
+/* clean() - Stabilizer.cpp:221-256 */
+int vs_stab_clean(vs_stab* s);
+/*
+ * stabilize(frame) - Stabilizer.cpp:258-392.  Host frame in, host frame out.
+ * *produced = 1 and `out` filled when a stabilized frame is ready, 0 during
+ * the warm-up (the reference returns an empty Mat, :263-265,:384-387).
+ * `out` must hold out_h rows of out_stride bytes; query with vs_stab_out_size().
+ */
+int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride,
+                 int fmt, uint8_t* out, size_t out_stride, int* produced);
+/* flush() - Stabilizer.cpp:394-400 */
+int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced);
+/* Device-pointer forms: asynchronous on the instance stream, no host sync.
+ * `produced` is decided on the host from the frame count alone (E0). */
+int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride,
+                     int fmt, void* d_out, size_t out_stride, int* produced);
+int vs_stab_flush_dev(vs_stab* s, void* d_out, size_t out_stride, int* produced);
+int vs_stab_sync(vs_stab* s);
+/* size of the frames stabilize() returns for w x h input (crop/border rules,
+ * Stabilizer.cpp:981-990,1108-1127) */
+int vs_stab_out_size(const vs_stab* s, int w, int h, int* out_w, int* out_h);
+int vs_stab_get_counters(vs_stab* s, vs_counters* out);      /* synchronises  */
+int vs_stab_get_debug(vs_stab* s, vs_debug_frame* out);      /* synchronises  */
+/* copies the debug arrays of the last push: any pointer may be NULL.
+ * prev/curr: n_prev * 2 floats; status: n_prev bytes; inliers: n_valid bytes;
+ * detected: n_detected * 2 floats; gray: analysis image (aw*ah bytes). */
+int vs_stab_get_debug_arrays(vs_stab* s, float* prev_pts, float* curr_pts,
+                             uint8_t* status, uint8_t* inliers,
+                             float* detected_pts, uint8_t* gray, int* aw, int* ah);
+const char* vs_stab_last_error(const vs_stab* s);
+void*       vs_stab_stream(vs_stab* s);    /* hipStream_t of the instance     */
+/* capture one steady-state push_dev into a hipGraph and replay it from then
+ * on (two variants: with / without re-detection).  0 disables. */
+int vs_stab_enable_graph(vs_stab* s, int enable);
+
+/* ---- device memory helpers (so callers need no HIP headers) --------------- */
+int vs_dev_malloc(void** d_ptr, size_t bytes);
+int vs_dev_free(void* d_ptr);
+int vs_dev_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int vs_dev_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int vs_dev_memset(void* d_dst, int value, size_t bytes);
+int vs_dev_sync(void);
+const char* vs_last_error(void);           /* thread-local, op-level calls    */
+
+/* ---- stage operators on device buffers (stream = hipStream_t or NULL) ------
+ * Each one is the device counterpart of one OpenCV call made by
+ * src/Stabilizer.cpp; the file:line of that call is cited per function.     */
+
+/* cv::warpAffine(src,dst,T,size,INTER_LINEAR,BORDER_CONSTANT) -
+ * Stabilizer.cpp:1056-1060.  M = forward 2x3 float matrix as the reference
+ * builds it (:902-908).  `batch` frames of identical geometry, frame b at
+ * d_src + b*src_frame_bytes with matrix M + 6*b.  cn = 3 (BGR8) or 1. */
+int vs_op_warp_affine(const void* d_src, size_t src_stride, size_t src_frame_bytes,
+                      void* d_dst, size_t dst_stride, size_t dst_frame_bytes,
+                      int w, int h, int cn, const float* M, int batch, void* stream);
+/* NV12 surface: Y plane warped with M, interleaved UV plane at half
+ * resolution with the translation halved. */
+int vs_op_warp_affine_nv12(const void* d_src, size_t src_stride, void* d_dst,
+                           size_t dst_stride, int w, int h, const float* M,
+                           int batch, size_t src_frame_bytes, size_t dst_frame_bytes,
+                           void* stream);
+/* cv::resize(INTER_LINEAR) + cv::cvtColor(BGR2GRAY) - Stabilizer.cpp:304-305,
+ * 448-450.  fmt BGR8 (resize then gray), GRAY8 / NV12 (luma plane resize). */
+int vs_op_resize_gray(const void* d_src, size_t src_stride, int sw, int sh, int fmt,
+                      void* d_dst, size_t dst_stride, int dw, int dh, void* stream);
+/* cv::pyrDown as used inside calcOpticalFlowPyrLK - Stabilizer.cpp:611 */
+int vs_op_pyr_down(const void* d_src, size_t src_stride, int sw, int sh,
+                   void* d_dst, size_t dst_stride, void* stream);
+/* Scharr derivative image (int16, interleaved dx,dy) of calcOpticalFlowPyrLK */
+int vs_op_scharr(const void* d_src, size_t src_stride, int w, int h,
+                 void* d_dst /* int16[h][w][2] */, void* stream);
+/* cv::calcOpticalFlowPyrLK(prev,next,prevPts,nextPts,status,err,win,maxLevel,
+ * TermCriteria(COUNT+EPS,iters,eps)) - Stabilizer.cpp:611-619 */
+int vs_op_pyr_lk(const void* d_prev, const void* d_next, size_t stride, int w, int h,
+                 const float* d_prev_pts, int n, float* d_next_pts,
+                 uint8_t* d_status, float* d_err,
+                 int win, int max_level, int max_iters, double eps, void* stream);
+/* cv::goodFeaturesToTrack(gray,corners,maxCorners,quality,minDistance,noArray(),
+ * blockSize) - Stabilizer.cpp:354-358,740-744.  d_pts: maxCorners*2 floats,
+ * d_count: one int32.  d_eig (optional, w*h floats) receives the min-eigen map. */
+int vs_op_gftt(const void* d_gray, size_t stride, int w, int h, int max_corners,
+               double quality, double min_distance, int block_size,
+               float* d_pts, int32_t* d_count, float* d_eig, void* stream);
+/* cv::estimateAffinePartial2D(from,to,noArray(),RANSAC,thr,maxIters) -
+ * Stabilizer.cpp:647-649.  d_model: 6 doubles (or NaN when no model),
+ * d_inliers: n bytes, d_info: int32[4] = {ok, best_iter, iters_run, n_inliers}. */
+int vs_op_estimate_affine_partial2d(const float* d_from, const float* d_to, int n,
+                                    double thr, int max_iters, double* d_model,
+                                    uint8_t* d_inliers, int32_t* d_info, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VS_STAB_H */

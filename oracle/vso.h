@@ -1,0 +1,111 @@
+/*
+ * vso.h - CPU ORACLE for the stabilize() hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This directory is a plain C++ restatement of the algorithm that
+ * /root/reference/src/Stabilizer.cpp (CPU branch, useCuda=false) executes per
+ * frame, including the OpenCV 4.11 primitives it calls.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * product library (video-stab_amd/csrc) never includes or links anything here.
+ *
+ * PARITY UNPINNED.  The reference ships no tests, fixtures or golden vectors
+ *  and cannot be built here (it needs OpenCV 4.11 +
+ * CUDA + GStreamer + DeepStream; none are in the image, its binaries are
+ * aarch64).  The arithmetic of the path lives in OpenCV 4.11 (un-vendored
+ * third-party dependency, evidenced by `NEEDED libopencv_core.so.411` in
+ * examples/vs); the OpenCV primitives are restated here from the published
+ * algorithm of that version.  What pins this oracle instead: analytic
+ * known-answer tests (tests/test_oracle_kat.py) and the reference's own call
+ * sites/parameters, cited per function as file:line below.
+ *
+ * Where OpenCV's result depends on the SIMD width of the build (float
+ * accumulation order in calcOpticalFlowPyrLK, FMA use in cornerMinEigenVal)
+ * the oracle fixes ONE definition and says so at the function.
+ */
+#ifndef VSO_H
+#define VSO_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../include/vs_stab.h" /* vs_params_c / vs_debug_frame PODs only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- image primitives ----------------------------------------------------- */
+/* cv::resize(src,dst,Size(dw,dh),0,0,INTER_LINEAR) for CV_8UC(cn)
+ * (call sites Stabilizer.cpp:304,449,602,1121) */
+void vso_resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride, int cn,
+                          uint8_t* dst, int dw, int dh, size_t dstride);
+/* cv::cvtColor(BGR2GRAY) 8U (Stabilizer.cpp:305,450) */
+void vso_bgr2gray(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride);
+/* cv::pyrDown 8UC1, BORDER_REFLECT_101 (inside calcOpticalFlowPyrLK) */
+void vso_pyr_down(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, size_t dstride);
+/* calcSharrDeriv: int16 interleaved (dI/dx, dI/dy), h*w*2 */
+void vso_scharr(const uint8_t* src, int w, int h, size_t sstride, int16_t* dst);
+/* cv::copyMakeBorder (Stabilizer.cpp:982-987); border = vs_border */
+void vso_copy_make_border(const uint8_t* src, int w, int h, size_t sstride, int cn,
+                          uint8_t* dst, size_t dstride, int b, int border);
+/* cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT 0), forward matrix M (float[6])
+ * (Stabilizer.cpp:1056-1060) */
+void vso_warp_affine(const uint8_t* src, int w, int h, size_t sstride, int cn,
+                     uint8_t* dst, size_t dstride, const float* M);
+/* same, multi-threaded over rows (cpu_baseline "all cores" row); nthreads<=0: hw */
+void vso_warp_affine_mt(const uint8_t* src, int w, int h, size_t sstride, int cn,
+                        uint8_t* dst, size_t dstride, const float* M, int nthreads);
+/* NV12 policy of this build (no reference path): Y with M,
+ * interleaved UV at half size with the translation halved */
+void vso_warp_affine_nv12(const uint8_t* src, int w, int h, size_t sstride,
+                          uint8_t* dst, size_t dstride, const float* M);
+
+/* ---- features ------------------------------------------------------------- */
+/* cv::cornerMinEigenVal(gray, eig, blockSize, 3) */
+void vso_min_eigen(const uint8_t* gray, int w, int h, size_t stride, int block_size, float* eig);
+/* cv::goodFeaturesToTrack (Stabilizer.cpp:355-357, 740-744); returns count;
+ * n_candidates (optional) receives the number of local maxima examined list size */
+int vso_gftt(const uint8_t* gray, int w, int h, size_t stride, int max_corners,
+             double quality, double min_distance, int block_size, float* out_pts,
+             int* n_candidates);
+/* cv::calcOpticalFlowPyrLK (Stabilizer.cpp:611-619); returns levels used-1 */
+int vso_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int h, size_t stride,
+               const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err,
+               int win, int max_level, int max_iters, double eps);
+
+/* ---- model ---------------------------------------------------------------- */
+/* cv::RNG(seed).next() stream: fills out[0..n) */
+void vso_rng_stream(uint64_t seed, uint32_t* out, int n);
+/* cv::estimateAffinePartial2D(from,to,inliers,RANSAC,thr,max_iters,0.99,10)
+ * (Stabilizer.cpp:647-649).  model[6] double row-major; info[4] =
+ * {ok, best_iter, iters_run, n_inliers}.  returns ok. */
+int vso_estimate_affine_partial2d(const float* from, const float* to, int n, double thr,
+                                  int max_iters, double* model, uint8_t* inliers, int32_t* info);
+
+/* ---- trajectory (Stabilizer.cpp:1139-1172,1364-1458,1637-1780) ------------- */
+void vso_box_filter(const float* path, int n, int radius_param, int drone, float* out);
+void vso_gaussian_filter(const float* path, int n, float sigma, float* out);
+void vso_kalman_filter(const float* path, int n, float* out);
+int  vso_adaptive_radius(const float* px, const float* py, const float* pa, int n, int smoothing_radius);
+int  vso_motion_intent(const float* transforms /*n*3*/, int n, int frame_index);
+
+/* ---- vs::Stabilizer restated (Stabilizer.cpp:50-1172) ---------------------- */
+typedef struct vso_stab vso_stab;
+vso_stab* vso_stab_create(const vs_params_c* p);
+void      vso_stab_destroy(vso_stab* s);
+void      vso_stab_clean(vso_stab* s);
+/* stabilize(): returns 1 and fills out (out_w x out_h, tightly strided by out_stride) */
+int vso_stab_push(vso_stab* s, const uint8_t* data, int w, int h, size_t stride, int fmt,
+                  uint8_t* out, size_t out_stride);
+int vso_stab_flush(vso_stab* s, uint8_t* out, size_t out_stride);
+void vso_stab_out_size(const vso_stab* s, int w, int h, int* ow, int* oh);
+void vso_stab_get_debug(const vso_stab* s, vs_debug_frame* d);
+int  vso_stab_get_debug_arrays(const vso_stab* s, float* prev_pts, float* curr_pts,
+                               uint8_t* status, uint8_t* inliers, float* detected_pts,
+                               uint8_t* gray, int* aw, int* ah);
+/* threads used by row/point-parallel stages of vso_stab_push (default 1) */
+void vso_set_threads(int n);
+void vso_params_default(vs_params_c* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,69 @@
+// CPU ORACLE (test infrastructure) - shared helpers.
+#ifndef VSO_INTERNAL_H
+#define VSO_INTERNAL_H
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "vso.h"
+
+namespace vso {
+
+// cvRound: round-half-to-even (SSE cvtsd2si / lrint in the default FP mode)
+static inline int cv_round(double v) { return (int)lrint(v); }
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline int cv_floor(float v) {
+    int i = (int)v;
+    return i - (i > v);
+}
+static inline int cv_floor(double v) {
+    int i = (int)v;
+    return i - (i > v);
+}
+static inline short sat_short(int v) {
+    return (short)(v < SHRT_MIN ? SHRT_MIN : v > SHRT_MAX ? SHRT_MAX : v);
+}
+static inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+static inline int sat_int(double v) { return cv_round(v); }
+
+int border_interpolate(int p, int len, int border);
+void resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride, int cn, uint8_t* dst,
+                      int dw, int dh, size_t dstride);
+void bgr2gray(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride);
+void pyr_down(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, size_t dstride);
+void scharr(const uint8_t* src, int w, int h, size_t sstride, int16_t* dst);
+void copy_make_border(const uint8_t* src, int w, int h, size_t sstride, int cn, uint8_t* dst,
+                      size_t dstride, int b, int border);
+void warp_affine(const uint8_t* src, int w, int h, size_t sstride, int cn, uint8_t* dst,
+                 size_t dstride, const float* M, int nthreads);
+
+struct Gray {
+    int w = 0, h = 0;
+    std::vector<uint8_t> d;
+    bool empty() const { return d.empty(); }
+    void create(int w_, int h_) { w = w_; h = h_; d.assign((size_t)w * h, 0); }
+};
+
+int gftt(const uint8_t* gray, int w, int h, size_t stride, int max_corners, double quality,
+         double min_distance, int block_size, std::vector<float>& pts, int* n_candidates);
+int pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int h, size_t stride,
+           const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err, int win,
+           int max_level, int max_iters, double eps, int nthreads);
+int estimate_affine_partial2d(const float* from, const float* to, int n, double thr,
+                              int max_iters, double* model, uint8_t* inliers, int32_t* info);
+
+std::vector<float> box_filter(const std::vector<float>& path, int radius_param, bool drone);
+std::vector<float> gaussian_filter(const std::vector<float>& path, float sigma);
+std::vector<float> kalman_filter(const std::vector<float>& path);
+int adaptive_radius(const std::vector<float>& px, const std::vector<float>& py,
+                    const std::vector<float>& pa, int smoothing_radius);
+int motion_intent(const std::vector<float>& tr /* n*3 */, const float motion[3], int frame_index);
+float adaptive_strength(int intent, const float motion[3]);
+
+extern int g_threads;
+
+}  // namespace vso
+#endif

@@ -1,0 +1,283 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libvso_oracle.so).
+
+Test infrastructure: imported only from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "libvso_oracle.so")
+
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+i16p = C.POINTER(C.c_int16)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Oracle:
+    def __init__(self, lib):
+        from vsamd.capi import VsParams, VsDebugFrame
+        self.lib = lib
+        self.VsParams = VsParams
+        self.VsDebugFrame = VsDebugFrame
+        lib.vso_stab_create.restype = C.c_void_p
+        lib.vso_stab_create.argtypes = [C.POINTER(VsParams)]
+        lib.vso_stab_destroy.argtypes = [C.c_void_p]
+        lib.vso_stab_clean.argtypes = [C.c_void_p]
+        lib.vso_stab_push.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_size_t]
+        lib.vso_stab_flush.argtypes = [C.c_void_p, u8p, C.c_size_t]
+        lib.vso_stab_out_size.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, i32p]
+        lib.vso_stab_get_debug.argtypes = [C.c_void_p, C.POINTER(VsDebugFrame)]
+        lib.vso_stab_get_debug_arrays.argtypes = [C.c_void_p, f32p, f32p, u8p, u8p, f32p, u8p, i32p, i32p]
+        lib.vso_params_default.argtypes = [C.POINTER(VsParams)]
+        lib.vso_resize_linear_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_int, C.c_int, C.c_size_t]
+        lib.vso_bgr2gray.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
+        lib.vso_pyr_down.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
+        lib.vso_scharr.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i16p]
+        lib.vso_copy_make_border.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_size_t, C.c_int, C.c_int]
+        lib.vso_warp_affine.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_size_t, f32p]
+        lib.vso_warp_affine_mt.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_size_t, f32p, C.c_int]
+        lib.vso_warp_affine_nv12.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, f32p]
+        lib.vso_min_eigen.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, f32p]
+        lib.vso_gftt.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_int, f32p, i32p]
+        lib.vso_pyr_lk.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_size_t, f32p, C.c_int, f32p, u8p, f32p,
+                                   C.c_int, C.c_int, C.c_int, C.c_double]
+        lib.vso_rng_stream.argtypes = [C.c_uint64, C.POINTER(C.c_uint32), C.c_int]
+        lib.vso_estimate_affine_partial2d.argtypes = [f32p, f32p, C.c_int, C.c_double, C.c_int, f64p, u8p, i32p]
+        lib.vso_box_filter.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
+        lib.vso_gaussian_filter.argtypes = [f32p, C.c_int, C.c_float, f32p]
+        lib.vso_kalman_filter.argtypes = [f32p, C.c_int, f32p]
+        lib.vso_adaptive_radius.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int]
+        lib.vso_motion_intent.argtypes = [f32p, C.c_int, C.c_int]
+        lib.vso_set_threads.argtypes = [C.c_int]
+
+    # ---- primitives -------------------------------------------------------
+    def params(self, **kw):
+        p = self.VsParams()
+        self.lib.vso_params_default(C.byref(p))
+        for k, v in kw.items():
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+        return p
+
+    def resize(self, img, dw, dh):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((dh, dw) if cn == 1 else (dh, dw, cn), np.uint8)
+        self.lib.vso_resize_linear_u8(_p(img, u8p), w, h, w * cn, cn, _p(out, u8p), dw, dh, dw * cn)
+        return out
+
+    def bgr2gray(self, img):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        out = np.empty((h, w), np.uint8)
+        self.lib.vso_bgr2gray(_p(img, u8p), w, h, w * 3, _p(out, u8p), w)
+        return out
+
+    def analysis_gray(self, frame, aw, ah):
+        if frame.ndim == 3:
+            return self.bgr2gray(self.resize(frame, aw, ah))
+        return self.resize(frame, aw, ah)
+
+    def pyr_down(self, g):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self.lib.vso_pyr_down(_p(g, u8p), w, h, w, _p(out, u8p), out.shape[1])
+        return out
+
+    def scharr(self, g):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        out = np.empty((h, w, 2), np.int16)
+        self.lib.vso_scharr(_p(g, u8p), w, h, w, _p(out, i16p))
+        return out
+
+    def copy_make_border(self, img, b, border):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((h + 2 * b, w + 2 * b) if cn == 1 else (h + 2 * b, w + 2 * b, cn), np.uint8)
+        self.lib.vso_copy_make_border(_p(img, u8p), w, h, w * cn, cn, _p(out, u8p), (w + 2 * b) * cn, b, border)
+        return out
+
+    def warp_affine(self, img, M, threads=1):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        M = np.ascontiguousarray(M, np.float32).reshape(6)
+        out = np.empty_like(img)
+        self.lib.vso_warp_affine_mt(_p(img, u8p), w, h, w * cn, cn, _p(out, u8p), w * cn, _p(M, f32p), threads)
+        return out
+
+    def warp_affine_nv12(self, img, w, h, M):
+        img = np.ascontiguousarray(img)
+        M = np.ascontiguousarray(M, np.float32).reshape(6)
+        out = np.empty_like(img)
+        self.lib.vso_warp_affine_nv12(_p(img, u8p), w, h, w, _p(out, u8p), w, _p(M, f32p))
+        return out
+
+    def min_eigen(self, g, block_size=3):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        out = np.empty((h, w), np.float32)
+        self.lib.vso_min_eigen(_p(g, u8p), w, h, w, block_size, _p(out, f32p))
+        return out
+
+    def gftt(self, g, max_corners, quality, min_distance, block_size=3):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        cap = max_corners if max_corners > 0 else w * h
+        out = np.zeros((cap, 2), np.float32)
+        nc = C.c_int32(0)
+        n = self.lib.vso_gftt(_p(g, u8p), w, h, w, max_corners, quality, min_distance, block_size,
+                              _p(out, f32p), C.byref(nc))
+        return out[:n].copy(), nc.value
+
+    def pyr_lk(self, prev, nxt, pts, win=15, max_level=2, iters=20, eps=0.03):
+        prev = np.ascontiguousarray(prev)
+        nxt = np.ascontiguousarray(nxt)
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        n = pts.shape[0]
+        h, w = prev.shape
+        out = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        self.lib.vso_pyr_lk(_p(prev, u8p), _p(nxt, u8p), w, h, w, _p(pts, f32p), n, _p(out, f32p),
+                            _p(st, u8p), _p(err, f32p), win, max_level, iters, eps)
+        return out, st, err
+
+    def rng_stream(self, seed, n):
+        out = np.zeros(n, np.uint32)
+        self.lib.vso_rng_stream(seed, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return out
+
+    def estimate_affine_partial2d(self, a, b, thr=5.0, max_iters=500):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(b, np.float32).reshape(-1, 2)
+        n = a.shape[0]
+        model = np.zeros(6, np.float64)
+        inl = np.zeros(max(n, 1), np.uint8)
+        info = np.zeros(4, np.int32)
+        ok = self.lib.vso_estimate_affine_partial2d(_p(a, f32p), _p(b, f32p), n, thr, max_iters,
+                                                     _p(model, f64p), _p(inl, u8p), _p(info, i32p))
+        return ok, model, inl[:n], info
+
+    def box_filter(self, path, radius_param, drone=False):
+        path = np.ascontiguousarray(path, np.float32)
+        out = np.empty_like(path)
+        self.lib.vso_box_filter(_p(path, f32p), len(path), radius_param, int(drone), _p(out, f32p))
+        return out
+
+    def gaussian_filter(self, path, sigma):
+        path = np.ascontiguousarray(path, np.float32)
+        out = np.empty_like(path)
+        self.lib.vso_gaussian_filter(_p(path, f32p), len(path), sigma, _p(out, f32p))
+        return out
+
+    def kalman_filter(self, path):
+        path = np.ascontiguousarray(path, np.float32)
+        out = np.empty_like(path)
+        self.lib.vso_kalman_filter(_p(path, f32p), len(path), _p(out, f32p))
+        return out
+
+    def adaptive_radius(self, px, py, pa, smoothing_radius):
+        px, py, pa = [np.ascontiguousarray(v, np.float32) for v in (px, py, pa)]
+        return self.lib.vso_adaptive_radius(_p(px, f32p), _p(py, f32p), _p(pa, f32p), len(px), smoothing_radius)
+
+    def motion_intent(self, transforms, frame_index):
+        t = np.ascontiguousarray(transforms, np.float32).reshape(-1, 3)
+        return self.lib.vso_motion_intent(_p(t, f32p), t.shape[0], frame_index)
+
+    def stabilizer(self, params):
+        return OracleStab(self, params)
+
+
+class OracleStab:
+    """vs::Stabilizer restated on the CPU (oracle/vso_stabilizer.cpp)."""
+
+    def __init__(self, o, params):
+        self.o = o
+        self.lib = o.lib
+        self.h = self.lib.vso_stab_create(C.byref(params))
+
+    def close(self):
+        if self.h:
+            self.lib.vso_stab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def out_shape(self, frame, fmt):
+        w = frame.shape[1]
+        h = frame.shape[0] if fmt != 1 else frame.shape[0] * 2 // 3
+        ow, oh = C.c_int32(), C.c_int32()
+        self.lib.vso_stab_out_size(self.h, w, h, C.byref(ow), C.byref(oh))
+        if fmt == 0:
+            return (oh.value, ow.value, 3)
+        if fmt == 1:
+            return (oh.value * 3 // 2, ow.value)
+        return (oh.value, ow.value)
+
+    def push(self, frame, fmt=0):
+        frame = np.ascontiguousarray(frame)
+        w = frame.shape[1]
+        h = frame.shape[0] if fmt != 1 else frame.shape[0] * 2 // 3
+        cn = 3 if fmt == 0 else 1
+        out = np.zeros(self.out_shape(frame, fmt), np.uint8)
+        r = self.lib.vso_stab_push(self.h, _p(frame, u8p), w, h, w * cn, fmt, _p(out, u8p), out.shape[1] * cn)
+        return out if r else None
+
+    def flush(self, like, fmt=0):
+        cn = 3 if fmt == 0 else 1
+        out = np.zeros(self.out_shape(like, fmt), np.uint8)
+        r = self.lib.vso_stab_flush(self.h, _p(out, u8p), out.shape[1] * cn)
+        return out if r else None
+
+    def debug(self):
+        d = self.o.VsDebugFrame()
+        self.lib.vso_stab_get_debug(self.h, C.byref(d))
+        return d
+
+    def debug_arrays(self):
+        d = self.debug()
+        prev = np.zeros((max(d.n_prev, 1), 2), np.float32)
+        cur = np.zeros((max(d.n_prev, 1), 2), np.float32)
+        st = np.zeros(max(d.n_prev, 1), np.uint8)
+        inl = np.zeros(max(d.n_valid, 1), np.uint8)
+        det = np.zeros((max(d.n_detected, 1), 2), np.float32)
+        gray = np.zeros(960 * 540, np.uint8)
+        aw, ah = C.c_int32(), C.c_int32()
+        self.lib.vso_stab_get_debug_arrays(self.h, _p(prev, f32p), _p(cur, f32p), _p(st, u8p), _p(inl, u8p),
+                                           _p(det, f32p), _p(gray, u8p), C.byref(aw), C.byref(ah))
+        return dict(prev=prev[:d.n_prev], curr=cur[:d.n_prev], status=st[:d.n_prev], inliers=inl[:d.n_valid],
+                    detected=det[:d.n_detected] if d.detected else det[:0],
+                    gray=gray[:aw.value * ah.value].reshape(ah.value, aw.value))
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        if not os.path.exists(LIB):
+            build()
+        _cached = Oracle(C.CDLL(LIB))
+    return _cached

@@ -1,0 +1,191 @@
+"""HIP path vs CPU oracle, through the C ABI (libvideo-stab.so), on a real MI355X.
+
+Bar (north_star): bit-exact for every integer/byte/index output (gray, pyramid,
+derivatives, warped pixels under an identical matrix, feature lists and their
+order, LK status, inlier masks, chosen hypothesis); float outputs are compared
+bit-exactly where both sides run the same IEEE operation sequence (eigenvalue
+map, LK positions, refined model) and within the stated tolerance where a libm
+function is involved (atan2f / sinf / cosf: 1e-6 relative).
+"""
+import numpy as np
+import pytest
+
+from vsamd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def clip_small():
+    return synth.make_clip(synth.SEED_CONFIG1, 320, 240, 6)
+
+
+@pytest.fixture(scope="module")
+def grays(oracle, clip_small):
+    return [oracle.analysis_gray(f, 480, 360) for f in clip_small]
+
+
+# ---- W1 warpAffine -----------------------------------------------------------
+MATS = [
+    [1, 0, 0, 0, 1, 0],
+    [1, 0, 5, 0, 1, -3],
+    [0.99995, -0.01, 3.25, 0.01, 0.99995, -7.5],
+    [0.9986, 0.0523, -14.2, -0.0523, 0.9986, 9.9],      # 3 degrees
+    [0.7071, -0.7071, 80.0, 0.7071, 0.7071, -40.0],       # 45 degrees: LDS bbox overflow -> direct path
+    [1.5, 0.0, -20.0, 0.0, 1.5, 10.0],                    # zoom in
+    [0.5, 0.0, 30.0, 0.0, 0.5, 20.0],                     # zoom out (wide source footprint)
+    [1, 0, 1000.0, 0, 1, 0],                              # everything out of frame
+]
+
+
+@pytest.mark.parametrize("M", MATS)
+def test_warp_bgr_bit_exact(gpu, oracle, clip_small, M):
+    img = clip_small[0]
+    assert np.array_equal(gpu.warp_affine(img, M), oracle.warp_affine(img, M))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (17, 129), (240, 321), (33, 130)])
+def test_warp_ragged_sizes(gpu, oracle, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    h, w = shape
+    M = [0.9998, 0.02, 1.3, -0.02, 0.9998, -0.6]
+    for cn in (1, 3):
+        img = rng.integers(0, 256, (h, w) if cn == 1 else (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(gpu.warp_affine(img, M), oracle.warp_affine(img, M)), (shape, cn)
+
+
+def test_warp_batch_matches_single(gpu, oracle, clip_small):
+    imgs = np.stack(clip_small[:5])
+    Ms = np.array([[np.cos(a), -np.sin(a), dx, np.sin(a), np.cos(a), dy]
+                   for a, dx, dy in [(0.0, 0, 0), (0.002, 1.5, -2), (-0.004, -3, 4), (0.01, 7, 7), (0.0, -9.25, 0.5)]],
+                  np.float32)
+    out = gpu.warp_affine(imgs, Ms)
+    for i in range(5):
+        assert np.array_equal(out[i], oracle.warp_affine(imgs[i], Ms[i])), i
+
+
+def test_warp_full_hd_properties(gpu, oracle):
+    """BASELINE config 2 size: identity = exact copy; integer shift = exact shift;
+    a checksum of the rotated frame equals the oracle's."""
+    world = synth.make_world(synth.SEED_CONFIG2, 1920, 1080)
+    img = synth.render_frame(world, 1920, 1080, (300 * 256, 280 * 256, 90))
+    assert np.array_equal(gpu.warp_affine(img, [1, 0, 0, 0, 1, 0]), img)
+    out = gpu.warp_affine(img, [1, 0, 16, 0, 1, 9])
+    assert np.array_equal(out[9:, 16:], img[:-9, :-16]) and out[:9].max() == 0 and out[:, :16].max() == 0
+    M = [0.999998, -0.002, 2.75, 0.002, 0.999998, -1.25]
+    assert np.array_equal(gpu.warp_affine(img, M), oracle.warp_affine(img, M, threads=8))
+
+
+def test_warp_nv12(gpu, oracle, clip_small):
+    nv = synth.bgr_to_nv12(clip_small[0])
+    M = [0.99998, -0.006, 2.5, 0.006, 0.99998, -3.0]
+    assert np.array_equal(gpu.warp_affine_nv12(nv, 320, 240, M), oracle.warp_affine_nv12(nv, 320, 240, M))
+
+
+# ---- G1/G2 resize + gray --------------------------------------------------------
+@pytest.mark.parametrize("src,dst", [((240, 320), (480, 360)),      # upscale (config 1 regime)
+                                     ((240, 320), (160, 120)),      # exact 2x
+                                     ((240, 320), (80, 60)),        # 4x (first-frame regime)
+                                     ((241, 323), (100, 77))])      # odd sizes
+def test_resize_gray_bgr(gpu, oracle, src, dst):
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (src[0], src[1], 3), dtype=np.uint8)
+    dw, dh = dst
+    assert np.array_equal(gpu.resize_gray(img, dw, dh), oracle.analysis_gray(img, dw, dh))
+
+
+def test_resize_gray_single_channel(gpu, oracle):
+    rng = np.random.default_rng(12)
+    g = rng.integers(0, 256, (270, 480), dtype=np.uint8)
+    assert np.array_equal(gpu.resize_gray(g, 960, 540), oracle.resize(g, 960, 540))   # G2: 480x270 -> 960x540
+    assert np.array_equal(gpu.resize_gray(g, 240, 135), oracle.resize(g, 240, 135))
+
+
+def test_resize_gray_full_hd(gpu, oracle):
+    world = synth.make_world(synth.SEED_CONFIG2, 1920, 1080)
+    img = synth.render_frame(world, 1920, 1080, (256 * 256, 256 * 256, 0))
+    assert np.array_equal(gpu.resize_gray(img, 960, 540), oracle.analysis_gray(img, 960, 540))
+    assert np.array_equal(gpu.resize_gray(img, 480, 270), oracle.analysis_gray(img, 480, 270))
+
+
+# ---- pyramid + derivatives ------------------------------------------------------
+@pytest.mark.parametrize("shape", [(360, 480), (135, 241), (7, 9), (2, 2)])
+def test_pyr_down_and_scharr(gpu, oracle, shape):
+    rng = np.random.default_rng(shape[0])
+    g = rng.integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(gpu.pyr_down(g), oracle.pyr_down(g))
+    assert np.array_equal(gpu.scharr(g), oracle.scharr(g))
+
+
+# ---- F1 goodFeaturesToTrack -----------------------------------------------------
+@pytest.mark.parametrize("args", [(200, 0.02, 15.0, 3), (200, 0.01, 30.0, 3), (50, 0.05, 8.0, 5), (400, 0.01, 5.0, 3),
+                                  (30, 0.01, 0.0, 3)])
+def test_gftt_exact_list_and_order(gpu, oracle, grays, args):
+    g = grays[0]
+    pts_o, _ = oracle.gftt(g, *args)
+    pts_g, eig_g = gpu.gftt(g, *args, want_eig=True)
+    assert np.array_equal(eig_g.view(np.uint32), oracle.min_eigen(g, args[3]).view(np.uint32))   # float map bit-exact
+    assert pts_g.shape == pts_o.shape and np.array_equal(pts_g, pts_o)
+
+
+def test_gftt_flat_image_returns_nothing(gpu, oracle):
+    g = np.full((120, 160), 90, np.uint8)
+    assert len(gpu.gftt(g, 100, 0.01, 10.0, 3)) == 0
+    assert len(oracle.gftt(g, 100, 0.01, 10.0, 3)[0]) == 0
+
+
+def test_gftt_many_candidates_chunked_sort(gpu, oracle):
+    """> 8192 local maxima: exercises the chunked selection path of the sort kernel."""
+    rng = np.random.default_rng(99)
+    g = rng.integers(0, 256, (300, 400), dtype=np.uint8)
+    pts_o, nc = oracle.gftt(g, 3000, 0.0001, 3.0, 3)
+    assert nc > 8192
+    pts_g = gpu.gftt(g, 3000, 0.0001, 3.0, 3)
+    assert np.array_equal(pts_g, pts_o)
+
+
+# ---- L1 pyramidal LK ---------------------------------------------------------------
+@pytest.mark.parametrize("win,levels,iters,eps", [(15, 2, 20, 0.03), (21, 2, 20, 0.03), (21, 3, 30, 0.01)])
+def test_pyr_lk_exact(gpu, oracle, grays, win, levels, iters, eps):
+    g0, g1 = grays[0], grays[1]
+    pts, _ = oracle.gftt(g0, 200, 0.02, 15.0, 3)
+    # add points that leave the image / sit on flat areas to exercise status=0 paths
+    extra = np.array([[0.5, 0.5], [479.0, 359.0], [-30.0, 10.0], [240.3, 180.7], [600.0, 20.0]], np.float32)
+    pts = np.vstack([pts, extra])
+    no, so, eo = oracle.pyr_lk(g0, g1, pts, win, levels, iters, eps)
+    ng, sg, eg = gpu.pyr_lk(g0, g1, pts, win, levels, iters, eps)
+    assert np.array_equal(sg, so)
+    assert np.array_equal(ng.view(np.uint32), no.view(np.uint32))     # positions bit-exact
+    assert np.array_equal(eg.view(np.uint32), eo.view(np.uint32))
+
+
+# ---- R1 RANSAC ------------------------------------------------------------------------
+def _correspondences(seed, n, n_out, noise=0.2):
+    rng = np.random.default_rng(seed)
+    src = np.stack([rng.integers(5, 950, n), rng.integers(5, 530, n)], 1).astype(np.float32)
+    ang = rng.uniform(-0.02, 0.02)
+    a, b = np.cos(ang), np.sin(ang)
+    tx, ty = rng.uniform(-8, 8, 2)
+    dst = np.stack([a * src[:, 0] - b * src[:, 1] + tx, b * src[:, 0] + a * src[:, 1] + ty], 1)
+    dst += rng.normal(0, noise, dst.shape)
+    idx = rng.choice(n, n_out, replace=False)
+    dst[idx] += rng.uniform(10, 60, (n_out, 2)) * rng.choice([-1, 1], (n_out, 2))
+    return src, dst.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,n_out", [(200, 0), (200, 60), (200, 150), (57, 20), (4, 0), (3, 0), (2, 0), (400, 390)])
+def test_ransac_exact(gpu, oracle, n, n_out):
+    src, dst = _correspondences(n * 7 + n_out, n, n_out)
+    oko, mo, io, fo = oracle.estimate_affine_partial2d(src, dst)
+    okg, mg, ig, fg = gpu.estimate_affine_partial2d(src, dst)
+    assert okg == oko
+    assert np.array_equal(fg, fo)                     # ok, kept hypothesis, iterations run, inlier count
+    assert np.array_equal(ig, io)                     # inlier mask
+    if oko:
+        assert np.array_equal(mg.view(np.uint64), mo.view(np.uint64))   # refined model, double, bit-exact
+
+
+def test_ransac_too_few_points(gpu, oracle):
+    src = np.array([[3, 4]], np.float32)
+    okg, mg, ig, fg = gpu.estimate_affine_partial2d(src, src)
+    assert okg == 0 and np.all(np.isnan(mg)) and fg[1] == -1

@@ -1,0 +1,405 @@
+// Shi-Tomasi corner detector for gfx950: device counterpart of
+//   cv::goodFeaturesToTrack(gray, corners, maxCorners, quality, minDistance,
+//                           noArray(), blockSize)
+// as called at /root/reference/src/Stabilizer.cpp:355-357 (first frame) and
+// :740-744 (every second frame; 200, 0.02, 15.0, 3).  Three launches:
+//
+//  1. min_eigen_kernel  - fused Sobel -> covariance -> box -> lambda_min on a
+//     64x16 tile staged through LDS (gray read once, the 2 MB eigenvalue map
+//     written once) + chip-wide max via one atomic per workgroup.
+//  2. nms_kernel        - threshold(TOZERO, max*quality), 3x3 dilate compare,
+//     wave-aggregated append of (value,index) keys.
+//  3. select_kernel     - ONE workgroup: bitonic sort of the keys in LDS
+//     (value descending, ties -> higher address first, i.e. OpenCV's
+//     greaterThanPtr) followed by the sequential-equivalent greedy
+//     min-distance selection: one wave takes 64 candidates per step, tests
+//     them against an LDS cell grid, and resolves the in-step order with
+//     ballot / first-set-bit, so the accepted list is exactly the one the
+//     serial loop produces.
+//
+// Float definitions (no FMA contraction, see oracle/vso_gftt.cpp header):
+//   Dx = ((r0+r2)*f1 + r1*f0), Dy = t2 - t0, f1=(float)(1/(4*bs*255)), f0=2*f1
+//   box sums in double (exact), lambda = (a+c) - sqrtf((a-c)*(a-c) + b*b).
+#include "vs_common.h"
+
+namespace vsd {
+namespace {
+
+constexpr int TW = 64, TH = 16, NT = 256;
+constexpr int MAX_BS = 7;
+constexpr int GW_MAX = TW + MAX_BS - 1 + 2, GH_MAX = TH + MAX_BS - 1 + 2;
+constexpr int CW_MAX = TW + MAX_BS - 1, CH_MAX = TH + MAX_BS - 1;
+
+constexpr int SORT_CAP = 8192;
+constexpr int CELLS_MAX = 2560;
+constexpr int SLOTS = 4;
+constexpr int ACC_MAX = 4096;
+constexpr int SEL_NT = 1024;
+
+__device__ __forceinline__ uint32_t order_key(float v) {
+    uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+__global__ __launch_bounds__(NT) void min_eigen_kernel(const uint8_t* __restrict__ gray, size_t stride, int w,
+                                                       int h, int bs, float f1, float* __restrict__ eig,
+                                                       uint32_t* __restrict__ max_key) {
+    __shared__ uint8_t g[GH_MAX][GW_MAX + 2];
+    __shared__ float cxx[CH_MAX][CW_MAX + 1], cxy[CH_MAX][CW_MAX + 1], cyy[CH_MAX][CW_MAX + 1];
+    __shared__ uint32_t smax[NT / 64];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int anchor = bs / 2, hi = bs - 1 - anchor;
+    const int gx0 = x0 - anchor - 1, gy0 = y0 - anchor - 1;   // image coords of g[0][0]
+    const int GW = TW + bs - 1 + 2, GH = TH + bs - 1 + 2;
+    const int CW = TW + bs - 1, CH = TH + bs - 1;
+    const float f0 = 2.f * f1;
+    for (int i = tid; i < GW * GH; i += NT) {
+        const int ly = i / GW, lx = i - ly * GW;
+        g[ly][lx] = gray[(size_t)reflect101(gy0 + ly, h) * stride + reflect101(gx0 + lx, w)];
+    }
+    __syncthreads();
+    // covariance at every position the tile's box windows touch; positions
+    // outside the image take the value at the REFLECT_101 position
+    for (int i = tid; i < CW * CH; i += NT) {
+        const int cy = i / CW, cx = i - cy * CW;
+        const int px = x0 - anchor + cx, py = y0 - anchor + cy;
+        float vxx = 0.f, vxy = 0.f, vyy = 0.f;
+        if (px >= -anchor && px <= w - 1 + hi && py >= -anchor && py <= h - 1 + hi) {
+            const int qx = reflect101(px, w) - gx0, qy = reflect101(py, h) - gy0;   // LDS coords
+            const int a00 = g[qy - 1][qx - 1], a01 = g[qy - 1][qx], a02 = g[qy - 1][qx + 1];
+            const int a10 = g[qy][qx - 1], a11 = g[qy][qx], a12 = g[qy][qx + 1];
+            const int a20 = g[qy + 1][qx - 1], a21 = g[qy + 1][qx], a22 = g[qy + 1][qx + 1];
+            const float r0 = (float)(a02 - a00), r1 = (float)(a12 - a10), r2 = (float)(a22 - a20);
+            const float dx = (r0 + r2) * f1 + r1 * f0;
+            const float t0 = (float)a01 * f0 + (float)(a00 + a02) * f1;
+            const float t2 = (float)a21 * f0 + (float)(a20 + a22) * f1;
+            const float dy = t2 - t0;
+            (void)a11;
+            vxx = dx * dx; vxy = dx * dy; vyy = dy * dy;
+        }
+        cxx[cy][cx] = vxx; cxy[cy][cx] = vxy; cyy[cy][cx] = vyy;
+    }
+    __syncthreads();
+    uint32_t kmax = 0;
+    for (int i = tid; i < TW * TH; i += NT) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x < w && y < h) {
+            double s0 = 0, s1 = 0, s2 = 0;
+            for (int j = 0; j < bs; j++) {
+                double r0 = 0, r1 = 0, r2 = 0;
+                for (int k = 0; k < bs; k++) {
+                    r0 += (double)cxx[ty + j][tx + k];
+                    r1 += (double)cxy[ty + j][tx + k];
+                    r2 += (double)cyy[ty + j][tx + k];
+                }
+                s0 += r0; s1 += r1; s2 += r2;
+            }
+            const float a = (float)s0 * 0.5f, b = (float)s1, c = (float)s2 * 0.5f;
+            const float d = (a - c) * (a - c) + b * b;
+            const float e = (a + c) - sqrtf(d);
+            eig[(size_t)y * w + x] = e;
+            const uint32_t k = order_key(e);
+            kmax = k > kmax ? k : kmax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(kmax, off, 64);
+        kmax = o > kmax ? o : kmax;
+    }
+    if ((tid & 63) == 0) smax[tid >> 6] = kmax;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = smax[0];
+        for (int i = 1; i < NT / 64; i++) m = smax[i] > m ? smax[i] : m;
+        atomicMax(max_key, m);
+    }
+}
+
+__global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ eig, int w, int h, double quality,
+                                                 const uint32_t* __restrict__ max_key,
+                                                 unsigned long long* __restrict__ cand, int cap,
+                                                 int32_t* __restrict__ counters) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+    const float maxv = key_to_float(*max_key);
+    const float thr = (float)((double)maxv * quality);
+    const float* r = eig + (size_t)y * w + x;
+    const float v = r[0] > thr ? r[0] : 0.f;   // THRESH_TOZERO
+    if (v == 0.f) return;
+    float m = v;
+#pragma unroll
+    for (int j = -1; j <= 1; j++)
+#pragma unroll
+        for (int i = -1; i <= 1; i++) {
+            const float n = r[j * w + i];
+            const float tn = n > thr ? n : 0.f;
+            m = tn > m ? tn : m;
+        }
+    if (v != m) return;
+    const int pos = atomicAdd(&counters[0], 1);
+    if (pos < cap) cand[pos] = ((unsigned long long)order_key(v) << 32) | (uint32_t)(y * w + x);
+    else counters[2] = 1;
+}
+
+struct SelArgs {
+    const unsigned long long* cand;
+    int32_t* counters;
+    int cap, w, h, max_corners;
+    double min_dist2;      // minDistance^2 (double, as cv compares it)
+    int use_dist;          // minDistance >= 1
+    int cell, gw, gh;
+    float* out_pts;
+    int32_t* out_count;
+};
+
+__global__ __launch_bounds__(SEL_NT) void select_kernel(SelArgs a) {
+    __shared__ unsigned long long keys[SORT_CAP];
+    __shared__ uint32_t cell_cnt[CELLS_MAX];
+    __shared__ uint32_t cell_pts[CELLS_MAX * SLOTS];
+    __shared__ uint32_t acc_xy[ACC_MAX];
+    __shared__ int s_m, s_nacc, s_done, s_cnt, s_overflow;
+    __shared__ unsigned long long s_upper;
+    const int tid = threadIdx.x;
+    int ncand = a.counters[0];
+    if (ncand > a.cap) ncand = a.cap;
+    const int ncells = a.gw * a.gh;
+    const bool grid_ok = a.use_dist && ncells <= CELLS_MAX;
+    if (grid_ok) for (int i = tid; i < ncells; i += SEL_NT) cell_cnt[i] = 0;
+    if (tid == 0) { s_nacc = 0; s_done = 0; s_upper = ~0ull; s_overflow = 0; }
+    __syncthreads();
+
+    while (true) {
+        // ---- choose the next chunk: the (up to) SORT_CAP largest keys below s_upper
+        const unsigned long long upper = s_upper;
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        int local = 0;
+        for (int i = tid; i < ncand; i += SEL_NT) local += a.cand[i] < upper ? 1 : 0;
+        if (local) atomicAdd(&s_cnt, local);
+        __syncthreads();
+        const int remaining = s_cnt;
+        if (remaining == 0) break;
+        unsigned long long lo = 0;   // keys in [lo, upper) form the chunk
+        if (remaining > SORT_CAP) {
+            // largest T with count(key in [T, upper)) >= SORT_CAP ... found bit by bit;
+            // keys are unique, so the chunk [T, upper) then holds exactly SORT_CAP keys
+            unsigned long long T = 0;
+            for (int bit = 63; bit >= 0; bit--) {
+                const unsigned long long trial = T | (1ull << bit);
+                __syncthreads();
+                if (tid == 0) s_cnt = 0;
+                __syncthreads();
+                int c = 0;
+                if (trial < upper)
+                    for (int i = tid; i < ncand; i += SEL_NT) { const unsigned long long k = a.cand[i]; c += (k >= trial && k < upper) ? 1 : 0; }
+                if (c) atomicAdd(&s_cnt, c);
+                __syncthreads();
+                if (trial < upper && s_cnt >= SORT_CAP) T = trial;
+            }
+            lo = T;
+        }
+        __syncthreads();
+        if (tid == 0) s_m = 0;
+        __syncthreads();
+        for (int i = tid; i < ncand; i += SEL_NT) {
+            const unsigned long long k = a.cand[i];
+            if (k >= lo && k < upper) {
+                const int p = atomicAdd(&s_m, 1);
+                if (p < SORT_CAP) keys[p] = k;
+            }
+        }
+        __syncthreads();
+        const int m = s_m < SORT_CAP ? s_m : SORT_CAP;
+        int np2 = 64;
+        while (np2 < m) np2 <<= 1;
+        for (int i = m + tid; i < np2; i += SEL_NT) keys[i] = 0ull;
+        __syncthreads();
+        // ---- bitonic sort, descending
+        for (int k = 2; k <= np2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < np2; i += SEL_NT) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long ki = keys[i], kj = keys[ixj];
+                        const bool desc = (i & k) == 0;
+                        if (desc ? (ki < kj) : (ki > kj)) { keys[i] = kj; keys[ixj] = ki; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- greedy selection by wave 0 (sequential-equivalent)
+        if (tid < 64) {
+            const int lane = tid;
+            int nacc = s_nacc;
+            volatile uint32_t* vcnt = cell_cnt;
+            volatile uint32_t* vpts = cell_pts;
+            volatile uint32_t* vacc = acc_xy;
+            bool full = false;
+            for (int base = 0; base < m && !full; base += 64) {
+                const int i = base + lane;
+                const bool has = i < m;
+                const unsigned long long key = has ? keys[i] : 0ull;
+                const int idx = (int)(uint32_t)key;
+                const int y = idx / a.w, x = idx - y * a.w;
+                int xc = 0, yc = 0;
+                bool ok = has;
+                if (a.use_dist) {
+                    xc = x / a.cell; yc = y / a.cell;
+                    if (ok) {
+                        if (grid_ok) {
+                            const int cx1 = xc > 0 ? xc - 1 : 0, cx2 = xc + 1 < a.gw ? xc + 1 : a.gw - 1;
+                            const int cy1 = yc > 0 ? yc - 1 : 0, cy2 = yc + 1 < a.gh ? yc + 1 : a.gh - 1;
+                            for (int cy = cy1; cy <= cy2 && ok; cy++)
+                                for (int cx = cx1; cx <= cx2 && ok; cx++) {
+                                    const int c = cy * a.gw + cx;
+                                    int cnt = (int)vcnt[c];
+                                    cnt = cnt < SLOTS ? cnt : SLOTS;
+                                    for (int s = 0; s < cnt; s++) {
+                                        const uint32_t p = vpts[c * SLOTS + s];
+                                        const int dx = x - (int)(p & 0xFFFFu), dy = y - (int)(p >> 16);
+                                        if ((double)(dx * dx + dy * dy) < a.min_dist2) { ok = false; break; }
+                                    }
+                                }
+                        } else {
+                            for (int s = 0; s < nacc && ok; s++) {
+                                const uint32_t p = vacc[s];
+                                const int ax = (int)(p & 0xFFFFu), ay = (int)(p >> 16);
+                                const int dcx = ax / a.cell - xc, dcy = ay / a.cell - yc;
+                                if (dcx >= -1 && dcx <= 1 && dcy >= -1 && dcy <= 1) {
+                                    const int dx = x - ax, dy = y - ay;
+                                    if ((double)(dx * dx + dy * dy) < a.min_dist2) ok = false;
+                                }
+                            }
+                        }
+                    }
+                }
+                unsigned long long mask = __ballot(ok);
+                while (mask) {
+                    const int j = __ffsll((long long)mask) - 1;
+                    const int xj = __shfl(x, j, 64), yj = __shfl(y, j, 64);
+                    const int xcj = __shfl(xc, j, 64), ycj = __shfl(yc, j, 64);
+                    if (lane == j) {
+                        a.out_pts[2 * nacc] = (float)x;
+                        a.out_pts[2 * nacc + 1] = (float)y;
+                        const uint32_t packed = (uint32_t)x | ((uint32_t)y << 16);
+                        if (nacc < ACC_MAX) vacc[nacc] = packed;
+                        if (grid_ok) {
+                            const int c = yc * a.gw + xc;
+                            const uint32_t slot = vcnt[c];
+                            if (slot < (uint32_t)SLOTS) vpts[c * SLOTS + slot] = packed;
+                            else s_overflow = 1;
+                            vcnt[c] = slot + 1;
+                        }
+                        ok = false;
+                    }
+                    nacc++;
+                    if (nacc == a.max_corners) { full = true; break; }
+                    if (ok && a.use_dist) {
+                        const int dcx = xc - xcj, dcy = yc - ycj;
+                        if (dcx >= -1 && dcx <= 1 && dcy >= -1 && dcy <= 1) {
+                            const int dx = x - xj, dy = y - yj;
+                            if ((double)(dx * dx + dy * dy) < a.min_dist2) ok = false;
+                        }
+                    }
+                    mask = __ballot(ok);
+                }
+            }
+            if (lane == 0) {
+                s_nacc = nacc;
+                if (full) s_done = 1;
+                if (m > 0) s_upper = keys[m - 1];   // smallest key of this chunk
+                else s_done = 1;
+            }
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        *a.out_count = s_nacc;
+        a.counters[3] = s_nacc;
+        if (s_overflow) a.counters[2] = 2;
+    }
+}
+
+}  // namespace
+
+size_t gftt_work_bytes(int w, int h, int cap) {
+    return (size_t)w * h * 4 + (size_t)cap * 8 + 64 + 256;
+}
+
+void gftt_work_carve(void* base, int w, int h, int cap, GfttWork* out) {
+    uint8_t* p = (uint8_t*)base;
+    out->eig = (float*)p;
+    p += ((size_t)w * h * 4 + 63) & ~(size_t)63;
+    out->cand = (uint64_t*)p;
+    p += (size_t)cap * 8;
+    out->counters = (int32_t*)p;
+    out->cap = cap;
+}
+
+int launch_gftt(const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
+                double min_distance, int block_size, const GfttWork& wk, float* d_pts,
+                int32_t* d_count, hipStream_t st) {
+    if (!d_gray || !d_pts || !d_count || w < 3 || h < 3 || w > 65535 || h > 65535 || max_corners <= 0 ||
+        max_corners > ACC_MAX || block_size < 1 || block_size > MAX_BS || !wk.eig || !wk.cand ||
+        !wk.counters || wk.cap <= 0) {
+        set_last_error("gftt: invalid argument (1 <= blockSize <= 7, 0 < maxCorners <= 4096)");
+        return VS_ERR_INVALID_ARG;
+    }
+    VS_HIP_TRY(hipMemsetAsync(wk.counters, 0, 64, st));
+    double scale = (double)(1 << 2) * block_size * 255.0;
+    scale = 1.0 / scale;
+    const float f1 = (float)scale;
+    dim3 g1((w + TW - 1) / TW, (h + TH - 1) / TH);
+    hipLaunchKernelGGL(min_eigen_kernel, g1, dim3(NT), 0, st, d_gray, stride, w, h, block_size, f1, wk.eig,
+                       (uint32_t*)&wk.counters[1]);
+    dim3 g2((w + NT - 1) / NT, h);
+    hipLaunchKernelGGL(nms_kernel, g2, dim3(NT), 0, st, wk.eig, w, h, quality, (const uint32_t*)&wk.counters[1],
+                       (unsigned long long*)wk.cand, wk.cap, wk.counters);
+    SelArgs a;
+    a.cand = (const unsigned long long*)wk.cand;
+    a.counters = wk.counters;
+    a.cap = wk.cap; a.w = w; a.h = h; a.max_corners = max_corners;
+    a.use_dist = min_distance >= 1 ? 1 : 0;
+    a.min_dist2 = min_distance * min_distance;
+    a.cell = a.use_dist ? (int)lrint(min_distance) : 1;
+    a.gw = (w + a.cell - 1) / a.cell;
+    a.gh = (h + a.cell - 1) / a.cell;
+    a.out_pts = d_pts; a.out_count = d_count;
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_NT), 0, st, a);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+int run_gftt_op(const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
+                double min_distance, int block_size, float* d_pts, int32_t* d_count, float* d_eig,
+                hipStream_t st) {
+    if (w <= 0 || h <= 0) { set_last_error("gftt: invalid size"); return VS_ERR_INVALID_ARG; }
+    const int cap = w * h / 4 + 64;   // a 3x3 local maximum excludes its 8 neighbours
+    void* scratch = nullptr;
+    VS_HIP_TRY(hipMalloc(&scratch, gftt_work_bytes(w, h, cap)));
+    GfttWork wk;
+    gftt_work_carve(scratch, w, h, cap, &wk);
+    int rc = launch_gftt(d_gray, stride, w, h, max_corners, quality, min_distance, block_size, wk, d_pts, d_count, st);
+    if (rc == VS_OK && d_eig) {
+        hipError_t e = hipMemcpyAsync(d_eig, wk.eig, (size_t)w * h * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = VS_ERR_HIP; }
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    hipFree(scratch);
+    if (rc == VS_OK && e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = VS_ERR_HIP; }
+    return rc;
+}
+
+}  // namespace vsd

@@ -1,0 +1,179 @@
+// Fused cv::resize(INTER_LINEAR) + cv::cvtColor(BGR2GRAY): the analysis-image
+// producer of /root/reference/src/Stabilizer.cpp:304-305 (first frame, 480x270)
+// and :448-450 (every frame, 960x540), plus the single-channel resize of
+// :598-603.  Reads the full-resolution frame exactly once and writes only the
+// small gray image (the reference materialises a 3-channel intermediate).
+//
+// Integer arithmetic of the OpenCV 8-bit paths:
+//  * exact 2x decimation -> INTER_AREA fast path: (s00+s01+s10+s11+2)>>2
+//  * otherwise 11-bit horizontal coefficients, vertical pass
+//      (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2
+//  * gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
+#include "vs_common.h"
+
+namespace vsd {
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ uint32_t bgr_to_gray(uint32_t b, uint32_t g, uint32_t r) {
+    return (b * 3735u + g * 19235u + r * 9798u + (1u << 14)) >> 15;
+}
+
+// ---- exact 2x, BGR -> gray: 4 output pixels per lane --------------------------
+__global__ __launch_bounds__(NT) void half_bgr_gray_kernel(const uint8_t* __restrict__ src,
+                                                           size_t sstride, uint8_t* __restrict__ dst,
+                                                           size_t dstride, int dw, int dh, int vec_ok) {
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 output pixels
+    const int y = blockIdx.y;
+    const int x = gx * 4;
+    if (x >= dw || y >= dh) return;
+    const uint8_t* r0 = src + (size_t)(2 * y) * sstride + (size_t)x * 6;
+    const uint8_t* r1 = r0 + sstride;
+    uint8_t* d = dst + (size_t)y * dstride + x;
+    if (vec_ok && x + 3 < dw) {
+        // 24 contiguous bytes per row and lane (8-byte aligned)
+        uint32_t a[6], b[6];
+        const uint2* p0 = reinterpret_cast<const uint2*>(r0);
+        const uint2* p1 = reinterpret_cast<const uint2*>(r1);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            uint2 u = p0[i], v = p1[i];
+            a[2 * i] = u.x; a[2 * i + 1] = u.y;
+            b[2 * i] = v.x; b[2 * i + 1] = v.y;
+        }
+        auto byte_of = [](const uint32_t* w, int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 255u; };
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t c[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                c[k] = (byte_of(a, 6 * i + k) + byte_of(a, 6 * i + 3 + k) + byte_of(b, 6 * i + k) +
+                        byte_of(b, 6 * i + 3 + k) + 2u) >> 2;
+            out |= bgr_to_gray(c[0], c[1], c[2]) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(d) = out;
+    } else {
+        for (int i = 0; i < 4 && x + i < dw; i++) {
+            uint32_t c[3];
+            for (int k = 0; k < 3; k++)
+                c[k] = (r0[6 * i + k] + r0[6 * i + 3 + k] + r1[6 * i + k] + r1[6 * i + 3 + k] + 2u) >> 2;
+            d[i] = (uint8_t)bgr_to_gray(c[0], c[1], c[2]);
+        }
+    }
+}
+
+// ---- general bilinear (any scale), CN = 3 (-> gray) or 1 ----------------------
+template <int CN, bool TO_GRAY>
+__global__ __launch_bounds__(NT) void resize_gray_kernel(const uint8_t* __restrict__ src, size_t sstride,
+                                                         int sw, int sh, uint8_t* __restrict__ dst,
+                                                         size_t dstride, int dw, int dh, double scale_x,
+                                                         double scale_y, int area2) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dy = blockIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    uint32_t v[CN];
+    if (area2) {
+        const uint8_t* r0 = src + (size_t)(2 * dy) * sstride + (size_t)(2 * dx) * CN;
+        const uint8_t* r1 = r0 + sstride;
+#pragma unroll
+        for (int k = 0; k < CN; k++) v[k] = (r0[k] + r0[CN + k] + r1[k] + r1[CN + k] + 2u) >> 2;
+    } else {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = f_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        bool edge = false;
+        if (sx + 1 >= sw) {
+            edge = true;
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        }
+        const int a0 = sat_s16(f_round((1.f - fx) * 2048.f)), a1 = sat_s16(f_round(fx * 2048.f));
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = f_floor(fy);
+        fy -= sy;
+        const int b0 = sat_s16(f_round((1.f - fy) * 2048.f)), b1 = sat_s16(f_round(fy * 2048.f));
+        int sy0 = sy, sy1 = sy + 1;
+        sy0 = sy0 >= 0 ? (sy0 < sh ? sy0 : sh - 1) : 0;
+        sy1 = sy1 >= 0 ? (sy1 < sh ? sy1 : sh - 1) : 0;
+        const uint8_t* r0 = src + (size_t)sy0 * sstride + (size_t)sx * CN;
+        const uint8_t* r1 = src + (size_t)sy1 * sstride + (size_t)sx * CN;
+#pragma unroll
+        for (int k = 0; k < CN; k++) {
+            int h0, h1;
+            if (!edge) {
+                h0 = r0[k] * a0 + r0[CN + k] * a1;
+                h1 = r1[k] * a0 + r1[CN + k] * a1;
+            } else {
+                h0 = r0[k] * 2048;
+                h1 = r1[k] * 2048;
+            }
+            v[k] = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+    if (TO_GRAY) {
+        dst[(size_t)dy * dstride + dx] = (uint8_t)(CN == 3 ? bgr_to_gray(v[0], v[1], v[2]) : v[0]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < CN; k++) dst[(size_t)dy * dstride + (size_t)dx * CN + k] = (uint8_t)v[k];
+    }
+}
+
+}  // namespace
+
+int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
+                       uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st) {
+    if (!d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || dh > 65535 ||
+        (fmt != VS_FMT_BGR8 && fmt != VS_FMT_NV12 && fmt != VS_FMT_GRAY8)) {
+        set_last_error("resize_gray: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    // cv::resize: scale = 1/(dsize/ssize); INTER_LINEAR with an exact 2x2
+    // decimation is served by the INTER_AREA fast path.
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+    const int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y);
+    const bool area2 = std::abs(scale_x - isx) < DBL_EPSILON && std::abs(scale_y - isy) < DBL_EPSILON &&
+                       isx == 2 && isy == 2;
+    if (fmt == VS_FMT_BGR8 && area2) {
+        const int vec_ok = ((uintptr_t)d_src % 8 == 0) && (sstride % 8 == 0) && ((uintptr_t)d_dst % 4 == 0) &&
+                           (dstride % 4 == 0);
+        dim3 grid(((dw + 3) / 4 + NT - 1) / NT, dh);
+        hipLaunchKernelGGL(half_bgr_gray_kernel, grid, dim3(NT), 0, st, d_src, sstride, d_dst, dstride, dw, dh, vec_ok);
+    } else {
+        dim3 grid((dw + NT - 1) / NT, dh);
+        if (fmt == VS_FMT_BGR8)
+            hipLaunchKernelGGL((resize_gray_kernel<3, true>), grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst,
+                               dstride, dw, dh, scale_x, scale_y, area2 ? 1 : 0);
+        else
+            hipLaunchKernelGGL((resize_gray_kernel<1, true>), grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst,
+                               dstride, dw, dh, scale_x, scale_y, area2 ? 1 : 0);
+    }
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// cv::resize(INTER_LINEAR) keeping the channels (crop-n-zoom, Stabilizer.cpp:1121)
+int launch_resize_linear(const uint8_t* d_src, size_t sstride, int sw, int sh, int cn, uint8_t* d_dst,
+                         size_t dstride, int dw, int dh, hipStream_t st) {
+    if (!d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || dh > 65535 || (cn != 1 && cn != 3)) {
+        set_last_error("resize_linear: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+    const int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y);
+    const int area2 = std::abs(scale_x - isx) < DBL_EPSILON && std::abs(scale_y - isy) < DBL_EPSILON && isx == 2 && isy == 2;
+    dim3 grid((dw + NT - 1) / NT, dh);
+    if (cn == 3)
+        hipLaunchKernelGGL((resize_gray_kernel<3, false>), grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst, dstride,
+                           dw, dh, scale_x, scale_y, area2);
+    else
+        hipLaunchKernelGGL((resize_gray_kernel<1, false>), grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst, dstride,
+                           dw, dh, scale_x, scale_y, area2);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+}  // namespace vsd

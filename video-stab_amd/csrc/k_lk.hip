@@ -1,0 +1,277 @@
+// Pyramidal Lucas-Kanade tracker for gfx950: device counterpart of
+//   cv::calcOpticalFlowPyrLK(prevGray, currGray, prevPts, nextPts, status, err,
+//                            Size(win,win), maxLevel, TermCriteria(COUNT+EPS, iters, eps))
+// as called at /root/reference/src/Stabilizer.cpp:611-619 (15x15, maxLevel 2,
+// 20 iterations, eps 0.03; Stabilizer_legacy.cpp:218-224 uses 21x21).
+//
+// One wavefront (64 lanes) owns one feature point for ALL pyramid levels
+// (coarse to fine), so the whole tracker is a single launch: points are
+// independent, levels of one point are sequential.  The win*win window is
+// spread over the lanes (ceil(win^2/64) pixels per lane, kept in registers as
+// int16 I / dIx / dIy); the 2x2 normal-equation sums (A11,A12,A22 and per
+// iteration b1,b2) are exact int64 wave reductions, so the float solve that
+// follows is bit-identical to the oracle's.  Latency-bound gather kernel
+// (SURVEY.md 8a L1): images are <= 0.5 MB and stay in L2.
+#include "vs_common.h"
+
+namespace vsd {
+namespace {
+
+constexpr int MAX_LEVELS = 8;
+
+struct LKArgs {
+    LKLevel levels[MAX_LEVELS];
+    int max_level;
+    const float* prev_pts;
+    float* next_pts;
+    uint8_t* status;
+    float* err;
+    int n;
+    const int32_t* d_n;
+    int win;
+    int max_count;
+    double eps2;
+};
+
+__device__ __forceinline__ long long wave_sum(long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+struct Weights { int w00, w01, w10, w11; };
+
+__device__ __forceinline__ Weights make_weights(float a, float b) {
+    Weights w;
+    w.w00 = f_round((1.f - a) * (1.f - b) * 16384.f);
+    w.w01 = f_round(a * (1.f - b) * 16384.f);
+    w.w10 = f_round((1.f - a) * b * 16384.f);
+    w.w11 = 16384 - w.w00 - w.w01 - w.w10;
+    return w;
+}
+
+// bilinear image sample, REFLECT_101 padding (pyramid border), descaled by 9
+__device__ __forceinline__ int sample_img(const uint8_t* __restrict__ img, size_t stride, int w, int h,
+                                          int X, int Y, const Weights& wt) {
+    const int xa = reflect101(X, w), xb = reflect101(X + 1, w);
+    const uint8_t* r0 = img + (size_t)reflect101(Y, h) * stride;
+    const uint8_t* r1 = img + (size_t)reflect101(Y + 1, h) * stride;
+    return descale(r0[xa] * wt.w00 + r0[xb] * wt.w01 + r1[xa] * wt.w10 + r1[xb] * wt.w11, 9);
+}
+
+__device__ __forceinline__ short2 load_deriv(const int16_t* __restrict__ d, int w, int h, int x, int y) {
+    if ((unsigned)x >= (unsigned)w || (unsigned)y >= (unsigned)h) return make_short2(0, 0);
+    return *reinterpret_cast<const short2*>(d + ((size_t)y * w + x) * 2);
+}
+
+template <int NPX>
+__global__ __launch_bounds__(64) void lk_kernel(LKArgs a) {
+    const int pt = blockIdx.x;
+    const int lane = threadIdx.x;
+    int n = a.n;
+    if (a.d_n) { int dn = *a.d_n; n = dn < n ? dn : n; }
+    if (pt >= n) return;
+    const int win = a.win, area = win * win;
+    int ox[NPX], oy[NPX];
+    bool valid[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; k++) {
+        const int p = lane + 64 * k;
+        valid[k] = p < area;
+        const int yy = valid[k] ? p / win : 0;
+        oy[k] = yy;
+        ox[k] = valid[k] ? p - yy * win : 0;
+    }
+    const float halfWin = (win - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float px0 = a.prev_pts[2 * pt], py0 = a.prev_pts[2 * pt + 1];
+    float outx = 0.f, outy = 0.f;  // nextPts[pt]
+    int status = 1;
+    float err = 0.f;
+
+    for (int level = a.max_level; level >= 0; level--) {
+        const LKLevel L = a.levels[level];
+        const float scale = (float)(1. / (double)(1 << level));
+        float prevx = px0 * scale, prevy = py0 * scale;
+        if (level == a.max_level) { outx = prevx; outy = prevy; }
+        else { outx = outx * 2.f; outy = outy * 2.f; }
+        prevx -= halfWin; prevy -= halfWin;
+        const int ipx = f_floor(prevx), ipy = f_floor(prevy);
+        if (ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h) {
+            if (level == 0) { status = 0; err = 0.f; }
+            continue;
+        }
+        Weights wt = make_weights(prevx - ipx, prevy - ipy);
+        short Iw[NPX], Ix[NPX], Iy[NPX];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int k = 0; k < NPX; k++) {
+            Iw[k] = 0; Ix[k] = 0; Iy[k] = 0;
+            if (valid[k]) {
+                const int X = ipx + ox[k], Y = ipy + oy[k];
+                const int ival = sample_img(L.prev, L.stride, L.w, L.h, X, Y, wt);
+                const short2 d00 = load_deriv(L.deriv, L.w, L.h, X, Y);
+                const short2 d01 = load_deriv(L.deriv, L.w, L.h, X + 1, Y);
+                const short2 d10 = load_deriv(L.deriv, L.w, L.h, X, Y + 1);
+                const short2 d11 = load_deriv(L.deriv, L.w, L.h, X + 1, Y + 1);
+                const int ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
+                const int iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
+                Iw[k] = (short)ival; Ix[k] = (short)ixval; Iy[k] = (short)iyval;
+                sA11 += (long long)(ixval * ixval);
+                sA12 += (long long)(ixval * iyval);
+                sA22 += (long long)(iyval * iyval);
+            }
+        }
+        sA11 = wave_sum(sA11); sA12 = wave_sum(sA12); sA22 = wave_sum(sA22);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                             (float)(2 * win * win);
+        if (minEig < 1e-4f || D < FLT_EPSILON) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = 1.f / D;
+        float cx = outx - halfWin, cy = outy - halfWin;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < a.max_count; j++) {
+            const int inx = f_floor(cx), iny = f_floor(cy);
+            if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+                if (level == 0) status = 0;
+                break;
+            }
+            wt = make_weights(cx - inx, cy - iny);
+            long long sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int k = 0; k < NPX; k++) {
+                if (valid[k]) {
+                    const int diff = sample_img(L.next, L.stride, L.w, L.h, inx + ox[k], iny + oy[k], wt) - Iw[k];
+                    sb1 += (long long)(diff * Ix[k]);
+                    sb2 += (long long)(diff * Iy[k]);
+                }
+            }
+            sb1 = wave_sum(sb1); sb2 = wave_sum(sb2);
+            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            cx += dx; cy += dy;
+            outx = cx + halfWin; outy = cy + halfWin;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= a.eps2) break;
+            if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (status && level == 0) {
+            const float npx = outx - halfWin, npy = outy - halfWin;
+            const int inx = f_floor(npx), iny = f_floor(npy);
+            if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+                status = 0;
+            } else {
+                wt = make_weights(npx - inx, npy - iny);
+                long long es = 0;
+#pragma unroll
+                for (int k = 0; k < NPX; k++) {
+                    if (valid[k]) {
+                        const int diff = sample_img(L.next, L.stride, L.w, L.h, inx + ox[k], iny + oy[k], wt) - Iw[k];
+                        es += diff < 0 ? -diff : diff;
+                    }
+                }
+                es = wave_sum(es);
+                err = (float)es * 1.f / (float)(32 * win * win);
+            }
+        }
+    }
+    if (lane == 0) {
+        a.next_pts[2 * pt] = outx;
+        a.next_pts[2 * pt + 1] = outy;
+        a.status[pt] = (uint8_t)status;
+        a.err[pt] = err;
+    }
+}
+
+}  // namespace
+
+int launch_pyr_lk(const LKLevel* levels, int max_level, const float* d_prev_pts, int n,
+                  const int32_t* d_n, float* d_next_pts, uint8_t* d_status, float* d_err, int win,
+                  int max_iters, double eps, hipStream_t st) {
+    if (!levels || max_level < 0 || max_level >= MAX_LEVELS || n < 0 || win < 3 || win > 31 ||
+        !d_prev_pts || !d_next_pts || !d_status || !d_err) {
+        set_last_error("pyr_lk: invalid argument (3 <= win <= 31, max_level < 8)");
+        return VS_ERR_INVALID_ARG;
+    }
+    if (n == 0) return VS_OK;
+    LKArgs a;
+    for (int i = 0; i <= max_level; i++) a.levels[i] = levels[i];
+    for (int i = max_level + 1; i < MAX_LEVELS; i++) a.levels[i] = levels[max_level];
+    a.max_level = max_level;
+    a.prev_pts = d_prev_pts; a.next_pts = d_next_pts; a.status = d_status; a.err = d_err;
+    a.n = n; a.d_n = d_n; a.win = win;
+    // SparsePyrLKOpticalFlowImpl::calc: clamp criteria, epsilon is squared
+    a.max_count = max_iters < 0 ? 0 : (max_iters > 100 ? 100 : max_iters);
+    double e = eps < 0 ? 0. : (eps > 10. ? 10. : eps);
+    a.eps2 = e * e;
+    const int npx = (win * win + 63) / 64;
+    dim3 grid(n), block(64);
+    if (npx <= 4) hipLaunchKernelGGL(lk_kernel<4>, grid, block, 0, st, a);
+    else if (npx <= 7) hipLaunchKernelGGL(lk_kernel<7>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(lk_kernel<16>, grid, block, 0, st, a);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// vs_op_pyr_lk: builds both pyramids and the derivative images, then tracks.
+int run_pyr_lk_op(const uint8_t* d_prev, const uint8_t* d_next, size_t stride, int w, int h,
+                  const float* d_prev_pts, int n, float* d_next_pts, uint8_t* d_status,
+                  float* d_err, int win, int max_level, int max_iters, double eps, hipStream_t st) {
+    if (!d_prev || !d_next || w <= 0 || h <= 0 || max_level < 0 || max_level >= MAX_LEVELS) {
+        set_last_error("pyr_lk: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    // buildOpticalFlowPyramid: stop when the next level would not exceed the window
+    int lw[MAX_LEVELS], lh[MAX_LEVELS];
+    int levels = 0;
+    {
+        int sw = w, sh = h;
+        for (int level = 0; level <= max_level; level++) {
+            lw[level] = sw; lh[level] = sh;
+            levels = level;
+            sw = (sw + 1) / 2; sh = (sh + 1) / 2;
+            if (sw <= win || sh <= win) break;
+        }
+    }
+    size_t img_bytes = 0, der_bytes = 0;
+    for (int i = 1; i <= levels; i++) img_bytes += (size_t)lw[i] * lh[i];
+    for (int i = 0; i <= levels; i++) der_bytes += (size_t)lw[i] * lh[i] * 4;
+    uint8_t* scratch = nullptr;
+    const size_t total = 2 * img_bytes + der_bytes + 64;
+    VS_HIP_TRY(hipMalloc((void**)&scratch, total));
+    LKLevel L[MAX_LEVELS];
+    uint8_t* pp = scratch;
+    uint8_t* pn = scratch + img_bytes;
+    int16_t* pd = reinterpret_cast<int16_t*>(scratch + ((2 * img_bytes + 15) & ~(size_t)15));
+    int rc = VS_OK;
+    for (int i = 0; i <= levels && rc == VS_OK; i++) {
+        L[i].w = lw[i]; L[i].h = lh[i];
+        if (i == 0) { L[i].prev = d_prev; L[i].next = d_next; L[i].stride = stride; }
+        else {
+            rc = launch_pyr_down(L[i - 1].prev, L[i - 1].stride, lw[i - 1], lh[i - 1], pp, lw[i], st);
+            if (rc == VS_OK) rc = launch_pyr_down(L[i - 1].next, L[i - 1].stride, lw[i - 1], lh[i - 1], pn, lw[i], st);
+            L[i].prev = pp; L[i].next = pn; L[i].stride = lw[i];
+            pp += (size_t)lw[i] * lh[i]; pn += (size_t)lw[i] * lh[i];
+        }
+        if (rc == VS_OK) rc = launch_scharr(L[i].prev, L[i].stride, lw[i], lh[i], pd, st);
+        L[i].deriv = pd;
+        pd += (size_t)lw[i] * lh[i] * 2;
+    }
+    if (rc == VS_OK) rc = launch_pyr_lk(L, levels, d_prev_pts, n, nullptr, d_next_pts, d_status, d_err, win, max_iters, eps, st);
+    hipError_t e = hipStreamSynchronize(st);
+    hipFree(scratch);
+    if (rc == VS_OK && e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = VS_ERR_HIP; }
+    return rc;
+}
+
+}  // namespace vsd

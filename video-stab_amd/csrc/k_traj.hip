@@ -1,0 +1,381 @@
+// Small per-frame device kernels that keep stabilize() free of host round
+// trips (so one step is a fixed kernel sequence, capturable in a hipGraph):
+//
+//  compact_kernel - status compaction of the LK result, order preserving
+//      (/root/reference/src/Stabilizer.cpp:629-641), one wave, ballot + prefix.
+//  traj_append_kernel - model -> (dx,dy,da) (:644-662), drone filters
+//      (:2468-2520,:2605-2682), transforms_/path_ append (:673-688),
+//      adaptSmoothingRadius (:1461-1492).
+//  traj_emit_kernel - the part of applyNextSmoothTransform() that produces the
+//      2x3 matrix (:783-908): box / gaussian / kalman smoothing evaluated only
+//      around the frame that leaves the queue (the reference re-smooths the
+//      whole history per frame), motion-intent gain, T = [cos -sin dx; sin cos dy].
+//
+// History lives in device ring buffers (last RING entries of transforms_ and
+// path_); the Kalman filter is advanced incrementally (it is a forward
+// recursion, so resuming from the stored state reproduces the reference's
+// from-scratch run bit for bit).
+#include "vs_common.h"
+#include "traj_state.h"
+
+namespace vsd {
+namespace {
+
+__global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ prev, const float* __restrict__ cur,
+                                                     const uint8_t* __restrict__ status, int n_cap,
+                                                     const int32_t* __restrict__ d_n, float* __restrict__ vp,
+                                                     float* __restrict__ vc, int32_t* __restrict__ d_m,
+                                                     vs_debug_frame* dbg) {
+    const int lane = threadIdx.x;
+    int n = *d_n;
+    n = n < n_cap ? n : n_cap;
+    int m = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool keep = i < n && status[i] != 0;
+        const unsigned long long mask = __ballot(keep);
+        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) {
+            vp[2 * pos] = prev[2 * i]; vp[2 * pos + 1] = prev[2 * i + 1];
+            vc[2 * pos] = cur[2 * i]; vc[2 * pos + 1] = cur[2 * i + 1];
+        }
+        m += __popcll(mask);
+    }
+    if (lane == 0) {
+        *d_m = m;
+        dbg->n_prev = n;
+        dbg->n_valid = m;
+    }
+}
+
+__device__ __forceinline__ float hf_mag(const float t[3]) {
+    return sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] * 100.0f);
+}
+
+__global__ void traj_append_kernel(TrajState* s, TrajParams p, const double* __restrict__ model,
+                                   const int32_t* __restrict__ info, const int32_t* __restrict__ d_nprev,
+                                   vs_debug_frame* dbg, int have_prev_gray) {
+    if (threadIdx.x != 0) return;
+    float tr[3] = {0.f, 0.f, 0.f};
+    const int nprev = *d_nprev;
+    dbg->ransac_best_iter = -1; dbg->ransac_iters_run = 0; dbg->n_inliers = 0;
+    for (int i = 0; i < 6; i++) dbg->model[i] = __longlong_as_double(0x7FF8000000000000LL);
+    if (nprev > 0 && have_prev_gray) {              // Stabilizer.cpp:596
+        float T[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};  // :644
+        if (info[0]) {                               // :650-652
+            for (int i = 0; i < 6; i++) { T[i] = (float)model[i]; dbg->model[i] = model[i]; }
+        }
+        dbg->ransac_best_iter = info[1]; dbg->ransac_iters_run = info[2]; dbg->n_inliers = info[3];
+        tr[0] = T[2]; tr[1] = T[5]; tr[2] = atan2f(T[3], T[0]);   // :660-662
+        if (p.drone) {
+            // applyDeadZoneFreeze :2605-2655 (updateMotionAccumulator :2667-2682)
+            const float magnitude = hf_mag(tr);
+            const float decayed = s->hfAccum * p.hf_decay;
+            s->hfAccum = fmaxf(decayed, magnitude);
+            s->hfAccum = fminf(s->hfAccum, p.hf_dead_zone * 5.0f);
+            s->hfAccum = fmaxf(0.0f, fminf(s->hfAccum, 100.0f));
+            const float cur = magnitude;
+            bool frozen = false;
+            if (!s->hfInDeadZone && cur < p.hf_dead_zone) { s->hfInDeadZone = 1; s->hfFreezeCounter = p.hf_freeze_duration; }
+            if (s->hfInDeadZone) {
+                s->hfFreezeCounter--;
+                const bool durationExpired = s->hfFreezeCounter <= 0;
+                const bool significantMotion = cur > p.hf_dead_zone * 1.5f;
+                const bool accumulatedMotion = s->hfAccum > p.hf_dead_zone * 1.2f;
+                if (durationExpired || significantMotion || accumulatedMotion) {
+                    s->hfInDeadZone = 0; s->hfFreezeCounter = 0; s->hfAccum = 0.0f;
+                } else frozen = true;
+            }
+            if (frozen) { tr[0] = tr[1] = tr[2] = 0.0f; }
+            // applyMicroShakeSuppression :2468-2503
+            if (s->hfHistN >= 5) {
+                float xs[10], ys[10];
+                const int hn = s->hfHistN;
+                for (int i = 0; i < hn; i++) { xs[i] = s->hfHist[i][0]; ys[i] = s->hfHist[i][1]; }
+                for (int i = 1; i < hn; i++) {   // insertion sort (values only; any stable sort gives the same order statistics)
+                    float vx = xs[i]; int j = i - 1;
+                    while (j >= 0 && xs[j] > vx) { xs[j + 1] = xs[j]; j--; }
+                    xs[j + 1] = vx;
+                    float vy = ys[i]; j = i - 1;
+                    while (j >= 0 && ys[j] > vy) { ys[j + 1] = ys[j]; j--; }
+                    ys[j + 1] = vy;
+                }
+                const int mid = hn / 2;
+                s->hfMedian[0] = hn % 2 == 0 ? (xs[mid - 1] + xs[mid]) / 2.0f : xs[mid];
+                s->hfMedian[1] = hn % 2 == 0 ? (ys[mid - 1] + ys[mid]) / 2.0f : ys[mid];
+            }
+            const float d0 = tr[0] - s->hfMedian[0], d1 = tr[1] - s->hfMedian[1];
+            const float dm = sqrtf(d0 * d0 + d1 * d1);
+            if (dm < p.hf_shake_px) {
+                tr[0] = s->hfMedian[0] + d0 * 0.01f; tr[1] = s->hfMedian[1] + d1 * 0.01f;
+            } else if (dm < p.hf_shake_px * 2.0f) {
+                tr[0] = s->hfMedian[0] + d0 * 0.05f; tr[1] = s->hfMedian[1] + d1 * 0.05f;
+            }
+            // applyRotationLowPass :2505-2520
+            if (p.horizon_lock) {
+                s->hfRotLP = (1.0f - p.hf_rot_lp_alpha) * s->hfRotLP + p.hf_rot_lp_alpha * tr[2];
+                tr[2] = s->hfRotLP;
+            }
+            // updateTranslationHistory :2522-2529 (deque of the last 10)
+            if (s->hfHistN < 10) { s->hfHist[s->hfHistN][0] = tr[0]; s->hfHist[s->hfHistN][1] = tr[1]; s->hfHistN++; }
+            else {
+                for (int i = 0; i < 9; i++) { s->hfHist[i][0] = s->hfHist[i + 1][0]; s->hfHist[i][1] = s->hfHist[i + 1][1]; }
+                s->hfHist[9][0] = tr[0]; s->hfHist[9][1] = tr[1];
+            }
+        }
+    }
+    const int n = s->n;
+    const int slot = n & (TRAJ_RING - 1);
+    float pth[3];
+    for (int c = 0; c < 3; c++) {
+        s->transforms[slot][c] = tr[c];
+        pth[c] = n == 0 ? tr[c] : s->last_path[c] + tr[c];   // :681-687
+        s->path[slot][c] = pth[c];
+        s->last_path[c] = pth[c];
+        dbg->transform[c] = tr[c];
+    }
+    s->n = n + 1;
+    // updateAdaptiveParameters :1562-1574 -> adaptSmoothingRadius :1461-1492
+    if (p.adaptive && n + 1 >= 3) {
+        const float magnitude = sqrtf(tr[0] * tr[0] + tr[1] * tr[1]);
+        float motionScale = fmaxf(0.0f, fminf(1.0f, magnitude / 50.0f));
+        motionScale = 1.0f - motionScale;
+        const int newRadius = p.min_radius + (int)(motionScale * (float)(p.max_radius - p.min_radius));
+        if (newRadius != s->smoothing_radius) s->smoothing_radius = newRadius;
+    }
+}
+
+__device__ __forceinline__ float path_at(const TrajState* s, int i, int c) { return s->path[i & (TRAJ_RING - 1)][c]; }
+__device__ __forceinline__ float tr_at(const TrajState* s, int i, int c) { return s->transforms[i & (TRAJ_RING - 1)][c]; }
+
+// Stabilizer.cpp:1750-1780
+__device__ float variance_of(const float* v, int n) {
+    if (n == 0) return 0.0f;
+    float mean = 0.0f;
+    for (int i = 0; i < n; i++) mean += v[i];
+    mean /= n;
+    float var = 0.0f;
+    for (int i = 0; i < n; i++) { const float d = v[i] - mean; var += d * d; }
+    var /= n;
+    return var;
+}
+__device__ float consistency_of(const float* v, int n) {
+    if (n < 2) return 0.0f;
+    const float var = variance_of(v, n);
+    float mean = 0.0f;
+    for (int i = 0; i < n; i++) mean += v[i];
+    mean /= n;
+    if (mean == 0.0f) return 0.0f;
+    const float c = 1.0f / (1.0f + (var / (mean * mean)));
+    return fmaxf(0.0f, fminf(1.0f, c));
+}
+
+__global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __restrict__ M_out,
+                                 vs_debug_frame* dbg) {
+    if (threadIdx.x != 0) return;
+    const int n = s->n;
+    dbg->out_index = idx; dbg->box_radius = 0; dbg->intent = 0;
+    if (idx >= n) {   // Stabilizer.cpp:774-780: no transform for this frame -> frame returned as is
+        M_out[0] = 1.f; M_out[1] = 0.f; M_out[2] = 0.f; M_out[3] = 0.f; M_out[4] = 1.f; M_out[5] = 0.f;
+        for (int i = 0; i < 6; i++) M_out[6 + i] = M_out[i];
+        for (int c = 0; c < 3; c++) dbg->smoothed[c] = 0.f;
+        for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
+        return;
+    }
+    float sm[3];
+    if (p.method == VS_SMOOTH_GAUSSIAN) {          // :1364-1413
+        const int ks = p.gauss_ksize, center = ks / 2;
+        for (int c = 0; c < 3; c++) {
+            float acc = 0.0f;
+            for (int j = 0; j < ks; j++) {
+                // padded[idx + j]: reflect padding as the reference builds it (clamped when n <= center)
+                const int q = idx + j;
+                int src;
+                if (q < center) src = center - q;
+                else if (q < center + n) src = q - center;
+                else src = n - 1 - (q - center - n);
+                src = src < 0 ? 0 : (src > n - 1 ? n - 1 : src);
+                acc += path_at(s, src, c) * p.gauss_kernel[j];
+            }
+            sm[c] = acc;
+        }
+    } else if (p.method == VS_SMOOTH_KALMAN) {     // :1416-1458, advanced incrementally
+        const float q = 0.01f, r = 0.1f;
+        for (int c = 0; c < 3; c++) {
+            float* k = s->kal[c];   // x0,x1,P00,P01,P10,P11
+            int done = s->kal_n[c];
+            if (done == 0) {
+                k[0] = path_at(s, 0, c); k[1] = 0.f; k[2] = k[3] = k[4] = k[5] = 0.f;
+                s->kal_last[c] = k[0];
+                done = 1;
+            }
+            while (done <= idx) {
+                const float xp0 = k[0] + k[1], xp1 = k[1];
+                const float t00 = k[2] + k[4], t01 = k[3] + k[5], t10 = k[4], t11 = k[5];
+                const float Q00 = (t00 + t01) + q, Q01 = t01, Q10 = t10 + t11, Q11 = t11 + q;
+                const float S = Q00 + r;
+                const float K0 = Q00 / S, K1 = Q01 / S;
+                const float innov = path_at(s, done, c) - xp0;
+                k[0] = xp0 + K0 * innov; k[1] = xp1 + K1 * innov;
+                k[2] = Q00 - K0 * Q00; k[3] = Q01 - K0 * Q01;
+                k[4] = Q10 - K1 * Q00; k[5] = Q11 - K1 * Q01;
+                s->kal_last[c] = k[0];
+                done++;
+            }
+            s->kal_n[c] = done;
+            sm[c] = s->kal_last[c];
+        }
+    } else {                                         // :807-823 box with adaptive radius
+        // calculateAdaptiveRadius :1637-1673
+        int ar = s->smoothing_radius;
+        if (n >= 10) {
+            const int start = n - 20 > 0 ? n - 20 : 0;
+            const int count = n - start;
+            float mean[3] = {0, 0, 0}, var[3] = {0, 0, 0};
+            for (int i = start; i < n; i++) for (int c = 0; c < 3; c++) mean[c] += path_at(s, i, c);
+            for (int c = 0; c < 3; c++) mean[c] /= count;
+            for (int i = start; i < n; i++)
+                for (int c = 0; c < 3; c++) { const float d = path_at(s, i, c) - mean[c]; var[c] += d * d; }
+            for (int c = 0; c < 3; c++) var[c] /= count;
+            const float total = sqrtf(var[0] + var[1] + var[2] * 1000);
+            ar = (int)fmaxf(5.0f, fminf(25.0f, total * 2.0f));
+        }
+        // boxFilterConvolve :1139-1172
+        const int r = p.drone ? max(10, min(ar, 50)) : max(2, min(ar, 8));
+        dbg->box_radius = r;
+        if (n <= r) {
+            for (int c = 0; c < 3; c++) sm[c] = path_at(s, idx, c);
+        } else {
+            const int start = idx - r > 0 ? idx - r : 0;
+            const int end = idx + r < n - 1 ? idx + r : n - 1;
+            for (int c = 0; c < 3; c++) {
+                float sum = 0.0f;
+                int count = 0;
+                for (int j = start; j <= end; j++) { sum += path_at(s, j, c); count++; }
+                sm[c] = sum / count;
+            }
+        }
+    }
+    float raw[3], diff[3];
+    for (int c = 0; c < 3; c++) {
+        raw[c] = tr_at(s, idx, c);
+        diff[c] = sm[c] - path_at(s, idx, c);      // :850-851
+        dbg->smoothed[c] = sm[c];
+    }
+    if (idx > 0) {                                   // :854-888, analyzeMotionIntent :1676-1719
+        int intent = 0;
+        const float magnitude = sqrtf(raw[0] * raw[0] + raw[1] * raw[1]);
+        const float angularVel = (float)((double)(fabsf(raw[2]) * 180.0f) / 3.14159265358979323846 * (double)30.0f);
+        if (n >= 15) {
+            float mags[15], dirs[15];
+            int cnt = 0;
+            for (int i = idx - 15 > 0 ? idx - 15 : 0; i < idx; i++) {
+                if (i < n) {
+                    const float t0 = tr_at(s, i, 0), t1 = tr_at(s, i, 1);
+                    mags[cnt] = sqrtf(t0 * t0 + t1 * t1);
+                    dirs[cnt] = atan2f(t1, t0);
+                    cnt++;
+                }
+            }
+            if (cnt > 0) {
+                const float dv = variance_of(dirs, cnt);
+                const float mc = consistency_of(mags, cnt);
+                if (dv < 0.5f && mc > 0.7f && magnitude > 5.0f) intent = 1;
+                else if (magnitude < 3.0f && mc < 0.3f && angularVel > 10.0f) intent = 2;
+                else if (magnitude > 3.0f && magnitude < 15.0f && dv > 0.5f) intent = 3;
+            }
+        }
+        dbg->intent = intent;
+        // calculateAdaptiveStabilizationStrength :1722-1747 is consumed only for NORMAL (0.7)
+        const float g = intent == 1 ? 0.5f : intent == 2 ? 1.0f : intent == 3 ? 0.8f : 0.7f;
+        for (int c = 0; c < 3; c++) diff[c] *= g;
+    }
+    const float dx = raw[0] + diff[0], dy = raw[1] + diff[1];
+    float da = raw[2] + diff[2];
+    if (p.horizon_lock) da = 0.0f;                   // :897-899
+    const float cs = cosf(da), sn = sinf(da);         // :902-908
+    M_out[0] = cs; M_out[1] = -sn; M_out[2] = dx;
+    M_out[3] = sn; M_out[4] = cs; M_out[5] = dy;
+    // chroma plane of an NV12 surface: same rotation, translation halved
+    M_out[6] = cs; M_out[7] = -sn; M_out[8] = dx * 0.5f;
+    M_out[9] = sn; M_out[10] = cs; M_out[11] = dy * 0.5f;
+    for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
+}
+
+__global__ void traj_reset_kernel(TrajState* s, int smoothing_radius) {
+    if (threadIdx.x != 0) return;
+    s->n = 0;
+    for (int c = 0; c < 3; c++) { s->last_path[c] = 0.f; s->kal_n[c] = 0; s->kal_last[c] = 0.f; }
+    s->smoothing_radius = smoothing_radius;
+    s->hfMedian[0] = s->hfMedian[1] = 0.f; s->hfRotLP = 0.f;
+    s->hfInDeadZone = 0; s->hfFreezeCounter = 0; s->hfAccum = 0.f; s->hfHistN = 0;
+}
+
+// Border pre-pad: cv::copyMakeBorder (Stabilizer.cpp:981-990)
+__device__ __forceinline__ int border_index(int p, int len, int border) {
+    if ((unsigned)p < (unsigned)len) return p;
+    switch (border) {
+        case VS_BORDER_REPLICATE: return p < 0 ? 0 : len - 1;
+        case VS_BORDER_REFLECT:
+        case VS_BORDER_REFLECT_101: {
+            const int delta = border == VS_BORDER_REFLECT_101;
+            if (len == 1) return 0;
+            do {
+                if (p < 0) p = -p - 1 + delta;
+                else p = len - 1 - (p - len) - delta;
+            } while ((unsigned)p >= (unsigned)len);
+            return p;
+        }
+        case VS_BORDER_WRAP:
+            if (p < 0) p -= ((p - len + 1) / len) * len;
+            if (p >= len) p %= len;
+            return p;
+        default: return -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void make_border_kernel(const uint8_t* __restrict__ src, size_t sstride, int w, int h,
+                                                          int cn, uint8_t* __restrict__ dst, size_t dstride, int b,
+                                                          int border) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int ow = w + 2 * b;
+    if (x >= ow) return;
+    const int sy = border_index(y - b, h, border), sx = border_index(x - b, w, border);
+    for (int k = 0; k < cn; k++)
+        dst[(size_t)y * dstride + (size_t)x * cn + k] = (sx >= 0 && sy >= 0) ? src[(size_t)sy * sstride + (size_t)sx * cn + k] : 0;
+}
+
+}  // namespace
+
+int launch_compact(const float* prev, const float* cur, const uint8_t* status, int n_cap, const int32_t* d_n,
+                   float* vp, float* vc, int32_t* d_m, vs_debug_frame* dbg, hipStream_t st) {
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(64), 0, st, prev, cur, status, n_cap, d_n, vp, vc, d_m, dbg);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+int launch_traj_append(TrajState* s, const TrajParams& p, const double* model, const int32_t* info,
+                       const int32_t* d_nprev, vs_debug_frame* dbg, int have_prev_gray, hipStream_t st) {
+    hipLaunchKernelGGL(traj_append_kernel, dim3(1), dim3(64), 0, st, s, p, model, info, d_nprev, dbg, have_prev_gray);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, vs_debug_frame* dbg, hipStream_t st) {
+    hipLaunchKernelGGL(traj_emit_kernel, dim3(1), dim3(64), 0, st, s, p, idx, M_out, dbg);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st) {
+    hipLaunchKernelGGL(traj_reset_kernel, dim3(1), dim3(64), 0, st, s, smoothing_radius);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+int launch_make_border(const uint8_t* src, size_t sstride, int w, int h, int cn, uint8_t* dst, size_t dstride,
+                       int b, int border, hipStream_t st) {
+    dim3 grid((w + 2 * b + 255) / 256, h + 2 * b);
+    hipLaunchKernelGGL(make_border_kernel, grid, dim3(256), 0, st, src, sstride, w, h, cn, dst, dstride, b, border);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+}  // namespace vsd

@@ -1,0 +1,94 @@
+// Internal header of libvideo-stab (gfx950).  Not part of the C ABI.
+#ifndef VS_COMMON_H
+#define VS_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cfloat>
+#include <cmath>
+#include <string>
+
+#include "../../include/vs_stab.h"
+
+namespace vsd {
+
+// ---- error plumbing ---------------------------------------------------------
+void set_last_error(const std::string& msg);
+const char* get_last_error();
+
+#define VS_HIP_TRY(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            vsd::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));        \
+            return (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice ||               \
+                    _e == hipErrorInsufficientDriver || _e == hipErrorNoBinaryForGpu)      \
+                       ? VS_ERR_NO_DEVICE                                                  \
+                       : VS_ERR_HIP;                                                       \
+        }                                                                                  \
+    } while (0)
+
+#define VS_TRY(expr)                      \
+    do {                                  \
+        int _s = (expr);                  \
+        if (_s != VS_OK) return _s;       \
+    } while (0)
+
+int ensure_device();  // VS_OK when a gfx950-class device is usable
+
+// ---- device helpers: same integer semantics as OpenCV's cvRound/cvFloor -------
+#ifdef __HIPCC__
+__device__ __forceinline__ int d_round(double v) { return __double2int_rn(v); }
+__device__ __forceinline__ int f_round(float v) { return __float2int_rn(v); }
+__device__ __forceinline__ int f_floor(float v) { return __float2int_rd(v); }
+__device__ __forceinline__ int sat_s16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+__device__ __forceinline__ int reflect101(int p, int len) {
+    // cv::borderInterpolate(BORDER_REFLECT_101)
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+#endif
+
+// ---- stage launchers (device pointers, asynchronous on `st`) -----------------
+// d_M: batch*6 floats on the DEVICE (forward matrices).
+int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
+                       uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
+                       const float* d_M, int batch, hipStream_t st);
+int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
+                       uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st);
+int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst,
+                    size_t dstride, hipStream_t st);
+int launch_scharr(const uint8_t* d_src, size_t sstride, int w, int h, int16_t* d_dst,
+                  hipStream_t st);
+
+struct LKLevel {
+    const uint8_t* prev;
+    const uint8_t* next;
+    const int16_t* deriv;  // prev derivatives, w*h*2
+    int w, h;
+    size_t stride;
+};
+// Tracks n points over levels[max_level..0]; n may be a device count (d_n) or host n.
+int launch_pyr_lk(const LKLevel* levels, int max_level, const float* d_prev_pts, int n,
+                  const int32_t* d_n, float* d_next_pts, uint8_t* d_status, float* d_err, int win,
+                  int max_iters, double eps, hipStream_t st);
+
+struct GfttWork {            // device scratch owned by the caller
+    float* eig;              // w*h
+    uint64_t* cand;          // cap candidates (key = value bits << 32 | index)
+    int32_t* counters;       // [0]=ncand [1]=maxbits [2]=overflow [3]=n_out  (+ spare)
+    int cap;
+};
+size_t gftt_work_bytes(int w, int h, int cap);
+void gftt_work_carve(void* base, int w, int h, int cap, GfttWork* out);
+int launch_gftt(const uint8_t* d_gray, size_t stride, int w, int h, int max_corners,
+                double quality, double min_distance, int block_size, const GfttWork& wk,
+                float* d_pts, int32_t* d_count, hipStream_t st);
+
+}  // namespace vsd
+#endif

@@ -1,0 +1,405 @@
+"""ctypes binding of the product C-ABI (include/vs_stab.h, libvideo-stab.so).
+
+This is plumbing for tests/bench: every call goes straight into the HIP
+library.  There is no Python or CPU fallback - if the library is missing, or
+no GPU is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "csrc", "libvideo-stab.so")
+
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+
+FMT_BGR8, FMT_NV12, FMT_GRAY8 = 0, 1, 2
+BORDER_BLACK, BORDER_REFLECT, BORDER_REFLECT_101, BORDER_REPLICATE, BORDER_WRAP, BORDER_FADE = range(6)
+SMOOTH_BOX, SMOOTH_GAUSSIAN, SMOOTH_KALMAN = range(3)
+
+
+class VsParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("logging", C.c_int32), ("smoothing_radius", C.c_int32),
+        ("max_corners", C.c_int32), ("quality_level", C.c_double), ("min_distance", C.c_double),
+        ("block_size", C.c_int32), ("border_type", C.c_int32), ("border_size", C.c_int32),
+        ("crop_n_zoom", C.c_int32), ("smoothing_method", C.c_int32), ("horizon_lock", C.c_int32),
+        ("gaussian_sigma", C.c_double), ("adaptive_smoothing", C.c_int32),
+        ("min_smoothing_radius", C.c_int32), ("max_smoothing_radius", C.c_int32),
+        ("fade_alpha", C.c_float), ("fade_duration", C.c_int32), ("enable_virtual_canvas", C.c_int32),
+        ("drone_high_freq_mode", C.c_int32), ("hf_shake_px", C.c_float),
+        ("hf_analysis_max_width", C.c_int32), ("hf_rot_lp_alpha", C.c_float),
+        ("enable_conditional_clahe", C.c_int32), ("hf_dead_zone_threshold", C.c_float),
+        ("hf_freeze_duration", C.c_int32), ("hf_motion_accumulator_decay", C.c_float),
+        ("lk_win_size", C.c_int32), ("lk_max_level", C.c_int32), ("lk_max_iters", C.c_int32),
+        ("lk_epsilon", C.c_double), ("ransac_max_iters", C.c_int32), ("ransac_threshold", C.c_double),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+class VsCounters(C.Structure):
+    _fields_ = [
+        ("frames_in", C.c_uint64), ("frames_out", C.c_uint64), ("detections", C.c_uint64),
+        ("last_features", C.c_int32), ("last_tracked", C.c_int32), ("last_inliers", C.c_int32),
+        ("last_candidates", C.c_int32), ("gftt_overflow", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class VsDebugFrame(C.Structure):
+    _fields_ = [
+        ("n_prev", C.c_int32), ("n_valid", C.c_int32), ("ransac_best_iter", C.c_int32),
+        ("ransac_iters_run", C.c_int32), ("n_inliers", C.c_int32), ("detected", C.c_int32),
+        ("n_detected", C.c_int32), ("box_radius", C.c_int32), ("intent", C.c_int32),
+        ("out_index", C.c_int32), ("transform", C.c_float * 3), ("smoothed", C.c_float * 3),
+        ("warp_matrix", C.c_float * 6), ("model", C.c_double * 6),
+    ]
+
+
+class VsError(RuntimeError):
+    pass
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class DevBuf:
+    """A device allocation owned through vs_dev_malloc/vs_dev_free."""
+
+    def __init__(self, vs, nbytes):
+        self.vs = vs
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        vs.check(vs.lib.vs_dev_malloc(C.byref(p), max(self.nbytes, 16)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, vs, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(vs, arr.nbytes)
+        b.upload(arr)
+        return b
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= max(self.nbytes, 16)
+        self.vs.check(self.vs.lib.vs_dev_memcpy_h2d(C.c_void_p(self.ptr + offset), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def download(self, shape, dtype, offset=0):
+        out = np.empty(shape, dtype)
+        assert offset + out.nbytes <= max(self.nbytes, 16)
+        self.vs.check(self.vs.lib.vs_dev_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset), out.nbytes))
+        return out
+
+    def zero(self):
+        self.vs.check(self.vs.lib.vs_dev_memset(C.c_void_p(self.ptr), 0, max(self.nbytes, 16)))
+
+    def free(self):
+        if self.ptr:
+            self.vs.lib.vs_dev_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class VsLib:
+    def __init__(self, lib):
+        self.lib = lib
+        L = lib
+        vp = C.c_void_p
+        L.vs_abi_version.restype = C.c_int
+        L.vs_build_info.restype = C.c_char_p
+        L.vs_device_count.restype = C.c_int
+        L.vs_params_default.argtypes = [C.POINTER(VsParams)]
+        L.vs_status_string.restype = C.c_char_p
+        L.vs_status_string.argtypes = [C.c_int]
+        L.vs_last_error.restype = C.c_char_p
+        L.vs_stab_create.argtypes = [C.POINTER(VsParams), C.c_int, C.POINTER(vp)]
+        L.vs_stab_destroy.argtypes = [vp]
+        L.vs_stab_clean.argtypes = [vp]
+        L.vs_stab_push.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_size_t, i32p]
+        L.vs_stab_flush.argtypes = [vp, u8p, C.c_size_t, i32p]
+        L.vs_stab_push_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, C.c_size_t, i32p]
+        L.vs_stab_flush_dev.argtypes = [vp, vp, C.c_size_t, i32p]
+        L.vs_stab_sync.argtypes = [vp]
+        L.vs_stab_out_size.argtypes = [vp, C.c_int, C.c_int, i32p, i32p]
+        L.vs_stab_get_counters.argtypes = [vp, C.POINTER(VsCounters)]
+        L.vs_stab_get_debug.argtypes = [vp, C.POINTER(VsDebugFrame)]
+        L.vs_stab_get_debug_arrays.argtypes = [vp, f32p, f32p, u8p, u8p, f32p, u8p, i32p, i32p]
+        L.vs_stab_last_error.restype = C.c_char_p
+        L.vs_stab_last_error.argtypes = [vp]
+        L.vs_stab_stream.restype = vp
+        L.vs_stab_stream.argtypes = [vp]
+        L.vs_stab_enable_graph.argtypes = [vp, C.c_int]
+        L.vs_dev_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+        L.vs_dev_free.argtypes = [vp]
+        L.vs_dev_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+        L.vs_dev_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+        L.vs_dev_memset.argtypes = [vp, C.c_int, C.c_size_t]
+        L.vs_op_warp_affine.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                        C.c_int, f32p, C.c_int, vp]
+        L.vs_op_warp_affine_nv12.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, f32p, C.c_int,
+                                             C.c_size_t, C.c_size_t, vp]
+        L.vs_op_resize_gray.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, vp]
+        L.vs_op_pyr_down.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        L.vs_op_scharr.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, vp]
+        L.vs_op_pyr_lk.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp,
+                                   C.c_int, C.c_int, C.c_int, C.c_double, vp]
+        L.vs_op_gftt.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                 vp, vp, vp, vp]
+        L.vs_op_estimate_affine_partial2d.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
+
+    # ---- helpers ----------------------------------------------------------
+    def check(self, status, inst=None):
+        if status != 0:
+            msg = self.lib.vs_status_string(status).decode()
+            detail = (self.lib.vs_stab_last_error(inst) if inst else self.lib.vs_last_error()) or b""
+            raise VsError("%s: %s" % (msg, detail.decode()))
+
+    def params(self, **kw):
+        p = VsParams()
+        self.lib.vs_params_default(C.byref(p))
+        for k, v in kw.items():
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+        return p
+
+    def sync(self):
+        self.check(self.lib.vs_dev_sync())
+
+    # ---- stage operators, numpy in / numpy out (device round trip) ----------
+    def warp_affine(self, img, M):
+        """img: (h,w[,3]) or (b,h,w,3) uint8; M: (6,) or (b,6)."""
+        img = np.ascontiguousarray(img)
+        batched = img.ndim == 4 or (img.ndim == 3 and img.shape[2] not in (1, 3))
+        if img.ndim == 2:
+            b, (h, w), cn = 1, img.shape, 1
+        elif img.ndim == 3 and not batched:
+            b, (h, w, cn) = 1, img.shape
+        elif img.ndim == 3:
+            (b, h, w), cn = img.shape, 1
+        else:
+            b, h, w, cn = img.shape
+        M = np.ascontiguousarray(M, np.float32).reshape(b, 6)
+        d_in = DevBuf.from_array(self, img)
+        d_out = DevBuf(self, img.nbytes)
+        fb = h * w * cn
+        self.check(self.lib.vs_op_warp_affine(d_in.ptr, w * cn, fb, d_out.ptr, w * cn, fb, w, h, cn,
+                                              _p(M, f32p), b, None))
+        self.sync()
+        return d_out.download(img.shape, np.uint8)
+
+    def warp_affine_nv12(self, img, w, h, M):
+        img = np.ascontiguousarray(img)
+        M = np.ascontiguousarray(M, np.float32).reshape(1, 6)
+        d_in = DevBuf.from_array(self, img)
+        d_out = DevBuf(self, img.nbytes)
+        self.check(self.lib.vs_op_warp_affine_nv12(d_in.ptr, w, d_out.ptr, w, w, h, _p(M, f32p), 1,
+                                                   img.nbytes, img.nbytes, None))
+        self.sync()
+        return d_out.download(img.shape, np.uint8)
+
+    def resize_gray(self, img, dw, dh, fmt=None):
+        img = np.ascontiguousarray(img)
+        if fmt is None:
+            fmt = FMT_BGR8 if img.ndim == 3 else FMT_GRAY8
+        w = img.shape[1]
+        h = img.shape[0] if fmt != FMT_NV12 else img.shape[0] * 2 // 3
+        cn = 3 if fmt == FMT_BGR8 else 1
+        d_in = DevBuf.from_array(self, img)
+        d_out = DevBuf(self, dw * dh)
+        self.check(self.lib.vs_op_resize_gray(d_in.ptr, w * cn, w, h, fmt, d_out.ptr, dw, dw, dh, None))
+        self.sync()
+        return d_out.download((dh, dw), np.uint8)
+
+    def pyr_down(self, g):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        dh, dw = (h + 1) // 2, (w + 1) // 2
+        d_in = DevBuf.from_array(self, g)
+        d_out = DevBuf(self, dw * dh)
+        self.check(self.lib.vs_op_pyr_down(d_in.ptr, w, w, h, d_out.ptr, dw, None))
+        self.sync()
+        return d_out.download((dh, dw), np.uint8)
+
+    def scharr(self, g):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        d_in = DevBuf.from_array(self, g)
+        d_out = DevBuf(self, h * w * 4)
+        self.check(self.lib.vs_op_scharr(d_in.ptr, w, w, h, d_out.ptr, None))
+        self.sync()
+        return d_out.download((h, w, 2), np.int16)
+
+    def pyr_lk(self, prev, nxt, pts, win=15, max_level=2, iters=20, eps=0.03):
+        prev = np.ascontiguousarray(prev)
+        nxt = np.ascontiguousarray(nxt)
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        n = pts.shape[0]
+        h, w = prev.shape
+        d_prev = DevBuf.from_array(self, prev)
+        d_next = DevBuf.from_array(self, nxt)
+        d_pts = DevBuf.from_array(self, pts)
+        d_out = DevBuf(self, n * 8)
+        d_st = DevBuf(self, n)
+        d_err = DevBuf(self, n * 4)
+        self.check(self.lib.vs_op_pyr_lk(d_prev.ptr, d_next.ptr, w, w, h, d_pts.ptr, n, d_out.ptr, d_st.ptr,
+                                         d_err.ptr, win, max_level, iters, eps, None))
+        self.sync()
+        return (d_out.download((n, 2), np.float32), d_st.download((n,), np.uint8),
+                d_err.download((n,), np.float32))
+
+    def gftt(self, g, max_corners, quality, min_distance, block_size=3, want_eig=False):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        d_in = DevBuf.from_array(self, g)
+        d_pts = DevBuf(self, max(max_corners, 1) * 8)
+        d_cnt = DevBuf(self, 16)
+        d_eig = DevBuf(self, w * h * 4) if want_eig else None
+        self.check(self.lib.vs_op_gftt(d_in.ptr, w, w, h, max_corners, quality, min_distance, block_size,
+                                       d_pts.ptr, d_cnt.ptr, d_eig.ptr if d_eig else None, None))
+        self.sync()
+        n = int(d_cnt.download((1,), np.int32)[0])
+        pts = d_pts.download((max(max_corners, 1), 2), np.float32)[:n].copy()
+        if want_eig:
+            return pts, d_eig.download((h, w), np.float32)
+        return pts
+
+    def estimate_affine_partial2d(self, a, b, thr=5.0, max_iters=500):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(b, np.float32).reshape(-1, 2)
+        n = a.shape[0]
+        d_a = DevBuf.from_array(self, a)
+        d_b = DevBuf.from_array(self, b)
+        d_model = DevBuf(self, 48)
+        d_inl = DevBuf(self, max(n, 1))
+        d_info = DevBuf(self, 16)
+        self.check(self.lib.vs_op_estimate_affine_partial2d(d_a.ptr, d_b.ptr, n, thr, max_iters, d_model.ptr,
+                                                            d_inl.ptr, d_info.ptr, None))
+        self.sync()
+        info = d_info.download((4,), np.int32)
+        return (int(info[0]), d_model.download((6,), np.float64), d_inl.download((max(n, 1),), np.uint8)[:n], info)
+
+    def stabilizer(self, params, device=0):
+        return Stabilizer(self, params, device)
+
+
+class Stabilizer:
+    """One video stream: the C-ABI mirror of vs::Stabilizer (Stabilizer.h:177-198)."""
+
+    def __init__(self, vs, params, device=0):
+        self.vs = vs
+        self.lib = vs.lib
+        h = C.c_void_p()
+        vs.check(self.lib.vs_stab_create(C.byref(params), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.vs_stab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _geom(self, frame, fmt):
+        w = frame.shape[1]
+        h = frame.shape[0] if fmt != FMT_NV12 else frame.shape[0] * 2 // 3
+        return w, h, (3 if fmt == FMT_BGR8 else 1)
+
+    def out_shape(self, w, h, fmt):
+        ow, oh = C.c_int32(), C.c_int32()
+        self.vs.check(self.lib.vs_stab_out_size(self.h, w, h, C.byref(ow), C.byref(oh)), self.h)
+        if fmt == FMT_BGR8:
+            return (oh.value, ow.value, 3)
+        if fmt == FMT_NV12:
+            return (oh.value * 3 // 2, ow.value)
+        return (oh.value, ow.value)
+
+    def push(self, frame, fmt=FMT_BGR8):
+        """stabilize(frame): returns the stabilized frame or None (warm-up)."""
+        frame = np.ascontiguousarray(frame)
+        w, h, cn = self._geom(frame, fmt)
+        out = np.zeros(self.out_shape(w, h, fmt), np.uint8)
+        produced = C.c_int32(0)
+        self.vs.check(self.lib.vs_stab_push(self.h, _p(frame, u8p), w, h, w * cn, fmt, _p(out, u8p),
+                                            out.shape[1] * cn, C.byref(produced)), self.h)
+        return out if produced.value else None
+
+    def flush(self, like, fmt=FMT_BGR8):
+        w, h, cn = self._geom(like, fmt)
+        out = np.zeros(self.out_shape(w, h, fmt), np.uint8)
+        produced = C.c_int32(0)
+        self.vs.check(self.lib.vs_stab_flush(self.h, _p(out, u8p), out.shape[1] * cn, C.byref(produced)), self.h)
+        return out if produced.value else None
+
+    def push_dev(self, d_in, w, h, stride, fmt, d_out, out_stride):
+        produced = C.c_int32(0)
+        self.vs.check(self.lib.vs_stab_push_dev(self.h, d_in, w, h, stride, fmt, d_out, out_stride,
+                                                C.byref(produced)), self.h)
+        return produced.value
+
+    def flush_dev(self, d_out, out_stride):
+        produced = C.c_int32(0)
+        self.vs.check(self.lib.vs_stab_flush_dev(self.h, d_out, out_stride, C.byref(produced)), self.h)
+        return produced.value
+
+    def sync(self):
+        self.vs.check(self.lib.vs_stab_sync(self.h), self.h)
+
+    def clean(self):
+        self.vs.check(self.lib.vs_stab_clean(self.h), self.h)
+
+    def enable_graph(self, on=True):
+        self.vs.check(self.lib.vs_stab_enable_graph(self.h, int(on)), self.h)
+
+    def counters(self):
+        c = VsCounters()
+        self.vs.check(self.lib.vs_stab_get_counters(self.h, C.byref(c)), self.h)
+        return c
+
+    def debug(self):
+        d = VsDebugFrame()
+        self.vs.check(self.lib.vs_stab_get_debug(self.h, C.byref(d)), self.h)
+        return d
+
+    def debug_arrays(self):
+        d = self.debug()
+        prev = np.zeros((max(d.n_prev, 1), 2), np.float32)
+        cur = np.zeros((max(d.n_prev, 1), 2), np.float32)
+        st = np.zeros(max(d.n_prev, 1), np.uint8)
+        inl = np.zeros(max(d.n_valid, 1), np.uint8)
+        det = np.zeros((max(d.n_detected, 1), 2), np.float32)
+        gray = np.zeros(1920 * 1080, np.uint8)
+        aw, ah = C.c_int32(), C.c_int32()
+        self.vs.check(self.lib.vs_stab_get_debug_arrays(self.h, _p(prev, f32p), _p(cur, f32p), _p(st, u8p),
+                                                        _p(inl, u8p), _p(det, f32p), _p(gray, u8p),
+                                                        C.byref(aw), C.byref(ah)), self.h)
+        return dict(prev=prev[:d.n_prev], curr=cur[:d.n_prev], status=st[:d.n_prev], inliers=inl[:d.n_valid],
+                    detected=det[:d.n_detected] if d.detected else det[:0],
+                    gray=gray[:aw.value * ah.value].reshape(ah.value, aw.value))
+
+
+_cached = None
+
+
+def load(path=None):
+    """Load libvideo-stab.so; raises if it has not been built (no fallback)."""
+    global _cached
+    if _cached is None:
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise VsError("libvideo-stab.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _cached = VsLib(C.CDLL(path))
+    return _cached
