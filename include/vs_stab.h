@@ -171,6 +171,11 @@ int vs_stab_sync(vs_stab* s);
 /* size of the frames stabilize() returns for w x h input (crop/border rules,
  * Stabilizer.cpp:981-990,1108-1127) */
 int vs_stab_out_size(const vs_stab* s, int w, int h, int* out_w, int* out_h);
+/* size of the frame the LAST successful push/flush produced.  Equals
+ * vs_stab_out_size() except for the final frame of a flush when a border pad
+ * is configured: the reference returns that frame unpadded (Stabilizer.cpp:
+ * 774-780); it is then stored top-left in `out`, the rest zero. */
+int vs_stab_last_out_dims(const vs_stab* s, int* w, int* h);
 int vs_stab_get_counters(vs_stab* s, vs_counters* out);      /* synchronises  */
 int vs_stab_get_debug(vs_stab* s, vs_debug_frame* out);      /* synchronises  */
 /* copies the debug arrays of the last push: any pointer may be NULL.

@@ -155,6 +155,7 @@ static void generate_transform(vso_stab* s, const uint8_t* data, int w, int h, s
     d.detected = 0; d.n_detected = 0;
     for (int i = 0; i < 6; i++) d.model[i] = NAN;
     s->dbgPrev.clear(); s->dbgCurr.clear(); s->dbgStatus.clear(); s->dbgInliers.clear();
+    s->dbgDetected.clear();
     float tr[3] = {0.f, 0.f, 0.f};
     if (!s->prevKeypoints.empty() && !s->prevGray.empty()) {  // :596
         if (s->prevGray.w != aw || s->prevGray.h != ah) {      // :598-603

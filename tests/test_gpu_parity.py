@@ -137,7 +137,7 @@ def test_gftt_flat_image_returns_nothing(gpu, oracle):
 def test_gftt_many_candidates_chunked_sort(gpu, oracle):
     """> 8192 local maxima: exercises the chunked selection path of the sort kernel."""
     rng = np.random.default_rng(99)
-    g = rng.integers(0, 256, (300, 400), dtype=np.uint8)
+    g = rng.integers(0, 256, (480, 640), dtype=np.uint8)
     pts_o, nc = oracle.gftt(g, 3000, 0.0001, 3.0, 3)
     assert nc > 8192
     pts_g = gpu.gftt(g, 3000, 0.0001, 3.0, 3)

@@ -397,7 +397,7 @@ int run_gftt_op(const uint8_t* d_gray, size_t stride, int w, int h, int max_corn
         if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = VS_ERR_HIP; }
     }
     hipError_t e = hipStreamSynchronize(st);
-    hipFree(scratch);
+    (void)hipFree(scratch);
     if (rc == VS_OK && e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = VS_ERR_HIP; }
     return rc;
 }

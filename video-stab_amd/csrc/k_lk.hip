@@ -269,7 +269,7 @@ int run_pyr_lk_op(const uint8_t* d_prev, const uint8_t* d_next, size_t stride, i
     }
     if (rc == VS_OK) rc = launch_pyr_lk(L, levels, d_prev_pts, n, nullptr, d_next_pts, d_status, d_err, win, max_iters, eps, st);
     hipError_t e = hipStreamSynchronize(st);
-    hipFree(scratch);
+    (void)hipFree(scratch);
     if (rc == VS_OK && e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = VS_ERR_HIP; }
     return rc;
 }

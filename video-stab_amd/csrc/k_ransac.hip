@@ -302,7 +302,7 @@ int run_estimate_affine_partial2d(const float* d_from, const float* d_to, int n,
     VS_HIP_TRY(hipMalloc((void**)&counts, (size_t)max_iters * 4));
     int rc = launch_ransac(d_from, d_to, n, nullptr, 2, thr, max_iters, tab, counts, d_model, d_inliers, d_info, st);
     hipError_t e = hipStreamSynchronize(st);
-    hipFree(counts);
+    (void)hipFree(counts);
     if (rc == VS_OK && e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = VS_ERR_HIP; }
     return rc;
 }

@@ -67,6 +67,8 @@ struct vs_stab {
     bool first = true;
     int next_index = 0;
     int detect_counter = 0;
+    int n_transforms = 0;           // transforms_.size(), mirrored on the host
+    int last_out_w = 0, last_out_h = 0;
     int orig_w = 0, orig_h = 0;
     int host_radius = 30;
     // analysis images
@@ -135,11 +137,11 @@ void out_size(const vs_stab* s, int w, int h, int* ow, int* oh) {
 }
 
 void free_all(vs_stab* s) {
-    if (s->d_ring) hipFree(s->d_ring);
-    if (s->d_all) hipFree(s->d_all);
-    if (s->d_gftt_scratch) hipFree(s->d_gftt_scratch);
-    if (s->d_tmp) hipFree(s->d_tmp);
-    if (s->d_out) hipFree(s->d_out);
+    if (s->d_ring) (void)hipFree(s->d_ring);
+    if (s->d_all) (void)hipFree(s->d_all);
+    if (s->d_gftt_scratch) (void)hipFree(s->d_gftt_scratch);
+    if (s->d_tmp) (void)hipFree(s->d_tmp);
+    if (s->d_out) (void)hipFree(s->d_out);
     s->d_ring = s->d_all = s->d_tmp = s->d_out = nullptr;
     s->d_gftt_scratch = nullptr;
     s->allocated = false;
@@ -296,6 +298,7 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame) {
                            s->tab, s->d_counts, s->d_model, s->d_inliers, s->d_info, s->st));   // :644-659
     S_TRY(s, launch_traj_append(s->d_traj, s->tp, s->d_model, s->d_info, s->d_npts[pp], s->d_dbg,
                                 s->have_prev_gray ? 1 : 0, s->st));                  // :660-693
+    s->n_transforms++;
     s->last_detected = false;
     if ((++s->detect_counter % 2) == 0) {                                            // :696-746
         const int q = pp ^ 1;
@@ -322,7 +325,18 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride) {
     const uint8_t* frame = s->d_ring + (size_t)slot * s->frame_bytes;
     S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_dbg, s->st));
     int rc = VS_OK;
-    if (s->fmt == VS_FMT_NV12) {
+    int ow, oh;
+    out_size(s, s->w, s->h, &ow, &oh);
+    s->last_out_w = ow; s->last_out_h = oh;
+    if (idx >= s->n_transforms) {
+        // Stabilizer.cpp:774-780: no transform exists for this frame (last frame of a
+        // flush): the queued frame is returned as is, at its own size (no border pad).
+        if (ow != s->w || oh != s->h)
+            S_HIP(s, hipMemset2DAsync(d_out, out_stride, 0, (size_t)ow * s->cn, oh, s->st));
+        S_HIP(s, hipMemcpy2DAsync(d_out, out_stride, frame, s->row_bytes, s->row_bytes, s->rows_total,
+                                  hipMemcpyDeviceToDevice, s->st));
+        s->last_out_w = s->w; s->last_out_h = s->h;
+    } else if (s->fmt == VS_FMT_NV12) {
         rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_M, 1, s->st);
         if (rc == VS_OK)
             rc = launch_warp_affine(frame + (size_t)s->h * s->row_bytes, s->row_bytes, 0, s->w / 2, s->h / 2,
@@ -448,20 +462,20 @@ int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
 
 void vs_stab_destroy(vs_stab* s) {
     if (!s) return;
-    hipSetDevice(s->device);
-    if (s->st) hipStreamSynchronize(s->st);   // the destructor may race in-flight work (vsg.cpp:1374)
+    (void)hipSetDevice(s->device);
+    if (s->st) (void)hipStreamSynchronize(s->st);   // the destructor may race in-flight work (vsg.cpp:1374)
     free_all(s);
-    if (s->st) hipStreamDestroy(s->st);
+    if (s->st) (void)hipStreamDestroy(s->st);
     delete s;
 }
 
 int vs_stab_clean(vs_stab* s) {   // Stabilizer.cpp:221-256
     if (!s) return VS_ERR_INVALID_ARG;
-    hipSetDevice(s->device);
+    (void)hipSetDevice(s->device);
     if (s->st) S_HIP(s, hipStreamSynchronize(s->st));
     free_all(s);
     s->q_slot.clear(); s->q_idx.clear();
-    s->first = true; s->next_index = 0; s->w = s->h = 0; s->orig_w = s->orig_h = 0;
+    s->first = true; s->next_index = 0; s->w = s->h = 0; s->orig_w = s->orig_h = 0; s->n_transforms = 0;
     s->have_prev_gray = false; s->prev_small = false; s->cur = 0; s->pp = 0;
     s->host_radius = s->p.smoothing_radius;
     return VS_OK;
@@ -609,6 +623,12 @@ int vs_stab_get_debug_arrays(vs_stab* s, float* prev_pts, float* curr_pts, uint8
         if (aw) *aw = s->aw;
         if (ah) *ah = s->ah;
     }
+    return VS_OK;
+}
+
+int vs_stab_last_out_dims(const vs_stab* s, int* w, int* h) {
+    if (!s || !w || !h) return VS_ERR_INVALID_ARG;
+    *w = s->last_out_w; *h = s->last_out_h;
     return VS_OK;
 }
 

@@ -131,6 +131,7 @@ class VsLib:
         L.vs_stab_flush_dev.argtypes = [vp, vp, C.c_size_t, i32p]
         L.vs_stab_sync.argtypes = [vp]
         L.vs_stab_out_size.argtypes = [vp, C.c_int, C.c_int, i32p, i32p]
+        L.vs_stab_last_out_dims.argtypes = [vp, i32p, i32p]
         L.vs_stab_get_counters.argtypes = [vp, C.POINTER(VsCounters)]
         L.vs_stab_get_debug.argtypes = [vp, C.POINTER(VsDebugFrame)]
         L.vs_stab_get_debug_arrays.argtypes = [vp, f32p, f32p, u8p, u8p, f32p, u8p, i32p, i32p]
