@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stabilized frames/s on synthetic 1080p clips (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N>1 through torch.distributed.run;
+RANK / LOCAL_RANK / WORLD_SIZE come from the environment).  Each rank owns
+`--streams` independent video streams (default 1 = BASELINE configs[1]: one
+1920x1080 BGR8 stream, 200 corners, 3-level LK 21x21, RANSAC partial affine,
+warpAffine); streams never exchange data, so scaling is weak and there is no
+data-path collective - torch.distributed only provides the barrier and the
+max-over-ranks of the timed region.
+
+A step = one stabilize() (vs_stab_push_dev) per stream on a frame that is
+already resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "video-stab_amd"))
+
+from vsamd import capi, synth  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
+
+
+def make_params(vs):
+    # BASELINE.json configs[1]: 200 corners, 3-level LK (maxLevel 2) with a 21x21 window;
+    # everything else is the reference's live default (Stabilizer.h:76-175, Stabilizer.cpp:611-649).
+    return vs.params(max_corners=200, lk_win_size=21, lk_max_level=2, lk_max_iters=20, lk_epsilon=0.03,
+                     smoothing_radius=30)
+
+
+def clip_order(n_frames, n_steps):
+    """Ping-pong through the clip so consecutive frames always differ by one camera step."""
+    fwd = list(range(n_frames)) + list(range(n_frames - 2, 0, -1))
+    return [fwd[i % len(fwd)] for i in range(n_steps)]
+
+
+def cpu_baseline(width, height, frames, order_fn):
+    """The oracle (CPU restatement of src/Stabilizer.cpp, kind "port") on the same workload,
+    single thread, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    o = oracle_lib.load()
+    p = o.params(max_corners=200, lk_win_size=21, lk_max_level=2, lk_max_iters=20, lk_epsilon=0.03,
+                 smoothing_radius=30)
+    o.lib.vso_set_threads(1)
+    s = o.stabilizer(p)
+    warm, timed = 34, 90
+    order = order_fn(len(frames), warm + timed)
+    for i in order[:warm]:
+        s.push(frames[i])
+    t0 = time.perf_counter()
+    n_out = 0
+    for i in order[warm:]:
+        if s.push(frames[i]) is not None:
+            n_out += 1
+    dt = time.perf_counter() - t0
+    s.close()
+    # all-core variant of the same port (point-parallel LK, row-parallel warp)
+    ncores = os.cpu_count() or 1
+    o.lib.vso_set_threads(ncores)
+    s = o.stabilizer(p)
+    for i in order[:warm]:
+        s.push(frames[i])
+    t1 = time.perf_counter()
+    for i in order[warm:warm + 60]:
+        s.push(frames[i])
+    dt_mt = time.perf_counter() - t1
+    s.close()
+    o.lib.vso_set_threads(1)
+    return {
+        "value": round(timed / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": "%d steady-state stabilize() calls on the same %dx%d clip, oracle/ single thread" % (timed, width, height),
+        "all_cores": {"value": round(60 / dt_mt, 3), "cores": ncores,
+                      "note": "same port, LK points and warp rows spread over threads"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU (batch mode)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--clip-frames", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-stages", action="store_true", help="time every stage (adds event records)")
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph when available")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    vs = capi.load()
+    if vs.lib.vs_device_count() <= 0:
+        raise SystemExit("bench.py: no GPU visible - libvideo-stab has no CPU fallback")
+    vs.check(vs.lib.vs_dev_set_device(local_rank))
+
+    W, H = args.width, args.height
+    fb = W * H * 3
+    S = args.streams
+    # synthetic clips: stream j of rank r uses seed base + global stream id
+    clips, d_in = [], []
+    for j in range(S):
+        seed = synth.SEED_CONFIG2 + (rank * S + j)
+        frames = synth.make_clip(seed, W, H, args.clip_frames)
+        clips.append(frames)
+        buf = capi.DevBuf(vs, fb * len(frames))
+        for i, f in enumerate(frames):
+            buf.upload(f, i * fb)
+        d_in.append(buf)
+    d_out = [capi.DevBuf(vs, fb) for _ in range(S)]
+    stabs = [vs.stabilizer(make_params(vs), device=local_rank) for _ in range(S)]
+
+    preroll = 64   # past the 29-frame warm-up of smoothingRadius 30: every timed step produces a frame
+    total = preroll + args.warmup + args.steps
+    order = clip_order(args.clip_frames, total)
+
+    def step(i):
+        for j in range(S):
+            stabs[j].push_dev(d_in[j].ptr + order[i] * fb, W, H, W * 3, capi.FMT_BGR8, d_out[j].ptr, W * 3)
+
+    def sync_all():
+        for s in stabs:
+            s.sync()
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(preroll):
+        step(i)
+    sync_all()
+    if args.graph:
+        for s in stabs:
+            s.enable_graph(True)
+    for i in range(preroll, preroll + args.warmup):
+        step(i)
+    for s in stabs:
+        s.set_profiling(2 if args.profile_stages else 1)
+        s.stage_times()          # drop anything recorded so far
+    sync_all()
+    barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(preroll + args.warmup, total):
+        step(i)
+    sync_all()
+    barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-stage device time of the timed region (HIP events on the instance streams)
+    stage_ms = [0.0] * 8
+    stage_n = [0] * 8
+    for s in stabs:
+        ms, n = s.stage_times()
+        for k in range(8):
+            stage_ms[k] += ms[k]
+            stage_n[k] += n[k]
+    frames_out = sum(s.counters().frames_out for s in stabs)
+    assert frames_out >= args.steps * S, "timed steps did not all produce frames"
+
+    if rank == 0:
+        warp_bytes = 2.0 * fb                                    # algorithmic bytes per launch
+        warp_avg_ms = stage_ms[7] / max(stage_n[7], 1)
+        achieved = warp_bytes / (warp_avg_ms * 1e-3) / 1e9 if warp_avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "warp_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        total_frames = args.steps * S * n_gpus
+        out = {
+            "metric": "stabilized frames/sec @1080p (whole job; warp-stage HBM GB/s in roofline)",
+            "value": round(total_frames / elapsed, 2),
+            "unit": "frames/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d stream(s)/GPU %dx%d BGR8, 200 corners, 3-level LK 21x21, "
+                                   "RANSAC partial affine, warpAffine; frames resident in HBM" % (S, W, H),
+                       "streams_per_gpu": S, "graph": bool(args.graph)},
+            "roofline": {"bound": "hbm", "kernel": "warp_affine_kernel<3>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic, "bytes_per_launch": warp_bytes,
+                         "avg_launch_us": round(warp_avg_ms * 1e3, 3), "launches": stage_n[7]},
+        }
+        if args.profile_stages:
+            names = ["copy_in", "gray", "pyramid", "lk", "ransac", "traj", "gftt", "warp"]
+            out["stage_us_per_launch"] = {names[k]: round(stage_ms[k] / max(stage_n[k], 1) * 1e3, 2) for k in range(8)}
+            out["stage_launches"] = {names[k]: stage_n[k] for k in range(8)}
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, clips[0], clip_order)
+        print(json.dumps(out), flush=True)
+
+    for s in stabs:
+        s.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -190,7 +190,27 @@ void*       vs_stab_stream(vs_stab* s);    /* hipStream_t of the instance     */
  * on (two variants: with / without re-detection).  0 disables. */
 int vs_stab_enable_graph(vs_stab* s, int enable);
 
+/* Per-stage device timing with HIP events recorded on the instance stream
+ * (SURVEY.md section 5 "Tracing").  mode 0 = off, 1 = warp stage only,
+ * 2 = every stage.  vs_stab_get_stage_times() synchronises, adds the elapsed
+ * time of every event pair recorded since the last call into total_ms[stage]
+ * / launches[stage] (arrays of VS_STAGE_COUNT) and resets. */
+enum {
+    VS_STAGE_COPY_IN = 0,   /* frame into the queue ring                       */
+    VS_STAGE_GRAY = 1,      /* resize + BGR2GRAY                               */
+    VS_STAGE_PYRAMID = 2,   /* pyrDown + Scharr                                */
+    VS_STAGE_LK = 3,
+    VS_STAGE_RANSAC = 4,    /* compaction + score + select/refine              */
+    VS_STAGE_TRAJ = 5,      /* trajectory append + emit                        */
+    VS_STAGE_GFTT = 6,
+    VS_STAGE_WARP = 7,      /* warpAffine kernel(s) only                       */
+    VS_STAGE_COUNT = 8
+};
+int vs_stab_set_profiling(vs_stab* s, int mode);
+int vs_stab_get_stage_times(vs_stab* s, double* total_ms, int64_t* launches);
+
 /* ---- device memory helpers (so callers need no HIP headers) --------------- */
+int vs_dev_set_device(int device);          /* device used by the vs_dev_* / vs_op_* calls of this thread */
 int vs_dev_malloc(void** d_ptr, size_t bytes);
 int vs_dev_free(void* d_ptr);
 int vs_dev_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);

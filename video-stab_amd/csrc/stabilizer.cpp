@@ -105,7 +105,37 @@ struct vs_stab {
     size_t out_bytes = 0;
     uint8_t* d_all = nullptr;           // one allocation for the small buffers
     vs_counters counters;
+    // stage profiling (HIP events on the instance stream)
+    int prof_mode = 0;
+    struct Pending { hipEvent_t a, b; int stage; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
 };
+
+namespace {
+// Records an event pair around one stage when profiling is on.
+struct StageScope {
+    vs_stab* s;
+    int stage;
+    bool on = false;
+    hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(vs_stab* s) {
+        if (!s->ev_pool.empty()) { hipEvent_t e = s->ev_pool.back(); s->ev_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    StageScope(vs_stab* s_, int stage_) : s(s_), stage(stage_) {
+        if (s->prof_mode == 2 || (s->prof_mode == 1 && stage == VS_STAGE_WARP)) {
+            a = get(s); b = get(s);
+            if (a && b && hipEventRecord(a, s->st) == hipSuccess) on = true;
+        }
+    }
+    ~StageScope() {
+        if (on && hipEventRecord(b, s->st) == hipSuccess) s->pending.push_back({a, b, stage});
+    }
+};
+}  // namespace
 
 namespace {
 
@@ -275,12 +305,18 @@ int build_pyramid(vs_stab* s, int k) {
 int generate_transform(vs_stab* s, const uint8_t* d_frame) {
     const vs_params_c& p = s->p;
     const int c = s->cur, pv = s->cur ^ 1;
-    S_TRY(s, launch_resize_gray(d_frame, s->row_bytes, s->w, s->h, s->fmt, s->pyr[c].img[0], s->aw, s->aw, s->ah, s->st));  // :448-450
-    S_TRY(s, build_pyramid(s, c));
-    if (s->prev_small) {   // :598-603 (once: 480x270 -> analysis size)
-        S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[pv].img[0], s->aw, s->aw, s->ah, s->st));
-        S_TRY(s, build_pyramid(s, pv));
-        s->prev_small = false;
+    {
+        StageScope t(s, VS_STAGE_GRAY);
+        S_TRY(s, launch_resize_gray(d_frame, s->row_bytes, s->w, s->h, s->fmt, s->pyr[c].img[0], s->aw, s->aw, s->ah, s->st));  // :448-450
+    }
+    {
+        StageScope t(s, VS_STAGE_PYRAMID);
+        S_TRY(s, build_pyramid(s, c));
+        if (s->prev_small) {   // :598-603 (once: 480x270 -> analysis size)
+            S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[pv].img[0], s->aw, s->aw, s->ah, s->st));
+            S_TRY(s, build_pyramid(s, pv));
+            s->prev_small = false;
+        }
     }
     LKLevel L[MAX_PYR];
     for (int l = 0; l <= s->levels; l++) {
@@ -289,20 +325,30 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame) {
     }
     const int pp = s->pp;
     const int cap = s->pts_cap[pp];
-    S_TRY(s, launch_pyr_lk(L, s->levels, s->d_pts[pp], cap, s->d_npts[pp], s->d_next, s->d_status, s->d_err,
-                           p.lk_win_size, p.lk_max_iters, p.lk_epsilon, s->st));   // :611-619
+    {
+        StageScope t(s, VS_STAGE_LK);
+        S_TRY(s, launch_pyr_lk(L, s->levels, s->d_pts[pp], cap, s->d_npts[pp], s->d_next, s->d_status, s->d_err,
+                               p.lk_win_size, p.lk_max_iters, p.lk_epsilon, s->st));   // :611-619
+    }
     s->last_lk_pp = pp;
-    S_TRY(s, launch_compact(s->d_pts[pp], s->d_next, s->d_status, cap, s->d_npts[pp], s->d_vp, s->d_vc, s->d_m,
-                            s->d_dbg, s->st));                                       // :629-641
-    S_TRY(s, launch_ransac(s->d_vp, s->d_vc, std::max(cap, 0), s->d_m, 4, p.ransac_threshold, p.ransac_max_iters,
-                           s->tab, s->d_counts, s->d_model, s->d_inliers, s->d_info, s->st));   // :644-659
-    S_TRY(s, launch_traj_append(s->d_traj, s->tp, s->d_model, s->d_info, s->d_npts[pp], s->d_dbg,
-                                s->have_prev_gray ? 1 : 0, s->st));                  // :660-693
+    {
+        StageScope t(s, VS_STAGE_RANSAC);
+        S_TRY(s, launch_compact(s->d_pts[pp], s->d_next, s->d_status, cap, s->d_npts[pp], s->d_vp, s->d_vc, s->d_m,
+                                s->d_dbg, s->st));                                       // :629-641
+        S_TRY(s, launch_ransac(s->d_vp, s->d_vc, std::max(cap, 0), s->d_m, 4, p.ransac_threshold, p.ransac_max_iters,
+                               s->tab, s->d_counts, s->d_model, s->d_inliers, s->d_info, s->st));   // :644-659
+    }
+    {
+        StageScope t(s, VS_STAGE_TRAJ);
+        S_TRY(s, launch_traj_append(s->d_traj, s->tp, s->d_model, s->d_info, s->d_npts[pp], s->d_dbg,
+                                    s->have_prev_gray ? 1 : 0, s->st));                  // :660-693
+    }
     s->n_transforms++;
     s->last_detected = false;
     if ((++s->detect_counter % 2) == 0) {                                            // :696-746
         const int q = pp ^ 1;
         const int mc = std::min(p.max_corners, 200);
+        StageScope t(s, VS_STAGE_GFTT);
         S_TRY(s, launch_gftt(s->pyr[c].img[0], s->aw, s->aw, s->ah, mc, 0.02, 15.0, 3, s->gw, s->d_pts[q],
                              s->d_npts[q], s->st));
         s->pts_cap[q] = mc;
@@ -323,7 +369,10 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride) {
     const int slot = s->q_slot.front(), idx = s->q_idx.front();
     s->q_slot.pop_front(); s->q_idx.pop_front();
     const uint8_t* frame = s->d_ring + (size_t)slot * s->frame_bytes;
-    S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_dbg, s->st));
+    {
+        StageScope t(s, VS_STAGE_TRAJ);
+        S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_dbg, s->st));
+    }
     int rc = VS_OK;
     int ow, oh;
     out_size(s, s->w, s->h, &ow, &oh);
@@ -337,6 +386,7 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride) {
                                   hipMemcpyDeviceToDevice, s->st));
         s->last_out_w = s->w; s->last_out_h = s->h;
     } else if (s->fmt == VS_FMT_NV12) {
+        StageScope t(s, VS_STAGE_WARP);
         rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_M, 1, s->st);
         if (rc == VS_OK)
             rc = launch_warp_affine(frame + (size_t)s->h * s->row_bytes, s->row_bytes, 0, s->w / 2, s->h / 2,
@@ -345,15 +395,18 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride) {
     } else if (p.border_size > 0 && !p.crop_n_zoom) {                                 // :981-990
         const int b = p.border_size, bw = s->w + 2 * b, bh = s->h + 2 * b;
         rc = launch_make_border(frame, s->row_bytes, s->w, s->h, s->cn, s->d_tmp, (size_t)bw * s->cn, b, p.border_type, s->st);
+        StageScope t(s, VS_STAGE_WARP);
         if (rc == VS_OK)
             rc = launch_warp_affine(s->d_tmp, (size_t)bw * s->cn, 0, bw, bh, d_out, out_stride, 0, bw, bh, s->cn, s->d_M, 1, s->st);
     } else if (p.crop_n_zoom && p.border_size > 0 && s->w - 2 * p.border_size > 0 && s->h - 2 * p.border_size > 0) {  // :1108-1124
         const int b = p.border_size;
+        StageScope t(s, VS_STAGE_WARP);
         rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, s->d_tmp, s->row_bytes, 0, s->w, s->h, s->cn, s->d_M, 1, s->st);
         if (rc == VS_OK)
             rc = launch_resize_linear(s->d_tmp + ((size_t)b * s->w + b) * s->cn, s->row_bytes, s->w - 2 * b, s->h - 2 * b,
                                       s->cn, d_out, out_stride, s->orig_w, s->orig_h, s->st);
     } else {                                                                          // :1056-1060
+        StageScope t(s, VS_STAGE_WARP);
         rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, s->cn, s->d_M, 1, s->st);
     }
     s->free_slots.push_back(slot);
@@ -465,6 +518,8 @@ void vs_stab_destroy(vs_stab* s) {
     (void)hipSetDevice(s->device);
     if (s->st) (void)hipStreamSynchronize(s->st);   // the destructor may race in-flight work (vsg.cpp:1374)
     free_all(s);
+    for (auto& pe : s->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->st) (void)hipStreamDestroy(s->st);
     delete s;
 }
@@ -496,8 +551,11 @@ int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride
     if (rc != VS_OK) return rc;
     int slot;
     S_TRY(s, take_slot(s, &slot));
-    S_HIP(s, hipMemcpy2DAsync(s->d_ring + (size_t)slot * s->frame_bytes, s->row_bytes, d_data, stride, s->row_bytes,
-                              s->rows_total, hipMemcpyDeviceToDevice, s->st));
+    {
+        StageScope t(s, VS_STAGE_COPY_IN);
+        S_HIP(s, hipMemcpy2DAsync(s->d_ring + (size_t)slot * s->frame_bytes, s->row_bytes, d_data, stride, s->row_bytes,
+                                  s->rows_total, hipMemcpyDeviceToDevice, s->st));
+    }
     rc = push_common(s, slot, (uint8_t*)d_out, out_stride, produced);
     return rc;
 }
@@ -634,6 +692,31 @@ int vs_stab_last_out_dims(const vs_stab* s, int* w, int* h) {
 
 const char* vs_stab_last_error(const vs_stab* s) { return s ? s->err.c_str() : ""; }
 void* vs_stab_stream(vs_stab* s) { return s ? (void*)s->st : nullptr; }
+
+int vs_stab_set_profiling(vs_stab* s, int mode) {
+    if (!s || mode < 0 || mode > 2) return VS_ERR_INVALID_ARG;
+    s->prof_mode = mode;
+    return VS_OK;
+}
+
+int vs_stab_get_stage_times(vs_stab* s, double* total_ms, int64_t* launches) {
+    if (!s || !total_ms || !launches) return VS_ERR_INVALID_ARG;
+    for (int i = 0; i < VS_STAGE_COUNT; i++) { total_ms[i] = 0; launches[i] = 0; }
+    if (!s->st) return VS_OK;
+    S_HIP(s, hipSetDevice(s->device));
+    S_HIP(s, hipStreamSynchronize(s->st));
+    for (auto& pe : s->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess && pe.stage >= 0 && pe.stage < VS_STAGE_COUNT) {
+            total_ms[pe.stage] += ms;
+            launches[pe.stage]++;
+        }
+        s->ev_pool.push_back(pe.a);
+        s->ev_pool.push_back(pe.b);
+    }
+    s->pending.clear();
+    return VS_OK;
+}
 
 int vs_stab_enable_graph(vs_stab* s, int enable) {
     if (!s) return VS_ERR_INVALID_ARG;

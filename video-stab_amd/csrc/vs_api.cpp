@@ -105,6 +105,11 @@ const char* vs_status_string(int status) {
 const char* vs_last_error(void) { return get_last_error(); }
 
 // ---- device memory helpers ---------------------------------------------------
+int vs_dev_set_device(int device) {
+    VS_TRY(ensure_device());
+    VS_HIP_TRY(hipSetDevice(device));
+    return VS_OK;
+}
 int vs_dev_malloc(void** d_ptr, size_t bytes) {
     if (!d_ptr) return VS_ERR_INVALID_ARG;
     VS_TRY(ensure_device());

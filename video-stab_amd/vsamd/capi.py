@@ -140,6 +140,9 @@ class VsLib:
         L.vs_stab_stream.restype = vp
         L.vs_stab_stream.argtypes = [vp]
         L.vs_stab_enable_graph.argtypes = [vp, C.c_int]
+        L.vs_stab_set_profiling.argtypes = [vp, C.c_int]
+        L.vs_stab_get_stage_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.vs_dev_set_device.argtypes = [C.c_int]
         L.vs_dev_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
         L.vs_dev_free.argtypes = [vp]
         L.vs_dev_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
@@ -364,6 +367,16 @@ class Stabilizer:
 
     def enable_graph(self, on=True):
         self.vs.check(self.lib.vs_stab_enable_graph(self.h, int(on)), self.h)
+
+    def set_profiling(self, mode):
+        self.vs.check(self.lib.vs_stab_set_profiling(self.h, int(mode)), self.h)
+
+    def stage_times(self):
+        """(total_ms[8], launches[8]) accumulated since the last call (synchronises)."""
+        ms = (C.c_double * 8)()
+        n = (C.c_int64 * 8)()
+        self.vs.check(self.lib.vs_stab_get_stage_times(self.h, ms, n), self.h)
+        return list(ms), list(n)
 
     def counters(self):
         c = VsCounters()
