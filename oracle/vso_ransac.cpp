@@ -7,8 +7,8 @@
 //
 // Definition choice: the refinement's residual is linear in
 // (a,b,tx,ty), so cv::LMSolver converges to the linear least-squares solution;
-// the oracle solves the 4x4 normal equations in closed form (double, inliers
-// summed in index order).  Expected gap to an LM run: ~1e-12 relative.
+// the oracle solves the 4x4 normal equations in closed form (double; summation
+// order documented at refine()).  Expected gap to an LM run: ~1e-12 relative.
 #include "vso_internal.h"
 
 #include <algorithm>
@@ -66,20 +66,37 @@ static int find_inliers(const float* from, const float* to, int n, const double*
     return nz;
 }
 
-// least squares for X = a x - b y + tx, Y = b x + a y + ty over the inliers
+// least squares for X = a x - b y + tx, Y = b x + a y + ty over the inliers.
+// Summation order (any order is a valid restatement of the LS solution; this
+// one is what a 64-lane wavefront does): partial sum l takes the inliers with
+// index i = l, l+64, l+128, ... in increasing i; the 64 partials are then
+// combined by a butterfly, s[l] += s[l ^ off] for off = 32,16,8,4,2,1.
 static void refine(const float* from, const float* to, int n, const uint8_t* mask, double M[6]) {
-    double Sx = 0, Sy = 0, SX = 0, SY = 0, Sxx = 0, SxX = 0, SxY = 0;
+    double P[7][64];
+    for (auto& q : P) for (double& v : q) v = 0;
     int m = 0;
     for (int i = 0; i < n; i++) {
         if (!mask[i]) continue;
+        const int l = i & 63;
         double x = from[2 * i], y = from[2 * i + 1], X = to[2 * i], Y = to[2 * i + 1];
-        Sx += x; Sy += y; SX += X; SY += Y;
-        Sxx += x * x + y * y;
-        SxX += x * X + y * Y;
-        SxY += x * Y - y * X;
+        P[0][l] += x; P[1][l] += y; P[2][l] += X; P[3][l] += Y;
+        P[4][l] += x * x + y * y;
+        P[5][l] += x * X + y * Y;
+        P[6][l] += x * Y - y * X;
         m++;
     }
     if (m == 0) return;
+    double S[7];
+    for (int q = 0; q < 7; q++) {
+        double cur[64], nxt[64];
+        for (int l = 0; l < 64; l++) cur[l] = P[q][l];
+        for (int off = 32; off >= 1; off >>= 1) {
+            for (int l = 0; l < 64; l++) nxt[l] = cur[l] + cur[l ^ off];
+            for (int l = 0; l < 64; l++) cur[l] = nxt[l];
+        }
+        S[q] = cur[0];
+    }
+    const double Sx = S[0], Sy = S[1], SX = S[2], SY = S[3], Sxx = S[4], SxX = S[5], SxY = S[6];
     double N = (double)m;
     double den = N * Sxx - Sx * Sx - Sy * Sy;
     if (!(std::abs(den) > 0)) return;  // degenerate (all inliers coincide): keep the RANSAC model

@@ -20,6 +20,9 @@
 // Float definitions (no FMA contraction, see oracle/vso_gftt.cpp header):
 //   Dx = ((r0+r2)*f1 + r1*f0), Dy = t2 - t0, f1=(float)(1/(4*bs*255)), f0=2*f1
 //   box sums in double (exact), lambda = (a+c) - sqrtf((a-c)*(a-c) + b*b).
+#include <cstdio>
+#include <cstdlib>
+
 #include "vs_common.h"
 
 namespace vsd {
@@ -34,7 +37,7 @@ constexpr int SORT_CAP = 8192;
 constexpr int CELLS_MAX = 2560;
 constexpr int SLOTS = 4;
 constexpr int ACC_MAX = 4096;
-constexpr int SEL_NT = 1024;
+constexpr int SEL_NT = 256;
 
 __device__ __forceinline__ uint32_t order_key(float v) {
     uint32_t b = __float_as_uint(v);
@@ -153,7 +156,7 @@ struct SelArgs {
     const unsigned long long* cand;
     int32_t* counters;
     int cap, w, h, max_corners;
-    double min_dist2;      // minDistance^2 (double, as cv compares it)
+    int min_dist2_i;       // ceil(minDistance^2): integer d2 < minDistance^2  <=>  d2 < ceil(minDistance^2)
     int use_dist;          // minDistance >= 1
     int cell, gw, gh;
     float* out_pts;
@@ -182,11 +185,16 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(SelArgs a) {
         __syncthreads();
         if (tid == 0) s_cnt = 0;
         __syncthreads();
-        int local = 0;
-        for (int i = tid; i < ncand; i += SEL_NT) local += a.cand[i] < upper ? 1 : 0;
-        if (local) atomicAdd(&s_cnt, local);
-        __syncthreads();
-        const int remaining = s_cnt;
+        int remaining;
+        if (upper == ~0ull && ncand <= SORT_CAP) {
+            remaining = ncand;               // first (and only) chunk: no counting pass needed
+        } else {
+            int local = 0;
+            for (int i = tid; i < ncand; i += SEL_NT) local += a.cand[i] < upper ? 1 : 0;
+            if (local) atomicAdd(&s_cnt, local);
+            __syncthreads();
+            remaining = s_cnt;
+        }
         if (remaining == 0) break;
         unsigned long long lo = 0;   // keys in [lo, upper) form the chunk
         if (remaining > SORT_CAP) {
@@ -237,6 +245,18 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(SelArgs a) {
                 __syncthreads();
             }
         }
+        // ---- decode the sorted keys in place: key -> (x | y<<16) | (xc | yc<<16) << 32
+        // (integer divisions by w and by the cell size happen here, in parallel)
+        const unsigned long long last_key = m > 0 ? keys[m - 1] : 0ull;
+        __syncthreads();
+        for (int i = tid; i < m; i += SEL_NT) {
+            const int idx = (int)(uint32_t)keys[i];
+            const int y = idx / a.w, x = idx - y * a.w;
+            const int xc = x / a.cell, yc = y / a.cell;
+            keys[i] = (unsigned long long)((uint32_t)x | ((uint32_t)y << 16)) |
+                      ((unsigned long long)((uint32_t)xc | ((uint32_t)yc << 16)) << 32);
+        }
+        __syncthreads();
         // ---- greedy selection by wave 0 (sequential-equivalent)
         if (tid < 64) {
             const int lane = tid;
@@ -244,80 +264,88 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(SelArgs a) {
             volatile uint32_t* vcnt = cell_cnt;
             volatile uint32_t* vpts = cell_pts;
             volatile uint32_t* vacc = acc_xy;
+            const int md2 = a.min_dist2_i;
             bool full = false;
             for (int base = 0; base < m && !full; base += 64) {
                 const int i = base + lane;
                 const bool has = i < m;
-                const unsigned long long key = has ? keys[i] : 0ull;
-                const int idx = (int)(uint32_t)key;
-                const int y = idx / a.w, x = idx - y * a.w;
-                int xc = 0, yc = 0;
+                const unsigned long long e = has ? keys[i] : 0ull;
+                const uint32_t xy = (uint32_t)e;
+                const int x = (int)(xy & 0xFFFFu), y = (int)(xy >> 16);
+                const int xc = (int)((uint32_t)(e >> 32) & 0xFFFFu), yc = (int)((uint32_t)(e >> 48));
                 bool ok = has;
-                if (a.use_dist) {
-                    xc = x / a.cell; yc = y / a.cell;
-                    if (ok) {
-                        if (grid_ok) {
-                            const int cx1 = xc > 0 ? xc - 1 : 0, cx2 = xc + 1 < a.gw ? xc + 1 : a.gw - 1;
-                            const int cy1 = yc > 0 ? yc - 1 : 0, cy2 = yc + 1 < a.gh ? yc + 1 : a.gh - 1;
-                            for (int cy = cy1; cy <= cy2 && ok; cy++)
-                                for (int cx = cx1; cx <= cx2 && ok; cx++) {
-                                    const int c = cy * a.gw + cx;
-                                    int cnt = (int)vcnt[c];
-                                    cnt = cnt < SLOTS ? cnt : SLOTS;
-                                    for (int s = 0; s < cnt; s++) {
-                                        const uint32_t p = vpts[c * SLOTS + s];
-                                        const int dx = x - (int)(p & 0xFFFFu), dy = y - (int)(p >> 16);
-                                        if ((double)(dx * dx + dy * dy) < a.min_dist2) { ok = false; break; }
-                                    }
-                                }
-                        } else {
-                            for (int s = 0; s < nacc && ok; s++) {
-                                const uint32_t p = vacc[s];
-                                const int ax = (int)(p & 0xFFFFu), ay = (int)(p >> 16);
-                                const int dcx = ax / a.cell - xc, dcy = ay / a.cell - yc;
-                                if (dcx >= -1 && dcx <= 1 && dcy >= -1 && dcy <= 1) {
-                                    const int dx = x - ax, dy = y - ay;
-                                    if ((double)(dx * dx + dy * dy) < a.min_dist2) ok = false;
-                                }
+                if (a.use_dist && ok) {
+                    if (grid_ok) {
+                        // counts of the 3x3 neighbourhood first (independent LDS reads), then
+                        // the few occupied cells
+                        int cidx[9];
+                        uint32_t cnt[9];
+#pragma unroll
+                        for (int q = 0; q < 9; q++) {
+                            const int cx = xc + (q % 3) - 1, cy = yc + (q / 3) - 1;
+                            const bool in = cx >= 0 && cx < a.gw && cy >= 0 && cy < a.gh;
+                            cidx[q] = in ? cy * a.gw + cx : -1;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 9; q++) cnt[q] = cidx[q] >= 0 ? vcnt[cidx[q]] : 0u;
+#pragma unroll
+                        for (int q = 0; q < 9; q++) {
+                            const int c = cnt[q] < (uint32_t)SLOTS ? (int)cnt[q] : SLOTS;
+                            for (int sl = 0; sl < c; sl++) {
+                                const uint32_t p = vpts[cidx[q] * SLOTS + sl];
+                                const int dx = x - (int)(p & 0xFFFFu), dy = y - (int)(p >> 16);
+                                if (dx * dx + dy * dy < md2) ok = false;
                             }
                         }
+                    } else {
+                        for (int sl = 0; sl < nacc && ok; sl++) {
+                            const uint32_t p = vacc[sl];
+                            const int dx = x - (int)(p & 0xFFFFu), dy = y - (int)(p >> 16);
+                            if (dx * dx + dy * dy < md2) ok = false;
+                        }
                     }
                 }
+                // in-step order: visit the surviving lanes from the strongest on; a visited lane is
+                // accepted and knocks out the later lanes it conflicts with (registers only);
+                // grid / output updates of the accepted lanes happen together after the loop
                 unsigned long long mask = __ballot(ok);
+                unsigned long long accepted = 0ull;
+                const int nacc0 = nacc;
                 while (mask) {
-                    const int j = __ffsll((long long)mask) - 1;
-                    const int xj = __shfl(x, j, 64), yj = __shfl(y, j, 64);
-                    const int xcj = __shfl(xc, j, 64), ycj = __shfl(yc, j, 64);
-                    if (lane == j) {
-                        a.out_pts[2 * nacc] = (float)x;
-                        a.out_pts[2 * nacc + 1] = (float)y;
-                        const uint32_t packed = (uint32_t)x | ((uint32_t)y << 16);
-                        if (nacc < ACC_MAX) vacc[nacc] = packed;
-                        if (grid_ok) {
-                            const int c = yc * a.gw + xc;
-                            const uint32_t slot = vcnt[c];
-                            if (slot < (uint32_t)SLOTS) vpts[c * SLOTS + slot] = packed;
-                            else s_overflow = 1;
-                            vcnt[c] = slot + 1;
-                        }
-                        ok = false;
-                    }
+                    const int j = __ffsll((long long)mask) - 1;     // wave-uniform
+                    accepted |= 1ull << j;
                     nacc++;
                     if (nacc == a.max_corners) { full = true; break; }
-                    if (ok && a.use_dist) {
-                        const int dcx = xc - xcj, dcy = yc - ycj;
-                        if (dcx >= -1 && dcx <= 1 && dcy >= -1 && dcy <= 1) {
-                            const int dx = x - xj, dy = y - yj;
-                            if ((double)(dx * dx + dy * dy) < a.min_dist2) ok = false;
-                        }
+                    if (a.use_dist) {
+                        // a pair closer than minDistance always sits in neighbouring cells
+                        // (|dx| < minDistance <= cell + 0.5), so the distance test alone decides
+                        const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)xy, j);
+                        const int dx = x - (int)(pj & 0xFFFFu), dy = y - (int)(pj >> 16);
+                        if (dx * dx + dy * dy < md2) ok = false;
                     }
+                    if (lane == j) ok = false;
                     mask = __ballot(ok);
                 }
+                if ((accepted >> lane) & 1ull) {
+                    const int pos = nacc0 + __popcll(accepted & ((1ull << lane) - 1ull));
+                    a.out_pts[2 * pos] = (float)x;
+                    a.out_pts[2 * pos + 1] = (float)y;
+                    const uint32_t packed = (uint32_t)x | ((uint32_t)y << 16);
+                    if (pos < ACC_MAX) acc_xy[pos] = packed;
+                    if (grid_ok) {
+                        const int c = yc * a.gw + xc;
+                        const uint32_t slot = atomicAdd(&cell_cnt[c], 1u);
+                        if (slot < (uint32_t)SLOTS) cell_pts[c * SLOTS + slot] = packed;
+                        else s_overflow = 1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
             }
             if (lane == 0) {
                 s_nacc = nacc;
                 if (full) s_done = 1;
-                if (m > 0) s_upper = keys[m - 1];   // smallest key of this chunk
+                if (m > 0) s_upper = last_key;   // smallest key of this chunk
                 else s_done = 1;
             }
         }
@@ -372,7 +400,7 @@ int launch_gftt(const uint8_t* d_gray, size_t stride, int w, int h, int max_corn
     a.counters = wk.counters;
     a.cap = wk.cap; a.w = w; a.h = h; a.max_corners = max_corners;
     a.use_dist = min_distance >= 1 ? 1 : 0;
-    a.min_dist2 = min_distance * min_distance;
+    a.min_dist2_i = (int)std::ceil(std::min(min_distance * min_distance, 2.0e9));
     a.cell = a.use_dist ? (int)lrint(min_distance) : 1;
     a.gw = (w + a.cell - 1) / a.cell;
     a.gh = (h + a.cell - 1) / a.cell;

@@ -33,10 +33,46 @@ struct LKArgs {
     double eps2;
 };
 
-__device__ __forceinline__ long long wave_sum(long long v) {
+// ---- exact wave-wide integer sums without LDS traffic -----------------------
+// Butterfly inside each 16-lane row with DPP (xor 1, xor 2, half-mirror, mirror),
+// then the four row totals are read with v_readlane and added on the scalar unit.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+// 64-bit variant: the partner's (lo,hi) pair is fetched with two DPP moves and added
+// with a normal 64-bit add, four butterfly steps per 16-lane row, then the four row
+// totals are read with v_readlane and added on the scalar unit.  Per-lane partial
+// sums fit int32 (<= 16 px * 8160 * 4080); the wave total may not.
+template <int CTRL>
+__device__ __forceinline__ long long dpp_mov64(long long v) {
+    const int lo = dpp_mov<CTRL>((int)(unsigned)(unsigned long long)v);
+    const int hi = dpp_mov<CTRL>((int)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long long wave_sum(int p) {
+    long long v = p;
+    v += dpp_mov64<0xB1>(v);
+    v += dpp_mov64<0x4E>(v);
+    v += dpp_mov64<0x141>(v);
+    v += dpp_mov64<0x140>(v);
+    const int lo = (int)(unsigned)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
+    long long t = 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    for (int r = 0; r < 64; r += 16) {
+        const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, r);
+        const unsigned h = (unsigned)__builtin_amdgcn_readlane(hi, r);
+        t += (long long)(((unsigned long long)h << 32) | l);
+    }
+    return t;
 }
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -66,24 +102,53 @@ __device__ __forceinline__ short2 load_deriv(const int16_t* __restrict__ d, int 
     return *reinterpret_cast<const short2*>(d + ((size_t)y * w + x) * 2);
 }
 
+constexpr int LK_MARGIN = 6;                       // search region = window + 1 + 2*margin
+constexpr int LK_WIN_MAX = 31;
+constexpr int LK_PW_MAX = LK_WIN_MAX + 1;          // template patch side (bilinear needs +1)
+constexpr int LK_REG_MAX = LK_WIN_MAX + 1 + 2 * LK_MARGIN;
+
+// i / d and i % d for 0 <= i < 4096, 1 <= d <= 64 (exact: the float product is
+// off by < 1e-3 from the true quotient and we add 0.5/d of slack)
+__device__ __forceinline__ void divmod_small(int i, int d, float inv_d, int& q, int& r) {
+    q = (int)(((float)i + 0.5f) * inv_d);
+    r = i - q * d;
+}
+
 template <int NPX>
 __global__ __launch_bounds__(64) void lk_kernel(LKArgs a) {
+    // Per level everything the wave will touch is staged into LDS with ONE round of
+    // global loads: the template patch of the previous image, its derivative patch,
+    // and the search region of the next image (pyramid padding already applied).
+    __shared__ uint8_t pI[LK_PW_MAX * LK_PW_MAX];
+    __shared__ short2 pD[LK_PW_MAX * LK_PW_MAX];
+    __shared__ uint8_t region[LK_REG_MAX * LK_REG_MAX];
     const int pt = blockIdx.x;
     const int lane = threadIdx.x;
     int n = a.n;
     if (a.d_n) { int dn = *a.d_n; n = dn < n ? dn : n; }
     if (pt >= n) return;
     const int win = a.win, area = win * win;
-    int ox[NPX], oy[NPX];
+    const int PW = win + 1;
+    const int RW = win + 1 + 2 * LK_MARGIN;
+    const float inv_pw = 1.0f / (float)PW, inv_rw = 1.0f / (float)RW, inv_win = 1.0f / (float)win;
+    int poff[NPX], roff[NPX], ox[NPX], oy[NPX];
     bool valid[NPX];
 #pragma unroll
     for (int k = 0; k < NPX; k++) {
         const int p = lane + 64 * k;
         valid[k] = p < area;
-        const int yy = valid[k] ? p / win : 0;
-        oy[k] = yy;
-        ox[k] = valid[k] ? p - yy * win : 0;
+        int yy = 0, xx = 0;
+        if (valid[k]) divmod_small(p, win, inv_win, yy, xx);
+        ox[k] = xx; oy[k] = yy;
+        poff[k] = yy * PW + xx;
+        roff[k] = yy * RW + xx;
     }
+    // lane-strided walks over the PW x PW patch and the RW x RW region: start and step
+    int p_y0, p_x0, p_sy, p_sx, r_y0, r_x0, r_sy, r_sx;
+    divmod_small(lane, PW, inv_pw, p_y0, p_x0);
+    divmod_small(64, PW, inv_pw, p_sy, p_sx);
+    divmod_small(lane, RW, inv_rw, r_y0, r_x0);
+    divmod_small(64, RW, inv_rw, r_sy, r_sx);
     const float halfWin = (win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float px0 = a.prev_pts[2 * pt], py0 = a.prev_pts[2 * pt + 1];
@@ -103,28 +168,62 @@ __global__ __launch_bounds__(64) void lk_kernel(LKArgs a) {
             if (level == 0) { status = 0; err = 0.f; }
             continue;
         }
-        Weights wt = make_weights(prevx - ipx, prevy - ipy);
-        short Iw[NPX], Ix[NPX], Iy[NPX];
-        long long sA11 = 0, sA12 = 0, sA22 = 0;
-#pragma unroll
-        for (int k = 0; k < NPX; k++) {
-            Iw[k] = 0; Ix[k] = 0; Iy[k] = 0;
-            if (valid[k]) {
-                const int X = ipx + ox[k], Y = ipy + oy[k];
-                const int ival = sample_img(L.prev, L.stride, L.w, L.h, X, Y, wt);
-                const short2 d00 = load_deriv(L.deriv, L.w, L.h, X, Y);
-                const short2 d01 = load_deriv(L.deriv, L.w, L.h, X + 1, Y);
-                const short2 d10 = load_deriv(L.deriv, L.w, L.h, X, Y + 1);
-                const short2 d11 = load_deriv(L.deriv, L.w, L.h, X + 1, Y + 1);
-                const int ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
-                const int iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
-                Iw[k] = (short)ival; Ix[k] = (short)ixval; Iy[k] = (short)iyval;
-                sA11 += (long long)(ixval * ixval);
-                sA12 += (long long)(ixval * iyval);
-                sA22 += (long long)(iyval * iyval);
+        float cx = outx - halfWin, cy = outy - halfWin;
+        const int rx0 = f_floor(cx) - LK_MARGIN, ry0 = f_floor(cy) - LK_MARGIN;
+        // ---- stage (all loads of the level are in flight together).  Lane-strided element
+        // walk with incremental (row, col); patches that lie inside the image (the common
+        // case) skip the border arithmetic.
+        __syncthreads();
+        {
+            const bool inside = ipx >= 0 && ipy >= 0 && ipx + PW <= L.w && ipy + PW <= L.h;
+            int y = p_y0, x = p_x0;
+            for (int i = lane; i < PW * PW; i += 64) {
+                const int X = ipx + x, Y = ipy + y;
+                if (inside) {
+                    pI[i] = L.prev[(size_t)Y * L.stride + X];
+                    pD[i] = *reinterpret_cast<const short2*>(L.deriv + ((size_t)Y * L.w + X) * 2);
+                } else {
+                    pI[i] = L.prev[(size_t)reflect101(Y, L.h) * L.stride + reflect101(X, L.w)];
+                    pD[i] = load_deriv(L.deriv, L.w, L.h, X, Y);
+                }
+                x += p_sx; y += p_sy;
+                if (x >= PW) { x -= PW; y++; }
             }
         }
-        sA11 = wave_sum(sA11); sA12 = wave_sum(sA12); sA22 = wave_sum(sA22);
+        {
+            const bool inside = rx0 >= 0 && ry0 >= 0 && rx0 + RW <= L.w && ry0 + RW <= L.h;
+            int y = r_y0, x = r_x0;
+            for (int i = lane; i < RW * RW; i += 64) {
+                const int X = rx0 + x, Y = ry0 + y;
+                region[i] = inside ? L.next[(size_t)Y * L.stride + X]
+                                   : L.next[(size_t)reflect101(Y, L.h) * L.stride + reflect101(X, L.w)];
+                x += r_sx; y += r_sy;
+                if (x >= RW) { x -= RW; y++; }
+            }
+        }
+        __syncthreads();
+        // ---- template window, its gradients and the 2x2 matrix
+        Weights wt = make_weights(prevx - ipx, prevy - ipy);
+        short Iw[NPX], Ix[NPX], Iy[NPX];
+        int pA11 = 0, pA12 = 0, pA22 = 0;
+#pragma unroll
+        for (int k = 0; k < NPX; k++) {
+            // invalid slots read offset 0 and are zeroed afterwards
+            const int o = poff[k];
+            int ival = descale(__mul24((int)pI[o], wt.w00) + __mul24((int)pI[o + 1], wt.w01) +
+                               __mul24((int)pI[o + PW], wt.w10) + __mul24((int)pI[o + PW + 1], wt.w11), 9);
+            const short2 d00 = pD[o], d01 = pD[o + 1], d10 = pD[o + PW], d11 = pD[o + PW + 1];
+            int ixval = descale(__mul24((int)d00.x, wt.w00) + __mul24((int)d01.x, wt.w01) +
+                                __mul24((int)d10.x, wt.w10) + __mul24((int)d11.x, wt.w11), 14);
+            int iyval = descale(__mul24((int)d00.y, wt.w00) + __mul24((int)d01.y, wt.w01) +
+                                __mul24((int)d10.y, wt.w10) + __mul24((int)d11.y, wt.w11), 14);
+            if (!valid[k]) { ival = 0; ixval = 0; iyval = 0; }
+            Iw[k] = (short)ival; Ix[k] = (short)ixval; Iy[k] = (short)iyval;
+            pA11 += __mul24(ixval, ixval);
+            pA12 += __mul24(ixval, iyval);
+            pA22 += __mul24(iyval, iyval);
+        }
+        const long long sA11 = wave_sum(pA11), sA12 = wave_sum(pA12), sA22 = wave_sum(pA22);
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
@@ -134,7 +233,6 @@ __global__ __launch_bounds__(64) void lk_kernel(LKArgs a) {
             continue;
         }
         D = 1.f / D;
-        float cx = outx - halfWin, cy = outy - halfWin;
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < a.max_count; j++) {
             const int inx = f_floor(cx), iny = f_floor(cy);
@@ -143,16 +241,34 @@ __global__ __launch_bounds__(64) void lk_kernel(LKArgs a) {
                 break;
             }
             wt = make_weights(cx - inx, cy - iny);
-            long long sb1 = 0, sb2 = 0;
+            const int lx = inx - rx0, ly = iny - ry0;
+            const bool in_region = lx >= 0 && ly >= 0 && lx + win + 1 <= RW && ly + win + 1 <= RW;
+            int pb1 = 0, pb2 = 0;
+            if (in_region) {
+                // every slot is computed unconditionally (invalid slots carry Ix = Iy = 0 and a
+                // safe offset), so the LDS reads of all pixels are in flight together
+                const int rbase = ly * RW + lx;
 #pragma unroll
-            for (int k = 0; k < NPX; k++) {
-                if (valid[k]) {
-                    const int diff = sample_img(L.next, L.stride, L.w, L.h, inx + ox[k], iny + oy[k], wt) - Iw[k];
-                    sb1 += (long long)(diff * Ix[k]);
-                    sb2 += (long long)(diff * Iy[k]);
+                for (int k = 0; k < NPX; k++) {
+                    const uint8_t* r0 = &region[rbase + roff[k]];
+                    // signed 24-bit multiplies: w11 = 2^14 - w00 - w01 - w10 can be -1
+                    const int v = descale(__mul24((int)r0[0], wt.w00) + __mul24((int)r0[1], wt.w01) +
+                                          __mul24((int)r0[RW], wt.w10) + __mul24((int)r0[RW + 1], wt.w11), 9);
+                    const int diff = v - Iw[k];
+                    pb1 += __mul24(diff, (int)Ix[k]);
+                    pb2 += __mul24(diff, (int)Iy[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NPX; k++) {
+                    if (valid[k]) {
+                        const int diff = sample_img(L.next, L.stride, L.w, L.h, inx + ox[k], iny + oy[k], wt) - Iw[k];
+                        pb1 += diff * Ix[k];
+                        pb2 += diff * Iy[k];
+                    }
                 }
             }
-            sb1 = wave_sum(sb1); sb2 = wave_sum(sb2);
+            const long long sb1 = wave_sum(pb1), sb2 = wave_sum(pb2);
             const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
@@ -172,16 +288,30 @@ __global__ __launch_bounds__(64) void lk_kernel(LKArgs a) {
                 status = 0;
             } else {
                 wt = make_weights(npx - inx, npy - iny);
-                long long es = 0;
+                const int lx = inx - rx0, ly = iny - ry0;
+                const bool in_region = lx >= 0 && ly >= 0 && lx + win + 1 <= RW && ly + win + 1 <= RW;
+                int es = 0;
+                if (in_region) {
+                    const int rbase = ly * RW + lx;
 #pragma unroll
-                for (int k = 0; k < NPX; k++) {
-                    if (valid[k]) {
-                        const int diff = sample_img(L.next, L.stride, L.w, L.h, inx + ox[k], iny + oy[k], wt) - Iw[k];
-                        es += diff < 0 ? -diff : diff;
+                    for (int k = 0; k < NPX; k++) {
+                        const uint8_t* r0 = &region[rbase + roff[k]];
+                        const int v = descale(__mul24((int)r0[0], wt.w00) + __mul24((int)r0[1], wt.w01) +
+                                              __mul24((int)r0[RW], wt.w10) + __mul24((int)r0[RW + 1], wt.w11), 9);
+                        const int diff = v - Iw[k];
+                        es += valid[k] ? (diff < 0 ? -diff : diff) : 0;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPX; k++) {
+                        if (valid[k]) {
+                            const int diff = sample_img(L.next, L.stride, L.w, L.h, inx + ox[k], iny + oy[k], wt) - Iw[k];
+                            es += diff < 0 ? -diff : diff;
+                        }
                     }
                 }
-                es = wave_sum(es);
-                err = (float)es * 1.f / (float)(32 * win * win);
+                const long long est = wave_sum(es);
+                err = (float)est * 1.f / (float)(32 * win * win);
             }
         }
     }

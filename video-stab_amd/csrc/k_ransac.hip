@@ -22,6 +22,9 @@
 #include <mutex>
 #include <vector>
 
+#include <cstring>
+
+#include "traj_device.h"
 #include "vs_common.h"
 
 namespace vsd {
@@ -150,11 +153,20 @@ __device__ __forceinline__ bool is_inlier(const float F[6], float fx, float fy, 
     return a * a + b * b <= t;
 }
 
+constexpr int MAX_PTS = 4096;
+
 struct RansacArgs {
+    // correspondences.  With `status` != nullptr they are the raw LK output
+    // (prev/next + status) and every workgroup compacts them itself
+    // (Stabilizer.cpp:629-641); workgroup 0 also stores the compacted lists.
     const float* from;
     const float* to;
+    const uint8_t* status;
     int n;                    // host count (capacity); device count overrides when d_n != nullptr
     const int32_t* d_n;
+    float* vp;                // compacted lists (written when status != nullptr)
+    float* vc;
+    int32_t* d_m;             // compacted count
     int min_points;           // 2 for the plain operator, 4 when gated like Stabilizer.cpp:645
     float t;                  // (float)(thr*thr)
     int iters;
@@ -165,6 +177,11 @@ struct RansacArgs {
     double* model;            // out: 6 doubles (NaN when no model)
     uint8_t* inliers;         // out: n bytes
     int32_t* info;            // out: {ok, best_iter, iters_run, n_inliers}
+    // fused trajectory append (pipeline only)
+    TrajState* traj;
+    TrajParams tp;
+    vs_debug_frame* dbg;
+    int have_prev_gray;
 };
 
 __device__ __forceinline__ int device_count(const RansacArgs& a) {
@@ -173,120 +190,193 @@ __device__ __forceinline__ int device_count(const RansacArgs& a) {
     return n;
 }
 
+// Order-preserving compaction of the tracked pairs into LDS; returns M.
+__device__ __forceinline__ int compact_to_lds(const RansacArgs& a, int n, float2* sf, float2* st, int lane) {
+    int m = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool keep = i < n && (a.status == nullptr || a.status[i] != 0);
+        const unsigned long long mask = __ballot(keep);
+        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) {
+            sf[pos] = make_float2(a.from[2 * i], a.from[2 * i + 1]);
+            st[pos] = make_float2(a.to[2 * i], a.to[2 * i + 1]);
+        }
+        m += __popcll(mask);
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(64) void ransac_score_kernel(RansacArgs a) {
+    extern __shared__ float2 s_pts[];          // [2][a.n]: compacted from / to
+    float2* sf = s_pts;
+    float2* st = s_pts + a.n;
     const int k = blockIdx.x, lane = threadIdx.x;
     const int n = device_count(a);
-    if (n < a.min_points || n <= 2 || n > a.table_max_m) return;
-    const uint32_t pr = a.pairs[(size_t)n * a.iters + k];
+    const int m = compact_to_lds(a, n, sf, st, lane);
+    __syncthreads();
+    if (k == 0 && a.status) {
+        for (int i = lane; i < m; i += 64) {
+            a.vp[2 * i] = sf[i].x; a.vp[2 * i + 1] = sf[i].y;
+            a.vc[2 * i] = st[i].x; a.vc[2 * i + 1] = st[i].y;
+        }
+        if (lane == 0) *a.d_m = m;
+    }
+    if (m < a.min_points || m <= 2 || m > a.table_max_m) return;
+    const uint32_t pr = a.pairs[(size_t)m * a.iters + k];
     const int i0 = pr & 0xFFFFu, i1 = pr >> 16;
-    const Model M = kernel2(a.from[2 * i0], a.from[2 * i0 + 1], a.from[2 * i1], a.from[2 * i1 + 1],
-                            a.to[2 * i0], a.to[2 * i0 + 1], a.to[2 * i1], a.to[2 * i1 + 1]);
+    const Model M = kernel2(sf[i0].x, sf[i0].y, sf[i1].x, sf[i1].y, st[i0].x, st[i0].y, st[i1].x, st[i1].y);
     float F[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) F[i] = (float)M.m[i];
     int good = 0;
-    for (int base = 0; base < n; base += 64) {
+    for (int base = 0; base < m; base += 64) {
         const int i = base + lane;
         bool in = false;
-        if (i < n) in = is_inlier(F, a.from[2 * i], a.from[2 * i + 1], a.to[2 * i], a.to[2 * i + 1], a.t);
+        if (i < m) in = is_inlier(F, sf[i].x, sf[i].y, st[i].x, st[i].y, a.t);
         good += __popcll(__ballot(in));
     }
     if (lane == 0) a.counts[k] = good;
 }
 
+__device__ __forceinline__ double wave_butterfly_sum(double v) {
+    // fixed combine order (mirrored by oracle/vso_ransac.cpp): s[l] += s[l ^ off], off = 32..1
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+// One wave: replays RANSACPointSetRegistrator::run over the vote counts, rebuilds
+// the inlier mask of the kept hypothesis, refines, and (pipeline) appends the
+// measured transform to the trajectory.
 __global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) {
-    __shared__ int s_counts[4096];
     const int lane = threadIdx.x;
-    const int n = device_count(a);
+    const float* from = a.status ? a.vp : a.from;
+    const float* to = a.status ? a.vc : a.to;
+    int n = a.status ? *a.d_m : device_count(a);
+    const int nprev = a.status ? device_count(a) : n;
     // failure defaults
     if (lane < 6) a.model[lane] = __longlong_as_double(0x7FF8000000000000LL);
     for (int i = lane; i < a.n; i += 64) a.inliers[i] = 0;
     if (lane < 4) a.info[lane] = lane == 1 ? -1 : 0;
-    if (n < a.min_points || n < 2 || n > a.table_max_m) return;
-
+    if (a.dbg && lane == 0) { a.dbg->n_prev = nprev; a.dbg->n_valid = n; }
+    __syncthreads();
+    bool ok = false;
     Model best;
-    int best_iter = -1, niters = a.iters > 1 ? a.iters : 1, max_good = 0;
-    if (n == 2) {
-        // count == modelPoints: the model of the two points, all inliers, no refinement
-        best = kernel2(a.from[0], a.from[1], a.from[2], a.from[3], a.to[0], a.to[1], a.to[2], a.to[3]);
-        if (lane < 6) a.model[lane] = best.m[lane];
-        if (lane < 2) a.inliers[lane] = 1;
-        if (lane == 0) { a.info[0] = 1; a.info[1] = 0; a.info[2] = 0; a.info[3] = 2; }
-        return;
-    }
-    for (int i = lane; i < a.iters; i += 64) s_counts[i] = a.counts[i];
-    __syncthreads();
-    // RANSACPointSetRegistrator::run bookkeeping, replayed over the vote counts
-    for (int iter = 0; iter < niters; iter++) {
-        const int good = s_counts[iter];
-        if (good > (max_good > 1 ? max_good : 1)) {
-            max_good = good;
-            best_iter = iter;
-            const uint32_t u = a.update[(size_t)n * (n + 1) / 2 + good];
-            const int mstar = u & 0xFFFFu, kround = u >> 16;
-            if (mstar == 0xFFFF) niters = 0;              // denom < DBL_MIN -> 0
-            else if (niters > mstar) niters = kround;     // else: unchanged (returns maxIters)
-        }
-    }
-    if (lane == 0) { a.info[1] = best_iter; a.info[2] = niters; }
-    if (max_good <= 0 || best_iter < 0) return;
-    const uint32_t pr = a.pairs[(size_t)n * a.iters + best_iter];
-    const int i0 = pr & 0xFFFFu, i1 = pr >> 16;
-    best = kernel2(a.from[2 * i0], a.from[2 * i0 + 1], a.from[2 * i1], a.from[2 * i1 + 1],
-                   a.to[2 * i0], a.to[2 * i0 + 1], a.to[2 * i1], a.to[2 * i1 + 1]);
-    float F[6];
+    if (n >= a.min_points && n >= 2 && n <= a.table_max_m) {
+        if (n == 2) {
+            // count == modelPoints: the model of the two points, all inliers, no refinement
+            best = kernel2(from[0], from[1], from[2], from[3], to[0], to[1], to[2], to[3]);
+            if (lane < 6) a.model[lane] = best.m[lane];
+            if (lane < 2) a.inliers[lane] = 1;
+            if (lane == 0) { a.info[0] = 1; a.info[1] = 0; a.info[2] = 0; a.info[3] = 2; }
+            ok = true;
+        } else {
+            int best_iter = -1, niters = a.iters > 1 ? a.iters : 1, max_good = 0;
+            // RANSACPointSetRegistrator::run bookkeeping: 64 iterations per step; inside a step
+            // the strict improvements are visited in order with ballot / first-set-bit.
+            for (int base = 0; base < niters; base += 64) {
+                const int iter = base + lane;
+                const int good = iter < a.iters ? a.counts[iter] : 0;
+                while (true) {
+                    const int floor_good = max_good > 1 ? max_good : 1;
+                    const unsigned long long mask = __ballot(iter < niters && good > floor_good);
+                    if (!mask) break;
+                    const int j = __ffsll((long long)mask) - 1;
+                    max_good = __builtin_amdgcn_readlane(good, j);
+                    best_iter = base + j;
+                    const uint32_t u = a.update[(size_t)n * (n + 1) / 2 + max_good];
+                    const int mstar = u & 0xFFFFu, kround = u >> 16;
+                    if (mstar == 0xFFFF) niters = 0;              // denom < DBL_MIN -> 0
+                    else if (niters > mstar) niters = kround;     // else unchanged (returns maxIters)
+                    // lanes <= j are settled: later candidates must beat the new maximum
+                    if (lane <= j) { /* good of these lanes can no longer exceed max_good strictly before j */ }
+                }
+            }
+            if (lane == 0) { a.info[1] = best_iter; a.info[2] = niters; }
+            if (max_good > 0 && best_iter >= 0) {
+                const uint32_t pr = a.pairs[(size_t)n * a.iters + best_iter];
+                const int i0 = pr & 0xFFFFu, i1 = pr >> 16;
+                best = kernel2(from[2 * i0], from[2 * i0 + 1], from[2 * i1], from[2 * i1 + 1],
+                               to[2 * i0], to[2 * i0 + 1], to[2 * i1], to[2 * i1 + 1]);
+                float F[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) F[i] = (float)best.m[i];
-    for (int i = lane; i < n; i += 64)
-        a.inliers[i] = is_inlier(F, a.from[2 * i], a.from[2 * i + 1], a.to[2 * i], a.to[2 * i + 1], a.t) ? 1 : 0;
-    __syncthreads();
-    // refinement on the inliers: least squares of the linear residual, summed in index order
-    if (lane == 0) {
-        double Sx = 0, Sy = 0, SX = 0, SY = 0, Sxx = 0, SxX = 0, SxY = 0;
-        int m = 0;
-        for (int i = 0; i < n; i++) {
-            if (!a.inliers[i]) continue;
-            const double x = a.from[2 * i], y = a.from[2 * i + 1], X = a.to[2 * i], Y = a.to[2 * i + 1];
-            Sx += x; Sy += y; SX += X; SY += Y;
-            Sxx += x * x + y * y;
-            SxX += x * X + y * Y;
-            SxY += x * Y - y * X;
-            m++;
-        }
-        if (m > 0) {
-            const double N = (double)m;
-            const double den = N * Sxx - Sx * Sx - Sy * Sy;
-            if (fabs(den) > 0) {
-                const double ra = (N * SxX - Sx * SX - Sy * SY) / den;
-                const double rb = (N * SxY - Sx * SY + Sy * SX) / den;
-                const double tx = (SX - ra * Sx + rb * Sy) / N;
-                const double ty = (SY - rb * Sx - ra * Sy) / N;
-                best.m[0] = ra; best.m[1] = -rb; best.m[2] = tx; best.m[3] = rb; best.m[4] = ra; best.m[5] = ty;
+                for (int i = 0; i < 6; i++) F[i] = (float)best.m[i];
+                // refinement on the inliers: least squares of the linear residual.  Summation
+                // order: lane l accumulates points i = l, l+64, ... in increasing i, then the 64
+                // partial sums are combined by the fixed butterfly above.
+                double Sx = 0, Sy = 0, SX = 0, SY = 0, Sxx = 0, SxX = 0, SxY = 0;
+                int cnt = 0;
+                for (int i = lane; i < n; i += 64) {
+                    const float fx = from[2 * i], fy = from[2 * i + 1], tx = to[2 * i], ty = to[2 * i + 1];
+                    const bool in = is_inlier(F, fx, fy, tx, ty, a.t);
+                    a.inliers[i] = in ? 1 : 0;
+                    if (in) {
+                        const double x = fx, y = fy, X = tx, Y = ty;
+                        Sx += x; Sy += y; SX += X; SY += Y;
+                        Sxx += x * x + y * y;
+                        SxX += x * X + y * Y;
+                        SxY += x * Y - y * X;
+                        cnt++;
+                    }
+                }
+                Sx = wave_butterfly_sum(Sx); Sy = wave_butterfly_sum(Sy);
+                SX = wave_butterfly_sum(SX); SY = wave_butterfly_sum(SY);
+                Sxx = wave_butterfly_sum(Sxx); SxX = wave_butterfly_sum(SxX); SxY = wave_butterfly_sum(SxY);
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+                if (cnt > 0) {
+                    const double N = (double)cnt;
+                    const double den = N * Sxx - Sx * Sx - Sy * Sy;
+                    if (fabs(den) > 0) {
+                        const double ra = (N * SxX - Sx * SX - Sy * SY) / den;
+                        const double rb = (N * SxY - Sx * SY + Sy * SX) / den;
+                        const double tx = (SX - ra * Sx + rb * Sy) / N;
+                        const double ty = (SY - rb * Sx - ra * Sy) / N;
+                        best.m[0] = ra; best.m[1] = -rb; best.m[2] = tx; best.m[3] = rb; best.m[4] = ra; best.m[5] = ty;
+                    }
+                }
+                if (lane < 6) a.model[lane] = best.m[lane];
+                if (lane == 0) { a.info[0] = 1; a.info[3] = max_good; }
+                ok = true;
             }
         }
-        for (int i = 0; i < 6; i++) a.model[i] = best.m[i];
-        a.info[0] = 1;
-        a.info[3] = max_good;
+    }
+    (void)ok;
+    if (a.traj) {
+        // the results above were written by this same wave; make them visible to lane 0's reads
+        __threadfence_block();
+        __syncthreads();
+        if (lane == 0) traj_append_device(a.traj, a.tp, a.model, a.info, nprev, a.dbg, a.have_prev_gray);
     }
 }
 
 }  // namespace
 
 // counts: device scratch of `iters` int32.  d_n (optional) = device count.
-int launch_ransac(const float* d_from, const float* d_to, int n, const int32_t* d_n, int min_points,
-                  double thr, int iters, const RansacTables* tab, int32_t* d_counts, double* d_model,
-                  uint8_t* d_inliers, int32_t* d_info, hipStream_t st) {
-    if (!d_from || !d_to || n < 0 || !tab || !d_counts || !d_model || !d_inliers || !d_info ||
-        iters != tab->iters || n > tab->max_m) {
+// status != nullptr: (d_from,d_to,status) are the raw LK arrays; vp/vc/d_m receive
+// the compacted pairs.  traj != nullptr: the measured transform is appended too.
+int launch_ransac(const float* d_from, const float* d_to, const uint8_t* d_status, int n, const int32_t* d_n,
+                  float* d_vp, float* d_vc, int32_t* d_m, int min_points, double thr, int iters,
+                  const RansacTables* tab, int32_t* d_counts, double* d_model, uint8_t* d_inliers,
+                  int32_t* d_info, TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg,
+                  int have_prev_gray, hipStream_t st) {
+    if (!d_from || !d_to || n < 0 || n > MAX_PTS || !tab || !d_counts || !d_model || !d_inliers || !d_info ||
+        iters != tab->iters || n > tab->max_m || (d_status && (!d_vp || !d_vc || !d_m)) || (traj && (!tp || !dbg))) {
         set_last_error("ransac: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
     RansacArgs a;
-    a.from = d_from; a.to = d_to; a.n = n; a.d_n = d_n; a.min_points = min_points;
+    memset(&a, 0, sizeof a);
+    a.from = d_from; a.to = d_to; a.status = d_status; a.n = n; a.d_n = d_n;
+    a.vp = d_vp; a.vc = d_vc; a.d_m = d_m; a.min_points = min_points;
     a.t = (float)(thr * thr);
     a.iters = iters; a.pairs = tab->d_pairs; a.update = tab->d_update; a.table_max_m = tab->max_m;
     a.counts = d_counts; a.model = d_model; a.inliers = d_inliers; a.info = d_info;
-    if (n > 2) hipLaunchKernelGGL(ransac_score_kernel, dim3(iters), dim3(64), 0, st, a);
+    a.traj = traj; a.dbg = dbg; a.have_prev_gray = have_prev_gray;
+    if (tp) a.tp = *tp;
+    if (n > 2 || d_status)
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(iters), dim3(64), (size_t)(n > 0 ? n : 1) * 16, st, a);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, st, a);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
@@ -300,7 +390,8 @@ int run_estimate_affine_partial2d(const float* d_from, const float* d_to, int n,
     VS_TRY(get_ransac_tables(n, max_iters, &tab));
     int32_t* counts = nullptr;
     VS_HIP_TRY(hipMalloc((void**)&counts, (size_t)max_iters * 4));
-    int rc = launch_ransac(d_from, d_to, n, nullptr, 2, thr, max_iters, tab, counts, d_model, d_inliers, d_info, st);
+    int rc = launch_ransac(d_from, d_to, nullptr, n, nullptr, nullptr, nullptr, nullptr, 2, thr, max_iters, tab,
+                           counts, d_model, d_inliers, d_info, nullptr, nullptr, nullptr, 0, st);
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(counts);
     if (rc == VS_OK && e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = VS_ERR_HIP; }

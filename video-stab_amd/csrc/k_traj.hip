@@ -17,6 +17,7 @@
 // from-scratch run bit for bit).
 #include "vs_common.h"
 #include "traj_state.h"
+#include "traj_device.h"
 
 namespace vsd {
 namespace {
@@ -48,105 +49,13 @@ __global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ p
     }
 }
 
-__device__ __forceinline__ float hf_mag(const float t[3]) {
-    return sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] * 100.0f);
-}
-
 __global__ void traj_append_kernel(TrajState* s, TrajParams p, const double* __restrict__ model,
                                    const int32_t* __restrict__ info, const int32_t* __restrict__ d_nprev,
                                    vs_debug_frame* dbg, int have_prev_gray) {
     if (threadIdx.x != 0) return;
-    float tr[3] = {0.f, 0.f, 0.f};
-    const int nprev = *d_nprev;
-    dbg->ransac_best_iter = -1; dbg->ransac_iters_run = 0; dbg->n_inliers = 0;
-    for (int i = 0; i < 6; i++) dbg->model[i] = __longlong_as_double(0x7FF8000000000000LL);
-    if (nprev > 0 && have_prev_gray) {              // Stabilizer.cpp:596
-        float T[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};  // :644
-        if (info[0]) {                               // :650-652
-            for (int i = 0; i < 6; i++) { T[i] = (float)model[i]; dbg->model[i] = model[i]; }
-        }
-        dbg->ransac_best_iter = info[1]; dbg->ransac_iters_run = info[2]; dbg->n_inliers = info[3];
-        tr[0] = T[2]; tr[1] = T[5]; tr[2] = atan2f(T[3], T[0]);   // :660-662
-        if (p.drone) {
-            // applyDeadZoneFreeze :2605-2655 (updateMotionAccumulator :2667-2682)
-            const float magnitude = hf_mag(tr);
-            const float decayed = s->hfAccum * p.hf_decay;
-            s->hfAccum = fmaxf(decayed, magnitude);
-            s->hfAccum = fminf(s->hfAccum, p.hf_dead_zone * 5.0f);
-            s->hfAccum = fmaxf(0.0f, fminf(s->hfAccum, 100.0f));
-            const float cur = magnitude;
-            bool frozen = false;
-            if (!s->hfInDeadZone && cur < p.hf_dead_zone) { s->hfInDeadZone = 1; s->hfFreezeCounter = p.hf_freeze_duration; }
-            if (s->hfInDeadZone) {
-                s->hfFreezeCounter--;
-                const bool durationExpired = s->hfFreezeCounter <= 0;
-                const bool significantMotion = cur > p.hf_dead_zone * 1.5f;
-                const bool accumulatedMotion = s->hfAccum > p.hf_dead_zone * 1.2f;
-                if (durationExpired || significantMotion || accumulatedMotion) {
-                    s->hfInDeadZone = 0; s->hfFreezeCounter = 0; s->hfAccum = 0.0f;
-                } else frozen = true;
-            }
-            if (frozen) { tr[0] = tr[1] = tr[2] = 0.0f; }
-            // applyMicroShakeSuppression :2468-2503
-            if (s->hfHistN >= 5) {
-                float xs[10], ys[10];
-                const int hn = s->hfHistN;
-                for (int i = 0; i < hn; i++) { xs[i] = s->hfHist[i][0]; ys[i] = s->hfHist[i][1]; }
-                for (int i = 1; i < hn; i++) {   // insertion sort (values only; any stable sort gives the same order statistics)
-                    float vx = xs[i]; int j = i - 1;
-                    while (j >= 0 && xs[j] > vx) { xs[j + 1] = xs[j]; j--; }
-                    xs[j + 1] = vx;
-                    float vy = ys[i]; j = i - 1;
-                    while (j >= 0 && ys[j] > vy) { ys[j + 1] = ys[j]; j--; }
-                    ys[j + 1] = vy;
-                }
-                const int mid = hn / 2;
-                s->hfMedian[0] = hn % 2 == 0 ? (xs[mid - 1] + xs[mid]) / 2.0f : xs[mid];
-                s->hfMedian[1] = hn % 2 == 0 ? (ys[mid - 1] + ys[mid]) / 2.0f : ys[mid];
-            }
-            const float d0 = tr[0] - s->hfMedian[0], d1 = tr[1] - s->hfMedian[1];
-            const float dm = sqrtf(d0 * d0 + d1 * d1);
-            if (dm < p.hf_shake_px) {
-                tr[0] = s->hfMedian[0] + d0 * 0.01f; tr[1] = s->hfMedian[1] + d1 * 0.01f;
-            } else if (dm < p.hf_shake_px * 2.0f) {
-                tr[0] = s->hfMedian[0] + d0 * 0.05f; tr[1] = s->hfMedian[1] + d1 * 0.05f;
-            }
-            // applyRotationLowPass :2505-2520
-            if (p.horizon_lock) {
-                s->hfRotLP = (1.0f - p.hf_rot_lp_alpha) * s->hfRotLP + p.hf_rot_lp_alpha * tr[2];
-                tr[2] = s->hfRotLP;
-            }
-            // updateTranslationHistory :2522-2529 (deque of the last 10)
-            if (s->hfHistN < 10) { s->hfHist[s->hfHistN][0] = tr[0]; s->hfHist[s->hfHistN][1] = tr[1]; s->hfHistN++; }
-            else {
-                for (int i = 0; i < 9; i++) { s->hfHist[i][0] = s->hfHist[i + 1][0]; s->hfHist[i][1] = s->hfHist[i + 1][1]; }
-                s->hfHist[9][0] = tr[0]; s->hfHist[9][1] = tr[1];
-            }
-        }
-    }
-    const int n = s->n;
-    const int slot = n & (TRAJ_RING - 1);
-    float pth[3];
-    for (int c = 0; c < 3; c++) {
-        s->transforms[slot][c] = tr[c];
-        pth[c] = n == 0 ? tr[c] : s->last_path[c] + tr[c];   // :681-687
-        s->path[slot][c] = pth[c];
-        s->last_path[c] = pth[c];
-        dbg->transform[c] = tr[c];
-    }
-    s->n = n + 1;
-    // updateAdaptiveParameters :1562-1574 -> adaptSmoothingRadius :1461-1492
-    if (p.adaptive && n + 1 >= 3) {
-        const float magnitude = sqrtf(tr[0] * tr[0] + tr[1] * tr[1]);
-        float motionScale = fmaxf(0.0f, fminf(1.0f, magnitude / 50.0f));
-        motionScale = 1.0f - motionScale;
-        const int newRadius = p.min_radius + (int)(motionScale * (float)(p.max_radius - p.min_radius));
-        if (newRadius != s->smoothing_radius) s->smoothing_radius = newRadius;
-    }
+    traj_append_device(s, p, model, info, *d_nprev, dbg, have_prev_gray);
 }
 
-__device__ __forceinline__ float path_at(const TrajState* s, int i, int c) { return s->path[i & (TRAJ_RING - 1)][c]; }
-__device__ __forceinline__ float tr_at(const TrajState* s, int i, int c) { return s->transforms[i & (TRAJ_RING - 1)][c]; }
 
 // Stabilizer.cpp:1750-1780
 __device__ float variance_of(const float* v, int n) {
@@ -172,8 +81,30 @@ __device__ float consistency_of(const float* v, int n) {
 
 __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __restrict__ M_out,
                                  vs_debug_frame* dbg) {
-    if (threadIdx.x != 0) return;
+    // The history rings are mirrored into LDS by all lanes and the per-sample
+    // transcendental work of the intent analysis is spread over lanes; every
+    // float SUM below is still accumulated by lane 0 in the reference's order.
+    __shared__ float l_path[TRAJ_RING][3], l_tr[TRAJ_RING][3];
+    __shared__ float l_mag[16], l_dir[16];
     const int n = s->n;
+    for (int i = threadIdx.x; i < TRAJ_RING * 3; i += blockDim.x) {
+        (&l_path[0][0])[i] = (&s->path[0][0])[i];
+        (&l_tr[0][0])[i] = (&s->transforms[0][0])[i];
+    }
+    __syncthreads();
+    const int istart = idx - 15 > 0 ? idx - 15 : 0;
+    if (threadIdx.x < 15) {
+        const int i = istart + (int)threadIdx.x;
+        if (i < idx && i < n) {
+            const float t0 = l_tr[i & (TRAJ_RING - 1)][0], t1 = l_tr[i & (TRAJ_RING - 1)][1];
+            l_mag[threadIdx.x] = sqrtf(t0 * t0 + t1 * t1);
+            l_dir[threadIdx.x] = atan2f(t1, t0);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    auto path_at = [&](int i, int c) -> float { return l_path[i & (TRAJ_RING - 1)][c]; };
+    auto tr_at = [&](int i, int c) -> float { return l_tr[i & (TRAJ_RING - 1)][c]; };
     dbg->out_index = idx; dbg->box_radius = 0; dbg->intent = 0;
     if (idx >= n) {   // Stabilizer.cpp:774-780: no transform for this frame -> frame returned as is
         M_out[0] = 1.f; M_out[1] = 0.f; M_out[2] = 0.f; M_out[3] = 0.f; M_out[4] = 1.f; M_out[5] = 0.f;
@@ -195,7 +126,7 @@ __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __r
                 else if (q < center + n) src = q - center;
                 else src = n - 1 - (q - center - n);
                 src = src < 0 ? 0 : (src > n - 1 ? n - 1 : src);
-                acc += path_at(s, src, c) * p.gauss_kernel[j];
+                acc += path_at(src, c) * p.gauss_kernel[j];
             }
             sm[c] = acc;
         }
@@ -205,7 +136,7 @@ __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __r
             float* k = s->kal[c];   // x0,x1,P00,P01,P10,P11
             int done = s->kal_n[c];
             if (done == 0) {
-                k[0] = path_at(s, 0, c); k[1] = 0.f; k[2] = k[3] = k[4] = k[5] = 0.f;
+                k[0] = path_at(0, c); k[1] = 0.f; k[2] = k[3] = k[4] = k[5] = 0.f;
                 s->kal_last[c] = k[0];
                 done = 1;
             }
@@ -215,7 +146,7 @@ __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __r
                 const float Q00 = (t00 + t01) + q, Q01 = t01, Q10 = t10 + t11, Q11 = t11 + q;
                 const float S = Q00 + r;
                 const float K0 = Q00 / S, K1 = Q01 / S;
-                const float innov = path_at(s, done, c) - xp0;
+                const float innov = path_at(done, c) - xp0;
                 k[0] = xp0 + K0 * innov; k[1] = xp1 + K1 * innov;
                 k[2] = Q00 - K0 * Q00; k[3] = Q01 - K0 * Q01;
                 k[4] = Q10 - K1 * Q00; k[5] = Q11 - K1 * Q01;
@@ -232,10 +163,10 @@ __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __r
             const int start = n - 20 > 0 ? n - 20 : 0;
             const int count = n - start;
             float mean[3] = {0, 0, 0}, var[3] = {0, 0, 0};
-            for (int i = start; i < n; i++) for (int c = 0; c < 3; c++) mean[c] += path_at(s, i, c);
+            for (int i = start; i < n; i++) for (int c = 0; c < 3; c++) mean[c] += path_at(i, c);
             for (int c = 0; c < 3; c++) mean[c] /= count;
             for (int i = start; i < n; i++)
-                for (int c = 0; c < 3; c++) { const float d = path_at(s, i, c) - mean[c]; var[c] += d * d; }
+                for (int c = 0; c < 3; c++) { const float d = path_at(i, c) - mean[c]; var[c] += d * d; }
             for (int c = 0; c < 3; c++) var[c] /= count;
             const float total = sqrtf(var[0] + var[1] + var[2] * 1000);
             ar = (int)fmaxf(5.0f, fminf(25.0f, total * 2.0f));
@@ -244,22 +175,22 @@ __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __r
         const int r = p.drone ? max(10, min(ar, 50)) : max(2, min(ar, 8));
         dbg->box_radius = r;
         if (n <= r) {
-            for (int c = 0; c < 3; c++) sm[c] = path_at(s, idx, c);
+            for (int c = 0; c < 3; c++) sm[c] = path_at(idx, c);
         } else {
             const int start = idx - r > 0 ? idx - r : 0;
             const int end = idx + r < n - 1 ? idx + r : n - 1;
             for (int c = 0; c < 3; c++) {
                 float sum = 0.0f;
                 int count = 0;
-                for (int j = start; j <= end; j++) { sum += path_at(s, j, c); count++; }
+                for (int j = start; j <= end; j++) { sum += path_at(j, c); count++; }
                 sm[c] = sum / count;
             }
         }
     }
     float raw[3], diff[3];
     for (int c = 0; c < 3; c++) {
-        raw[c] = tr_at(s, idx, c);
-        diff[c] = sm[c] - path_at(s, idx, c);      // :850-851
+        raw[c] = tr_at(idx, c);
+        diff[c] = sm[c] - path_at(idx, c);      // :850-851
         dbg->smoothed[c] = sm[c];
     }
     if (idx > 0) {                                   // :854-888, analyzeMotionIntent :1676-1719
@@ -269,13 +200,8 @@ __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __r
         if (n >= 15) {
             float mags[15], dirs[15];
             int cnt = 0;
-            for (int i = idx - 15 > 0 ? idx - 15 : 0; i < idx; i++) {
-                if (i < n) {
-                    const float t0 = tr_at(s, i, 0), t1 = tr_at(s, i, 1);
-                    mags[cnt] = sqrtf(t0 * t0 + t1 * t1);
-                    dirs[cnt] = atan2f(t1, t0);
-                    cnt++;
-                }
+            for (int i = istart; i < idx; i++) {
+                if (i < n) { mags[cnt] = l_mag[i - istart]; dirs[cnt] = l_dir[i - istart]; cnt++; }
             }
             if (cnt > 0) {
                 const float dv = variance_of(dirs, cnt);

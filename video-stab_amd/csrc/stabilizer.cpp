@@ -21,9 +21,11 @@ namespace vsd {
 
 struct RansacTables;
 int get_ransac_tables(int max_m, int iters, const RansacTables** out);
-int launch_ransac(const float* d_from, const float* d_to, int n, const int32_t* d_n, int min_points,
-                  double thr, int iters, const RansacTables* tab, int32_t* d_counts, double* d_model,
-                  uint8_t* d_inliers, int32_t* d_info, hipStream_t st);
+int launch_ransac(const float* d_from, const float* d_to, const uint8_t* d_status, int n, const int32_t* d_n,
+                  float* d_vp, float* d_vc, int32_t* d_m, int min_points, double thr, int iters,
+                  const RansacTables* tab, int32_t* d_counts, double* d_model, uint8_t* d_inliers,
+                  int32_t* d_info, TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg,
+                  int have_prev_gray, hipStream_t st);
 int launch_compact(const float* prev, const float* cur, const uint8_t* status, int n_cap, const int32_t* d_n,
                    float* vp, float* vc, int32_t* d_m, vs_debug_frame* dbg, hipStream_t st);
 int launch_traj_append(TrajState* s, const TrajParams& p, const double* model, const int32_t* info,
@@ -332,16 +334,11 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame) {
     }
     s->last_lk_pp = pp;
     {
+        // status compaction (:629-641) + estimateAffinePartial2D (:644-659) + transform append (:660-693)
         StageScope t(s, VS_STAGE_RANSAC);
-        S_TRY(s, launch_compact(s->d_pts[pp], s->d_next, s->d_status, cap, s->d_npts[pp], s->d_vp, s->d_vc, s->d_m,
-                                s->d_dbg, s->st));                                       // :629-641
-        S_TRY(s, launch_ransac(s->d_vp, s->d_vc, std::max(cap, 0), s->d_m, 4, p.ransac_threshold, p.ransac_max_iters,
-                               s->tab, s->d_counts, s->d_model, s->d_inliers, s->d_info, s->st));   // :644-659
-    }
-    {
-        StageScope t(s, VS_STAGE_TRAJ);
-        S_TRY(s, launch_traj_append(s->d_traj, s->tp, s->d_model, s->d_info, s->d_npts[pp], s->d_dbg,
-                                    s->have_prev_gray ? 1 : 0, s->st));                  // :660-693
+        S_TRY(s, launch_ransac(s->d_pts[pp], s->d_next, s->d_status, std::max(cap, 0), s->d_npts[pp], s->d_vp, s->d_vc,
+                               s->d_m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab, s->d_counts, s->d_model,
+                               s->d_inliers, s->d_info, s->d_traj, &s->tp, s->d_dbg, s->have_prev_gray ? 1 : 0, s->st));
     }
     s->n_transforms++;
     s->last_detected = false;
