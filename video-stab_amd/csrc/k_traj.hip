@@ -80,7 +80,7 @@ __device__ float consistency_of(const float* v, int n) {
 }
 
 __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __restrict__ M_out,
-                                 vs_debug_frame* dbg) {
+                                 double* __restrict__ Minv_out, vs_debug_frame* dbg) {
     // The history rings are mirrored into LDS by all lanes and the per-sample
     // transcendental work of the intent analysis is spread over lanes; every
     // float SUM below is still accumulated by lane 0 in the reference's order.
@@ -109,6 +109,8 @@ __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __r
     if (idx >= n) {   // Stabilizer.cpp:774-780: no transform for this frame -> frame returned as is
         M_out[0] = 1.f; M_out[1] = 0.f; M_out[2] = 0.f; M_out[3] = 0.f; M_out[4] = 1.f; M_out[5] = 0.f;
         for (int i = 0; i < 6; i++) M_out[6 + i] = M_out[i];
+        warp_invert(M_out, Minv_out);
+        warp_invert(M_out + 6, Minv_out + 6);
         for (int c = 0; c < 3; c++) dbg->smoothed[c] = 0.f;
         for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
         return;
@@ -225,6 +227,8 @@ __global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __r
     // chroma plane of an NV12 surface: same rotation, translation halved
     M_out[6] = cs; M_out[7] = -sn; M_out[8] = dx * 0.5f;
     M_out[9] = sn; M_out[10] = cs; M_out[11] = dy * 0.5f;
+    warp_invert(M_out, Minv_out);            // the warp kernels consume the inverse maps
+    warp_invert(M_out + 6, Minv_out + 6);
     for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
 }
 
@@ -286,8 +290,9 @@ int launch_traj_append(TrajState* s, const TrajParams& p, const double* model, c
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
-int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, vs_debug_frame* dbg, hipStream_t st) {
-    hipLaunchKernelGGL(traj_emit_kernel, dim3(1), dim3(64), 0, st, s, p, idx, M_out, dbg);
+int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(traj_emit_kernel, dim3(1), dim3(64), 0, st, s, p, idx, M_out, Minv_out, dbg);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

@@ -8,13 +8,18 @@
 //   ((v00*(32-fx)+v01*fx)*(32-fy) + (v10*(32-fx)+v11*fx)*fy + 512) >> 10
 // (the (0,0) table entry {32767,0,0,1} gives the same 8-bit result).
 //
-// HBM-bound kernel (12 B in / 12 B out per BGR pixel-pair... 2 x frame bytes
-// per frame).  One workgroup = one 128x16 output tile: the source bounding box
-// of the tile is staged once into LDS with coalesced 12-byte/lane loads
-// (one dword per pixel, zeros outside the image = BORDER_CONSTANT), every
-// output pixel then takes its 4 taps from LDS and each lane writes 4 pixels
-// with one 12-byte store.  Tiles whose bounding box does not fit the LDS
-// budget (large rotation / scale) take a direct global-load path.
+// HBM-bound stage: 2 x frame bytes of algorithmic traffic per frame.  One
+// workgroup = one 128x16 output tile:
+//   1. 144 lanes evaluate the double-precision column/row coordinate terms of
+//      the tile once (adelta/bdelta per column, X0/Y0 per row) into LDS;
+//   2. the source bounding box of the tile is staged into LDS with coalesced
+//      12-byte/lane loads, one dword per pixel, zeros outside the image
+//      (= BORDER_CONSTANT), so taps need no bounds logic;
+//   3. each lane produces 4 consecutive pixels of 2 rows: taps from LDS,
+//      horizontal lerps with v_dot4_u32_u8 on byte-permuted tap pairs, vertical
+//      lerp in 24-bit multiplies, one 12-byte store per 4 pixels.
+// Tiles whose bounding box does not fit the LDS budget (large rotation /
+// scale) take a direct global-load path with the same arithmetic.
 #include "vs_common.h"
 
 namespace vsd {
@@ -27,8 +32,10 @@ constexpr int PX = 4;        // consecutive output pixels per lane
 constexpr int NT = 256;      // threads per workgroup
 constexpr int TXN = TW / PX; // 32 lanes along x
 constexpr int TYN = NT / TXN;// 8 lane-rows
-constexpr int LDS_PX = 6144; // 24 KiB of staged pixels per workgroup
+constexpr int LDS_PX = 3072; // 12 KiB of staged pixels per workgroup
 constexpr int MAXB = 16;     // matrices passed by value per launch
+constexpr int SGW = 48;      // staging: 4-pixel groups handled per row pass (fast mapping)
+constexpr int SROWS = 5;     // staging: row passes held in registers (5 rows per pass)
 
 struct WarpArgs {
     const uint8_t* src;
@@ -36,40 +43,9 @@ struct WarpArgs {
     size_t sstride, sframe, dstride, dframe;
     int sw, sh, dw, dh;
     int src_aligned, dst_aligned;
-    const float* M_dev;          // batch*6 floats on the device, or nullptr
-    float M_val[MAXB * 6];       // used when M_dev == nullptr
+    const double* Minv_dev;      // batch*6 doubles on the device (inverse maps), or nullptr
+    double Minv_val[MAXB * 6];   // used when Minv_dev == nullptr
 };
-
-struct InvMap { double m[6]; };
-
-// cv::warpAffine: invert the forward matrix in double.
-__device__ __forceinline__ InvMap invert(const float* Mf) {
-    double M[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) M[i] = (double)Mf[i];
-    double D = M[0] * M[4] - M[1] * M[3];
-    D = D != 0 ? 1. / D : 0;
-    double A11 = M[4] * D, A22 = M[0] * D;
-    M[0] = A11; M[1] *= -D;
-    M[3] *= -D; M[4] = A22;
-    double b1 = -M[0] * M[2] - M[1] * M[5];
-    double b2 = -M[3] * M[2] - M[4] * M[5];
-    M[2] = b1; M[5] = b2;
-    InvMap r;
-#pragma unroll
-    for (int i = 0; i < 6; i++) r.m[i] = M[i];
-    return r;
-}
-
-// hal::warpAffine / WarpAffineInvoker coordinate generation (1/32 px units).
-__device__ __forceinline__ void row_base(const InvMap& iv, int y, int& X0, int& Y0) {
-    X0 = d_round((iv.m[1] * y + iv.m[2]) * 1024) + 16;
-    Y0 = d_round((iv.m[4] * y + iv.m[5]) * 1024) + 16;
-}
-__device__ __forceinline__ void col_delta(const InvMap& iv, int x, int& ad, int& bd) {
-    ad = d_round(iv.m[0] * x * 1024);
-    bd = d_round(iv.m[3] * x * 1024);
-}
 
 template <int CN>
 __device__ __forceinline__ uint32_t load_px_checked(const uint8_t* src, size_t sstride, int sw,
@@ -82,19 +58,34 @@ __device__ __forceinline__ uint32_t load_px_checked(const uint8_t* src, size_t s
     return v;
 }
 
+// p00/p01 = taps of the upper row, p10/p11 of the lower row (one pixel per dword,
+// channel c in byte c).  Horizontal lerps as byte dot products, vertical in 24 bits.
 template <int CN>
 __device__ __forceinline__ uint32_t blend(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11,
-                                          int fx, int fy) {
-    const uint32_t wx1 = fx, wx0 = 32 - fx, wy1 = fy, wy0 = 32 - fy;
-    uint32_t out = 0;
-#pragma unroll
-    for (int c = 0; c < CN; c++) {
-        uint32_t v00 = (p00 >> (8 * c)) & 255u, v01 = (p01 >> (8 * c)) & 255u;
-        uint32_t v10 = (p10 >> (8 * c)) & 255u, v11 = (p11 >> (8 * c)) & 255u;
-        uint32_t t = v00 * wx0 + v01 * wx1;
-        uint32_t b = v10 * wx0 + v11 * wx1;
-        uint32_t r = (t * wy0 + b * wy1 + 512u) >> 10;
-        out |= r << (8 * c);
+                                          uint32_t fx, uint32_t fy) {
+    const uint32_t wlo = (32u - fx) | (fx << 8);     // weights against bytes 0,1
+    const uint32_t whi = wlo << 16;                    // weights against bytes 2,3
+    const uint32_t wy0 = 32u - fy, wy1 = fy;
+    // (c0_a, c0_b, c1_a, c1_b): channels 0 and 1 of the two taps side by side
+    const uint32_t x0 = __builtin_amdgcn_perm(p01, p00, 0x05010400u);
+    const uint32_t x1 = __builtin_amdgcn_perm(p11, p10, 0x05010400u);
+    uint32_t out;
+    {
+        const uint32_t t = __builtin_amdgcn_udot4(x0, wlo, 0u, false);
+        const uint32_t b = __builtin_amdgcn_udot4(x1, wlo, 0u, false);
+        out = (__umul24(t, wy0) + __umul24(b, wy1) + 512u) >> 10;
+    }
+    if (CN > 1) {
+        const uint32_t t = __builtin_amdgcn_udot4(x0, whi, 0u, false);
+        const uint32_t b = __builtin_amdgcn_udot4(x1, whi, 0u, false);
+        out |= ((__umul24(t, wy0) + __umul24(b, wy1) + 512u) >> 10) << 8;
+    }
+    if (CN > 2) {
+        const uint32_t y0 = __builtin_amdgcn_perm(p01, p00, 0x0C0C0602u);   // (c2_a, c2_b, 0, 0)
+        const uint32_t y1 = __builtin_amdgcn_perm(p11, p10, 0x0C0C0602u);
+        const uint32_t t = __builtin_amdgcn_udot4(y0, wlo, 0u, false);
+        const uint32_t b = __builtin_amdgcn_udot4(y1, wlo, 0u, false);
+        out |= ((__umul24(t, wy0) + __umul24(b, wy1) + 512u) >> 10) << 16;
     }
     return out;
 }
@@ -102,31 +93,143 @@ __device__ __forceinline__ uint32_t blend(uint32_t p00, uint32_t p01, uint32_t p
 struct __attribute__((aligned(4))) U3 { uint32_t a, b, c; };
 
 template <int CN>
+__device__ __forceinline__ uint4 stage_group(const WarpArgs& a, const uint8_t* __restrict__ src, int sx, int sy) {
+    uint4 px = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned)sy < (unsigned)a.sh) {
+        if (a.src_aligned && sx >= 0 && sx + 3 < a.sw) {
+            const uint8_t* p = src + (size_t)sy * a.sstride + (size_t)sx * CN;
+            if (CN == 3) {
+                const U3 d = *reinterpret_cast<const U3*>(p);
+                px.x = d.a & 0xFFFFFFu;
+                px.y = (d.a >> 24) | ((d.b & 0xFFFFu) << 8);
+                px.z = (d.b >> 16) | ((d.c & 0xFFu) << 16);
+                px.w = d.c >> 8;
+            } else if (CN == 1) {
+                const uint32_t d = *reinterpret_cast<const uint32_t*>(p);
+                px.x = d & 255u; px.y = (d >> 8) & 255u; px.z = (d >> 16) & 255u; px.w = d >> 24;
+            } else {
+                const uint2 d = *reinterpret_cast<const uint2*>(p);
+                px.x = d.x & 0xFFFFu; px.y = d.x >> 16; px.z = d.y & 0xFFFFu; px.w = d.y >> 16;
+            }
+        } else {
+            px.x = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy);
+            px.y = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy);
+            px.z = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 2, sy);
+            px.w = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 3, sy);
+        }
+    }
+    return px;
+}
+
+template <int CN, bool USE_LDS>
+__device__ __forceinline__ void emit_rows(const WarpArgs& a, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                          const uint32_t* tile, const int* s_ad, const int* s_bd, const int* s_x0,
+                                          const int* s_y0, int x0, int y0, int x1, int y1, int bx0a, int by0, int bw) {
+    const int tid = threadIdx.x;
+    const int tx = tid % TXN, ty = tid / TXN;
+    const int x = x0 + PX * tx;
+    if (x > x1) return;
+    int ad[PX], bd[PX];
+#pragma unroll
+    for (int i = 0; i < PX; i++) { ad[i] = s_ad[PX * tx + i]; bd[i] = s_bd[PX * tx + i]; }
+    uint32_t o[TH / TYN][PX];
+#pragma unroll
+    for (int r = 0; r < TH / TYN; r++) {
+        const int yl = ty + TYN * r;
+        const int X0 = s_x0[yl], Y0 = s_y0[yl];
+        uint32_t p00[PX], p01[PX], p10[PX], p11[PX], fx[PX], fy[PX];
+#pragma unroll
+        for (int i = 0; i < PX; i++) {
+            const int X = (X0 + ad[i]) >> 5, Y = (Y0 + bd[i]) >> 5;
+            const int sx = sat_s16(X >> 5), sy = sat_s16(Y >> 5);
+            fx[i] = X & 31; fy[i] = Y & 31;
+            if (USE_LDS) {
+                // rows beyond the tile (yl past y1) still index inside the staged box of a
+                // full tile only; clamp them to the first row so the reads stay in bounds
+                const int idx = y0 + yl <= y1 ? __mul24(sy - by0, bw) + (sx - bx0a) : 0;
+                p00[i] = tile[idx]; p01[i] = tile[idx + 1];
+                p10[i] = tile[idx + bw]; p11[i] = tile[idx + bw + 1];
+            } else {
+                p00[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy);
+                p01[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy);
+                p10[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy + 1);
+                p11[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy + 1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PX; i++) o[r][i] = blend<CN>(p00[i], p01[i], p10[i], p11[i], fx[i], fy[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < TH / TYN; r++) {
+        const int y = y0 + ty + TYN * r;
+        if (y > y1) break;
+        uint8_t* d = dst + (size_t)y * a.dstride + (size_t)x * CN;
+        if (a.dst_aligned && x + PX - 1 <= x1) {
+            if (CN == 3) {
+                U3 v;
+                v.a = o[r][0] | (o[r][1] << 24);
+                v.b = (o[r][1] >> 8) | (o[r][2] << 16);
+                v.c = (o[r][2] >> 16) | (o[r][3] << 8);
+                *reinterpret_cast<U3*>(d) = v;
+            } else if (CN == 1) {
+                *reinterpret_cast<uint32_t*>(d) = o[r][0] | (o[r][1] << 8) | (o[r][2] << 16) | (o[r][3] << 24);
+            } else {
+                *reinterpret_cast<uint2*>(d) = make_uint2(o[r][0] | (o[r][1] << 16), o[r][2] | (o[r][3] << 16));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PX; i++) {
+                if (x + i > x1) break;
+#pragma unroll
+                for (int c = 0; c < CN; c++) d[i * CN + c] = (uint8_t)(o[r][i] >> (8 * c));
+            }
+        }
+    }
+}
+
+// hal::warpAffine / WarpAffineInvoker coordinate terms (1/1024 px; +16 = round_delta)
+__device__ __forceinline__ void col_terms(const double* m, int x, int& ad, int& bd) {
+    ad = d_round(m[0] * x * 1024);
+    bd = d_round(m[3] * x * 1024);
+}
+__device__ __forceinline__ void row_terms(const double* m, int y, int& X0, int& Y0) {
+    X0 = d_round((m[1] * y + m[2]) * 1024) + 16;
+    Y0 = d_round((m[4] * y + m[5]) * 1024) + 16;
+}
+
+template <int CN>
 __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_PX];
+    __shared__ int s_ad[TW], s_bd[TW], s_x0[TH], s_y0[TH];
     const int bz = blockIdx.z;
     const uint8_t* __restrict__ src = a.src + (size_t)bz * a.sframe;
     uint8_t* __restrict__ dst = a.dst + (size_t)bz * a.dframe;
-    const float* Mf = a.M_dev ? a.M_dev + 6 * bz : a.M_val + 6 * bz;
-    const InvMap iv = invert(Mf);
-
-    const int tid = threadIdx.x;
+    double m[6];   // inverse map of this frame (wave-uniform)
+    {
+        const double* mp = a.Minv_dev ? a.Minv_dev + 6 * bz : a.Minv_val + 6 * bz;
+#pragma unroll
+        for (int i = 0; i < 6; i++) m[i] = mp[i];
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int x1 = min(x0 + TW, a.dw) - 1, y1 = min(y0 + TH, a.dh) - 1;
 
-    // Source bounding box of the tile: the coordinate maps are monotone in x
-    // and in y separately, so the extremes are at the tile corners.
+    // ---- 1. source bounding box.  The maps are monotone in x and in y separately, so the
+    // extremes are at the tile corners: lane 0 evaluates (x0,y0), lane 1 (x1,y1), and the
+    // eight terms are broadcast with v_readlane (no LDS, no barrier before the loads).
     int bx0, bx1, by0, by1;
     {
-        int Xa, Ya, Xb, Yb, ad0, bd0, ad1, bd1;
-        row_base(iv, y0, Xa, Ya);
-        row_base(iv, y1, Xb, Yb);
-        col_delta(iv, x0, ad0, bd0);
-        col_delta(iv, x1, ad1, bd1);
-        int sx00 = sat_s16((Xa + ad0) >> 10), sx01 = sat_s16((Xa + ad1) >> 10);
-        int sx10 = sat_s16((Xb + ad0) >> 10), sx11 = sat_s16((Xb + ad1) >> 10);
-        int sy00 = sat_s16((Ya + bd0) >> 10), sy01 = sat_s16((Ya + bd1) >> 10);
-        int sy10 = sat_s16((Yb + bd0) >> 10), sy11 = sat_s16((Yb + bd1) >> 10);
+        int ad, bd, X0, Y0;
+        col_terms(m, (lane & 1) ? x1 : x0, ad, bd);
+        row_terms(m, (lane & 1) ? y1 : y0, X0, Y0);
+        const int ad0 = __builtin_amdgcn_readlane(ad, 0), ad1 = __builtin_amdgcn_readlane(ad, 1);
+        const int bd0 = __builtin_amdgcn_readlane(bd, 0), bd1 = __builtin_amdgcn_readlane(bd, 1);
+        const int Xa = __builtin_amdgcn_readlane(X0, 0), Xb = __builtin_amdgcn_readlane(X0, 1);
+        const int Ya = __builtin_amdgcn_readlane(Y0, 0), Yb = __builtin_amdgcn_readlane(Y0, 1);
+        const int sx00 = sat_s16((Xa + ad0) >> 10), sx01 = sat_s16((Xa + ad1) >> 10);
+        const int sx10 = sat_s16((Xb + ad0) >> 10), sx11 = sat_s16((Xb + ad1) >> 10);
+        const int sy00 = sat_s16((Ya + bd0) >> 10), sy01 = sat_s16((Ya + bd1) >> 10);
+        const int sy10 = sat_s16((Yb + bd0) >> 10), sy11 = sat_s16((Yb + bd1) >> 10);
         bx0 = min(min(sx00, sx01), min(sx10, sx11));
         bx1 = max(max(sx00, sx01), max(sx10, sx11)) + 1;
         by0 = min(min(sy00, sy01), min(sy10, sy11));
@@ -136,121 +239,94 @@ __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
     const int bw = (bx1 - bx0a + 1 + 3) & ~3;        // staged width, multiple of 4
     const int bh = by1 - by0 + 1;
     const bool use_lds = (long long)bw * bh <= LDS_PX;
+    const int gpr = bw >> 2;                         // 4-pixel groups per staged row
+    const bool fast_stage = use_lds && gpr <= SGW && bh <= 5 * SROWS;
 
-    if (use_lds) {
-        const int gpr = bw >> 2;                     // 4-pixel groups per staged row
+    // ---- 2. staging loads are issued first (5 rows x 48 groups per pass, no runtime division) ...
+    const int ly = tid / SGW, lx = tid - ly * SGW;
+    const bool stager = tid < 5 * SGW && lx < gpr;
+    uint4 staged[SROWS];
+    if (fast_stage && stager) {
+#pragma unroll
+        for (int k = 0; k < SROWS; k++) {
+            const int row = ly + 5 * k;
+            staged[k] = row < bh ? stage_group<CN>(a, src, bx0a + 4 * lx, by0 + row) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    // ---- ... the per-column / per-row coordinate terms of the tile are computed while those
+    // loads are in flight (adelta/bdelta per column, X0/Y0 per row, once per tile) ...
+    if (tid < TW) {
+        int ad, bd;
+        col_terms(m, x0 + tid, ad, bd);
+        s_ad[tid] = ad; s_bd[tid] = bd;
+    } else if (tid < TW + TH) {
+        int X0, Y0;
+        row_terms(m, y0 + (tid - TW), X0, Y0);
+        s_x0[tid - TW] = X0; s_y0[tid - TW] = Y0;
+    }
+    // ---- ... and then the staged pixels go to LDS (one dword per pixel, zeros outside the image)
+    if (fast_stage) {
+        if (stager) {
+#pragma unroll
+            for (int k = 0; k < SROWS; k++) {
+                const int row = ly + 5 * k;
+                if (row < bh) *reinterpret_cast<uint4*>(&tile[row * bw + 4 * lx]) = staged[k];
+            }
+        }
+    } else if (use_lds) {
         const int total = gpr * bh;
         for (int g = tid; g < total; g += NT) {
             const int row = g / gpr, gx = g - row * gpr;
-            const int sy = by0 + row, sx = bx0a + 4 * gx;
-            uint4 px = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)sy < (unsigned)a.sh) {
-                if (a.src_aligned && sx >= 0 && sx + 3 < a.sw) {
-                    const uint8_t* p = src + (size_t)sy * a.sstride + (size_t)sx * CN;
-                    if (CN == 3) {
-                        const U3 d = *reinterpret_cast<const U3*>(p);
-                        px.x = d.a & 0xFFFFFFu;
-                        px.y = (d.a >> 24) | ((d.b & 0xFFFFu) << 8);
-                        px.z = (d.b >> 16) | ((d.c & 0xFFu) << 16);
-                        px.w = d.c >> 8;
-                    } else if (CN == 1) {
-                        const uint32_t d = *reinterpret_cast<const uint32_t*>(p);
-                        px.x = d & 255u; px.y = (d >> 8) & 255u; px.z = (d >> 16) & 255u; px.w = d >> 24;
-                    } else {
-                        const uint2 d = *reinterpret_cast<const uint2*>(p);
-                        px.x = d.x & 0xFFFFu; px.y = d.x >> 16; px.z = d.y & 0xFFFFu; px.w = d.y >> 16;
-                    }
-                } else {
-                    px.x = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy);
-                    px.y = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy);
-                    px.z = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 2, sy);
-                    px.w = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 3, sy);
-                }
-            }
+            const uint4 px = stage_group<CN>(a, src, bx0a + 4 * gx, by0 + row);
             *reinterpret_cast<uint4*>(&tile[row * bw + 4 * gx]) = px;
         }
-        __syncthreads();
     }
+    __syncthreads();
 
-    const int tx = tid % TXN, ty = tid / TXN;
-    const int x = x0 + PX * tx;
-    if (x > x1) return;
-    int ad[PX], bd[PX];
-#pragma unroll
-    for (int i = 0; i < PX; i++) col_delta(iv, x + i, ad[i], bd[i]);
+    // ---- 3. output: 4 consecutive pixels x 2 rows per lane (the LDS / direct choice is
+    // tile-uniform: two straight-line bodies, so all taps of a lane are in flight together)
+    if (use_lds) emit_rows<CN, true>(a, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw);
+    else emit_rows<CN, false>(a, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw);
+}
 
-#pragma unroll
-    for (int r = 0; r < TH / TYN; r++) {
-        const int y = y0 + ty + TYN * r;
-        if (y > y1) break;
-        int X0, Y0;
-        row_base(iv, y, X0, Y0);
-        uint32_t o[PX];
-#pragma unroll
-        for (int i = 0; i < PX; i++) {
-            const int X = (X0 + ad[i]) >> 5, Y = (Y0 + bd[i]) >> 5;
-            const int sx = sat_s16(X >> 5), sy = sat_s16(Y >> 5);
-            const int fx = X & 31, fy = Y & 31;
-            uint32_t p00, p01, p10, p11;
-            if (use_lds) {
-                const int idx = (sy - by0) * bw + (sx - bx0a);
-                p00 = tile[idx]; p01 = tile[idx + 1];
-                p10 = tile[idx + bw]; p11 = tile[idx + bw + 1];
-            } else {
-                p00 = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy);
-                p01 = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy);
-                p10 = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy + 1);
-                p11 = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy + 1);
-            }
-            o[i] = blend<CN>(p00, p01, p10, p11, fx, fy);
-        }
-        uint8_t* d = dst + (size_t)y * a.dstride + (size_t)x * CN;
-        if (a.dst_aligned && x + PX - 1 <= x1) {
-            if (CN == 3) {
-                U3 v;
-                v.a = o[0] | (o[1] << 24);
-                v.b = (o[1] >> 8) | (o[2] << 16);
-                v.c = (o[2] >> 16) | (o[3] << 8);
-                *reinterpret_cast<U3*>(d) = v;
-            } else if (CN == 1) {
-                *reinterpret_cast<uint32_t*>(d) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-            } else {
-                *reinterpret_cast<uint2*>(d) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < PX; i++) {
-                if (x + i > x1) break;
-#pragma unroll
-                for (int c = 0; c < CN; c++) d[i * CN + c] = (uint8_t)(o[i] >> (8 * c));
-            }
-        }
-    }
+template <int CN>
+void launch_one(const WarpArgs& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL(warp_affine_kernel<CN>, grid, dim3(NT), 0, st, a);
+}
+
+void fill_common(WarpArgs& a, const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh, uint8_t* d_dst,
+                 size_t dstride, size_t dframe, int dw, int dh, int cn) {
+    a.src = d_src; a.dst = d_dst;
+    a.sstride = sstride; a.sframe = sframe; a.dstride = dstride; a.dframe = dframe;
+    a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;
+    const int galign = cn == 2 ? 8 : 4;
+    a.src_aligned = ((uintptr_t)d_src % galign == 0) && (sstride % galign == 0) && (sframe % galign == 0);
+    a.dst_aligned = ((uintptr_t)d_dst % galign == 0) && (dstride % galign == 0) && (dframe % galign == 0);
+}
+
+bool bad_args(const void* d_src, const void* d_dst, const void* M, size_t sstride, int sw, int sh, size_t dstride,
+              int dw, int dh, int cn, int batch) {
+    return !d_src || !d_dst || !M || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || batch <= 0 ||
+           (cn != 1 && cn != 2 && cn != 3) || sstride < (size_t)sw * cn || dstride < (size_t)dw * cn ||
+           dh > 65535 * TH;
 }
 
 }  // namespace
 
 int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                        uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
-                       const float* d_M, int batch, hipStream_t st) {
-    if (!d_src || !d_dst || !d_M || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || batch <= 0 ||
-        batch > 65535 || (cn != 1 && cn != 2 && cn != 3) || sstride < (size_t)sw * cn ||
-        dstride < (size_t)dw * cn) {
+                       const double* d_Minv, int batch, hipStream_t st) {
+    if (bad_args(d_src, d_dst, d_Minv, sstride, sw, sh, dstride, dw, dh, cn, batch) || batch > 65535) {
         set_last_error("warp_affine: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
     WarpArgs a;
-    a.src = d_src; a.dst = d_dst;
-    a.sstride = sstride; a.sframe = sframe; a.dstride = dstride; a.dframe = dframe;
-    a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;
-    const int galign = cn == 3 ? 4 : cn == 2 ? 8 : 4;
-    a.src_aligned = ((uintptr_t)d_src % galign == 0) && (sstride % galign == 0) && (sframe % galign == 0);
-    a.dst_aligned = ((uintptr_t)d_dst % galign == 0) && (dstride % galign == 0) && (dframe % galign == 0);
-    a.M_dev = d_M;
+    fill_common(a, d_src, sstride, sframe, sw, sh, d_dst, dstride, dframe, dw, dh, cn);
+    a.Minv_dev = d_Minv;
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, batch);
-    if (cn == 3) hipLaunchKernelGGL(warp_affine_kernel<3>, grid, dim3(NT), 0, st, a);
-    else if (cn == 1) hipLaunchKernelGGL(warp_affine_kernel<1>, grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL(warp_affine_kernel<2>, grid, dim3(NT), 0, st, a);
+    if (cn == 3) launch_one<3>(a, grid, st);
+    else if (cn == 1) launch_one<1>(a, grid, st);
+    else launch_one<2>(a, grid, st);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -260,27 +336,24 @@ int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int 
 int launch_warp_affine_hostM(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                              uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
                              const float* h_M, int batch, hipStream_t st) {
-    if (!d_src || !d_dst || !h_M || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || batch <= 0 ||
-        (cn != 1 && cn != 2 && cn != 3) || sstride < (size_t)sw * cn || dstride < (size_t)dw * cn) {
+    if (bad_args(d_src, d_dst, h_M, sstride, sw, sh, dstride, dw, dh, cn, batch)) {
         set_last_error("warp_affine: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
     for (int b0 = 0; b0 < batch; b0 += MAXB) {
         const int nb = batch - b0 < MAXB ? batch - b0 : MAXB;
         WarpArgs a;
-        a.src = d_src + (size_t)b0 * sframe; a.dst = d_dst + (size_t)b0 * dframe;
-        a.sstride = sstride; a.sframe = sframe; a.dstride = dstride; a.dframe = dframe;
-        a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;
-        const int galign = cn == 3 ? 4 : cn == 2 ? 8 : 4;
-        a.src_aligned = ((uintptr_t)a.src % galign == 0) && (sstride % galign == 0) && (sframe % galign == 0);
-        a.dst_aligned = ((uintptr_t)a.dst % galign == 0) && (dstride % galign == 0) && (dframe % galign == 0);
-        a.M_dev = nullptr;
-        for (int i = 0; i < nb * 6; i++) a.M_val[i] = h_M[(size_t)b0 * 6 + i];
-        for (int i = nb * 6; i < MAXB * 6; i++) a.M_val[i] = 0.f;
+        fill_common(a, d_src + (size_t)b0 * sframe, sstride, sframe, sw, sh, d_dst + (size_t)b0 * dframe, dstride,
+                    dframe, dw, dh, cn);
+        a.Minv_dev = nullptr;
+        for (int b = 0; b < MAXB; b++) {
+            if (b < nb) warp_invert(h_M + (size_t)(b0 + b) * 6, a.Minv_val + 6 * b);   // cv::warpAffine inverts on the host too
+            else for (int i = 0; i < 6; i++) a.Minv_val[6 * b + i] = 0.;
+        }
         dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, nb);
-        if (cn == 3) hipLaunchKernelGGL(warp_affine_kernel<3>, grid, dim3(NT), 0, st, a);
-        else if (cn == 1) hipLaunchKernelGGL(warp_affine_kernel<1>, grid, dim3(NT), 0, st, a);
-        else hipLaunchKernelGGL(warp_affine_kernel<2>, grid, dim3(NT), 0, st, a);
+        if (cn == 3) launch_one<3>(a, grid, st);
+        else if (cn == 1) launch_one<1>(a, grid, st);
+        else launch_one<2>(a, grid, st);
         VS_HIP_TRY(hipGetLastError());
     }
     return VS_OK;

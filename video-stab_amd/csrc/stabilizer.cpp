@@ -6,8 +6,18 @@
 // warm-up ends, on which frames features are re-detected).  Everything that
 // depends on image content stays on the GPU between kernels: keypoints and
 // their count, LK status, the RANSAC model, the trajectory history and the
-// warp matrix.  A steady-state stabilize() is therefore a fixed sequence of
-// asynchronous launches on the instance stream with no host synchronisation.
+// warp matrix.  A steady-state stabilize() is a fixed set of asynchronous
+// launches with no host synchronisation, spread over three HIP streams so that
+// independent work of consecutive frames overlaps:
+//
+//   pre   : copy-in -> resize+gray -> pyramid + Scharr      (frame k+1 ...)
+//   det   : goodFeaturesToTrack on the new gray image        (frame k, every 2nd)
+//   main  : LK -> RANSAC+append -> trajectory emit -> warp   (... while frame k tracks)
+//
+// Cross-stream order is expressed with events only where data demands it
+// (pyramid ready, keypoints ready, buffer no longer read).  Pyramids are
+// triple-buffered and the frame ring has spare slots so that `pre` of the next
+// frame never waits for `main` of the current one.
 #include <algorithm>
 #include <cstring>
 #include <deque>
@@ -26,19 +36,19 @@ int launch_ransac(const float* d_from, const float* d_to, const uint8_t* d_statu
                   const RansacTables* tab, int32_t* d_counts, double* d_model, uint8_t* d_inliers,
                   int32_t* d_info, TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg,
                   int have_prev_gray, hipStream_t st);
-int launch_compact(const float* prev, const float* cur, const uint8_t* status, int n_cap, const int32_t* d_n,
-                   float* vp, float* vc, int32_t* d_m, vs_debug_frame* dbg, hipStream_t st);
-int launch_traj_append(TrajState* s, const TrajParams& p, const double* model, const int32_t* info,
-                       const int32_t* d_nprev, vs_debug_frame* dbg, int have_prev_gray, hipStream_t st);
-int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, vs_debug_frame* dbg, hipStream_t st);
+int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
+                     hipStream_t st);
 int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st);
 int launch_make_border(const uint8_t* src, size_t sstride, int w, int h, int cn, uint8_t* dst, size_t dstride,
                        int b, int border, hipStream_t st);
 int launch_resize_linear(const uint8_t* d_src, size_t sstride, int sw, int sh, int cn, uint8_t* d_dst,
                          size_t dstride, int dw, int dh, hipStream_t st);
 
-constexpr int FRAME_RING = 36;      // clamp(smoothingRadius,5,35) frames are queued at most (+1 in flight)
+constexpr int FRAME_RING = 40;      // <= 35 queued frames (clamp(smoothingRadius,5,35)) + slack so that a
+                                    // slot is reused several frames after the warp that released it
 constexpr int MAX_PYR = 8;
+constexpr int NPYR = 3;             // pyramid buffers: frame k writes k%3 while LK(k-1) still reads (k-1)%3,(k-2)%3
+constexpr int EVR = 4;              // per-frame event ring
 
 struct Pyramid {
     uint8_t* img[MAX_PYR] = {};
@@ -52,7 +62,9 @@ using namespace vsd;
 struct vs_stab {
     vs_params_c p;
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;       // main
+    hipStream_t st_pre = nullptr;
+    hipStream_t st_det = nullptr;
     std::string err;
     // geometry, fixed by the first frame
     bool allocated = false;
@@ -65,9 +77,9 @@ struct vs_stab {
     // frame queue (Stabilizer.h:311-312)
     uint8_t* d_ring = nullptr;
     std::deque<int> q_slot, q_idx;
-    std::vector<int> free_slots;
+    std::deque<int> free_slots;     // FIFO: the slot released longest ago is reused first
     bool first = true;
-    int next_index = 0;
+    int next_index = 0;             // index of the frame being pushed (nextFrameIndex_)
     int detect_counter = 0;
     int n_transforms = 0;           // transforms_.size(), mirrored on the host
     int last_out_w = 0, last_out_h = 0;
@@ -75,8 +87,7 @@ struct vs_stab {
     int host_radius = 30;
     // analysis images
     uint8_t* d_first_gray = nullptr;     // 480x270 (Stabilizer.cpp:277)
-    Pyramid pyr[2];
-    int cur = 0;
+    Pyramid pyr[NPYR];
     bool prev_small = false;
     bool have_prev_gray = false;
     // keypoints (ping-pong: LK reads pts[pp], a re-detection writes pts[pp^1])
@@ -96,10 +107,11 @@ struct vs_stab {
     TrajState* d_traj = nullptr;
     TrajParams tp;
     float* d_M = nullptr;               // [0..5] frame matrix, [6..11] chroma matrix
+    double* d_Minv = nullptr;           // their inverse maps (what the warp kernels consume)
     vs_debug_frame* d_dbg = nullptr;
     int last_detect_pp = -1;            // buffer that holds the points detected on the last push
     bool last_detected = false;
-    int last_gray_slot = 0;
+    int last_gray_buf = 0;
     // scratch for border / host I/O
     uint8_t* d_tmp = nullptr;
     size_t tmp_bytes = 0;
@@ -107,7 +119,16 @@ struct vs_stab {
     size_t out_bytes = 0;
     uint8_t* d_all = nullptr;           // one allocation for the small buffers
     vs_counters counters;
-    // stage profiling (HIP events on the instance stream)
+    // cross-stream dependencies
+    hipEvent_t ev_gray[NPYR] = {}, ev_pre[NPYR] = {};
+    hipEvent_t ev_lk[EVR] = {}, ev_det[EVR] = {};
+    bool det_valid[EVR] = {false, false, false, false};
+    hipEvent_t ev_first = nullptr;
+    hipEvent_t ev_slot[FRAME_RING] = {};
+    bool slot_valid[FRAME_RING] = {};
+    hipEvent_t pts_event[2] = {nullptr, nullptr};   // recorded by the detection that filled pts[i]
+    bool pts_pending[2] = {false, false};
+    // stage profiling (HIP events on the stream the stage runs on)
     int prof_mode = 0;
     struct Pending { hipEvent_t a, b; int stage; };
     std::vector<Pending> pending;
@@ -115,10 +136,12 @@ struct vs_stab {
 };
 
 namespace {
+
 // Records an event pair around one stage when profiling is on.
 struct StageScope {
     vs_stab* s;
     int stage;
+    hipStream_t st;
     bool on = false;
     hipEvent_t a = nullptr, b = nullptr;
     static hipEvent_t get(vs_stab* s) {
@@ -127,19 +150,16 @@ struct StageScope {
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
-    StageScope(vs_stab* s_, int stage_) : s(s_), stage(stage_) {
+    StageScope(vs_stab* s_, int stage_, hipStream_t st_) : s(s_), stage(stage_), st(st_) {
         if (s->prof_mode == 2 || (s->prof_mode == 1 && stage == VS_STAGE_WARP)) {
             a = get(s); b = get(s);
-            if (a && b && hipEventRecord(a, s->st) == hipSuccess) on = true;
+            if (a && b && hipEventRecord(a, st) == hipSuccess) on = true;
         }
     }
     ~StageScope() {
-        if (on && hipEventRecord(b, s->st) == hipSuccess) s->pending.push_back({a, b, stage});
+        if (on && hipEventRecord(b, st) == hipSuccess) s->pending.push_back({a, b, stage});
     }
 };
-}  // namespace
-
-namespace {
 
 int fail(vs_stab* s, int code, const std::string& msg) {
     s->err = msg;
@@ -166,6 +186,14 @@ void out_size(const vs_stab* s, int w, int h, int* ow, int* oh) {
     const int b = s->p.border_size;
     if (b > 0 && !s->p.crop_n_zoom) { *ow = w + 2 * b; *oh = h + 2 * b; return; }
     *ow = w; *oh = h;   // crop+zoom resizes back to origSize_ == frame size
+}
+
+int sync_all(vs_stab* s) {
+    S_HIP(s, hipSetDevice(s->device));
+    if (s->st_pre) S_HIP(s, hipStreamSynchronize(s->st_pre));
+    if (s->st_det) S_HIP(s, hipStreamSynchronize(s->st_det));
+    if (s->st) S_HIP(s, hipStreamSynchronize(s->st));
+    return VS_OK;
 }
 
 void free_all(vs_stab* s) {
@@ -210,15 +238,15 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     }
     S_HIP(s, hipMalloc((void**)&s->d_ring, s->frame_bytes * FRAME_RING));
     s->free_slots.clear();
-    for (int i = FRAME_RING - 1; i >= 0; i--) s->free_slots.push_back(i);
+    for (int i = 0; i < FRAME_RING; i++) { s->free_slots.push_back(i); s->slot_valid[i] = false; }
     s->ncap = std::max(s->p.max_corners, 1);
     const int ncap = s->ncap;
     // carve the small buffers out of one allocation (256-byte aligned pieces)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t o_first = take((size_t)480 * 270);
-    size_t o_img[2][MAX_PYR], o_der[2][MAX_PYR];
-    for (int k = 0; k < 2; k++)
+    size_t o_img[NPYR][MAX_PYR], o_der[NPYR][MAX_PYR];
+    for (int k = 0; k < NPYR; k++)
         for (int l = 0; l <= s->levels; l++) {
             o_img[k][l] = take((size_t)s->lw[l] * s->lh[l]);
             o_der[k][l] = take((size_t)s->lw[l] * s->lh[l] * 4);
@@ -229,12 +257,12 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     size_t o_vp = take((size_t)ncap * 8), o_vc = take((size_t)ncap * 8);
     size_t o_status = take(ncap), o_inl = take(ncap);
     size_t o_m = take(16), o_info = take(16), o_counts = take((size_t)s->p.ransac_max_iters * 4);
-    size_t o_model = take(48), o_traj = take(sizeof(TrajState)), o_M = take(96), o_dbg = take(sizeof(vs_debug_frame));
+    size_t o_model = take(48), o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
     S_HIP(s, hipMemsetAsync(s->d_all, 0, off, s->st));
     uint8_t* b = s->d_all;
     s->d_first_gray = b + o_first;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < NPYR; k++)
         for (int l = 0; l <= s->levels; l++) {
             s->pyr[k].img[l] = b + o_img[k][l];
             s->pyr[k].der[l] = (int16_t*)(b + o_der[k][l]);
@@ -245,7 +273,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->d_status = b + o_status; s->d_inliers = b + o_inl;
     s->d_m = (int32_t*)(b + o_m); s->d_info = (int32_t*)(b + o_info); s->d_counts = (int32_t*)(b + o_counts);
     s->d_model = (double*)(b + o_model); s->d_traj = (TrajState*)(b + o_traj);
-    s->d_M = (float*)(b + o_M); s->d_dbg = (vs_debug_frame*)(b + o_dbg);
+    s->d_M = (float*)(b + o_M); s->d_Minv = (double*)(b + o_Minv); s->d_dbg = (vs_debug_frame*)(b + o_dbg);
     // GFTT scratch sized for the larger of the two detection images
     const int gmaxw = std::max(s->aw, 480), gmaxh = std::max(s->ah, 270);
     const int cap = gmaxw * gmaxh / 4 + 64;
@@ -259,6 +287,10 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->tmp_bytes = std::max(s->out_bytes, s->frame_bytes);
     S_HIP(s, hipMalloc((void**)&s->d_tmp, s->tmp_bytes));
     S_TRY(s, launch_traj_reset(s->d_traj, s->p.smoothing_radius, s->st));
+    // the zero-fill and the reset ran on `main`; nothing may touch the buffers before that
+    S_HIP(s, hipStreamSynchronize(s->st));
+    for (int i = 0; i < EVR; i++) s->det_valid[i] = false;
+    s->pts_pending[0] = s->pts_pending[1] = false;
     s->allocated = true;
     return VS_OK;
 }
@@ -294,81 +326,117 @@ void fill_traj_params(vs_stab* s) {
     for (int i = 0; i < ks; i++) t.gauss_kernel[i] /= sum;
 }
 
-int build_pyramid(vs_stab* s, int k) {
+int build_pyramid(vs_stab* s, int k, hipStream_t st) {
     Pyramid& P = s->pyr[k];
     for (int l = 1; l <= s->levels; l++)
-        S_TRY(s, launch_pyr_down(P.img[l - 1], s->lw[l - 1], s->lw[l - 1], s->lh[l - 1], P.img[l], s->lw[l], s->st));
+        S_TRY(s, launch_pyr_down(P.img[l - 1], s->lw[l - 1], s->lw[l - 1], s->lh[l - 1], P.img[l], s->lw[l], st));
     for (int l = 0; l <= s->levels; l++)
-        S_TRY(s, launch_scharr(P.img[l], s->lw[l], s->lw[l], s->lh[l], P.der[l], s->st));
+        S_TRY(s, launch_scharr(P.img[l], s->lw[l], s->lw[l], s->lh[l], P.der[l], st));
     return VS_OK;
 }
 
-// generateTransform (Stabilizer.cpp:402-761) for the frame in ring slot `slot`
-int generate_transform(vs_stab* s, const uint8_t* d_frame) {
+// `pre` stream, part 1: the frame enters the queue ring (waits until the slot's last reader is done)
+int enqueue_copy_in(vs_stab* s, int slot, const void* src, size_t stride, hipMemcpyKind kind) {
+    if (s->slot_valid[slot]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_slot[slot], 0));
+    StageScope t(s, VS_STAGE_COPY_IN, s->st_pre);
+    S_HIP(s, hipMemcpy2DAsync(s->d_ring + (size_t)slot * s->frame_bytes, s->row_bytes, src, stride, s->row_bytes,
+                              s->rows_total, kind, s->st_pre));
+    return VS_OK;
+}
+
+// generateTransform (Stabilizer.cpp:402-761) for frame index f >= 1 held in `d_frame`
+int generate_transform(vs_stab* s, const uint8_t* d_frame, int f) {
     const vs_params_c& p = s->p;
-    const int c = s->cur, pv = s->cur ^ 1;
+    const int c = f % NPYR, pv = (f - 1) % NPYR;
+    // ---- pre: gray + pyramid into buffer c.  Its previous readers were LK(f-2) (as "prev")
+    // and, if frame f-3 re-detected, the detector.
+    if (f - 2 >= 1) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_lk[(f - 2) % EVR], 0));
+    if (f - 3 >= 1 && s->det_valid[(f - 3) % EVR]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_det[(f - 3) % EVR], 0));
     {
-        StageScope t(s, VS_STAGE_GRAY);
-        S_TRY(s, launch_resize_gray(d_frame, s->row_bytes, s->w, s->h, s->fmt, s->pyr[c].img[0], s->aw, s->aw, s->ah, s->st));  // :448-450
+        StageScope t(s, VS_STAGE_GRAY, s->st_pre);
+        S_TRY(s, launch_resize_gray(d_frame, s->row_bytes, s->w, s->h, s->fmt, s->pyr[c].img[0], s->aw, s->aw, s->ah, s->st_pre));  // :448-450
     }
+    S_HIP(s, hipEventRecord(s->ev_gray[c], s->st_pre));
     {
-        StageScope t(s, VS_STAGE_PYRAMID);
-        S_TRY(s, build_pyramid(s, c));
+        StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
+        S_TRY(s, build_pyramid(s, c, s->st_pre));
         if (s->prev_small) {   // :598-603 (once: 480x270 -> analysis size)
-            S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[pv].img[0], s->aw, s->aw, s->ah, s->st));
-            S_TRY(s, build_pyramid(s, pv));
+            S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[pv].img[0], s->aw, s->aw, s->ah, s->st_pre));
+            S_TRY(s, build_pyramid(s, pv, s->st_pre));
             s->prev_small = false;
         }
+    }
+    S_HIP(s, hipEventRecord(s->ev_pre[c], s->st_pre));
+
+    // ---- det: every second call re-detects on the new gray image (:696-746).  Needs only
+    // img[0]; its output buffer pts[pp^1] was last read by LK(f-2), which `pre` waited for.
+    const int pp = s->pp;
+    s->last_detected = false;
+    s->det_valid[f % EVR] = false;
+    int next_pp = pp;
+    if ((++s->detect_counter % 2) == 0) {
+        const int q = pp ^ 1;
+        const int mc = std::min(p.max_corners, 200);
+        S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_gray[c], 0));
+        {
+            StageScope t(s, VS_STAGE_GFTT, s->st_det);
+            S_TRY(s, launch_gftt(s->pyr[c].img[0], s->aw, s->aw, s->ah, mc, 0.02, 15.0, 3, s->gw, s->d_pts[q],
+                                 s->d_npts[q], s->st_det));
+        }
+        S_HIP(s, hipEventRecord(s->ev_det[f % EVR], s->st_det));
+        s->det_valid[f % EVR] = true;
+        s->pts_event[q] = s->ev_det[f % EVR];
+        s->pts_pending[q] = true;
+        s->pts_cap[q] = mc;
+        next_pp = q;
+        s->last_detected = true;
+        s->last_detect_pp = q;
+        s->counters.detections++;
+    }
+
+    // ---- main: LK needs this frame's pyramid and the keypoints of the last detection
+    S_HIP(s, hipStreamWaitEvent(s->st, s->ev_pre[c], 0));
+    if (s->pts_pending[pp]) {
+        S_HIP(s, hipStreamWaitEvent(s->st, s->pts_event[pp], 0));
+        s->pts_pending[pp] = false;
     }
     LKLevel L[MAX_PYR];
     for (int l = 0; l <= s->levels; l++) {
         L[l].prev = s->pyr[pv].img[l]; L[l].next = s->pyr[c].img[l]; L[l].deriv = s->pyr[pv].der[l];
         L[l].w = s->lw[l]; L[l].h = s->lh[l]; L[l].stride = s->lw[l];
     }
-    const int pp = s->pp;
     const int cap = s->pts_cap[pp];
     {
-        StageScope t(s, VS_STAGE_LK);
+        StageScope t(s, VS_STAGE_LK, s->st);
         S_TRY(s, launch_pyr_lk(L, s->levels, s->d_pts[pp], cap, s->d_npts[pp], s->d_next, s->d_status, s->d_err,
                                p.lk_win_size, p.lk_max_iters, p.lk_epsilon, s->st));   // :611-619
     }
+    S_HIP(s, hipEventRecord(s->ev_lk[f % EVR], s->st));
     s->last_lk_pp = pp;
     {
         // status compaction (:629-641) + estimateAffinePartial2D (:644-659) + transform append (:660-693)
-        StageScope t(s, VS_STAGE_RANSAC);
+        StageScope t(s, VS_STAGE_RANSAC, s->st);
         S_TRY(s, launch_ransac(s->d_pts[pp], s->d_next, s->d_status, std::max(cap, 0), s->d_npts[pp], s->d_vp, s->d_vc,
                                s->d_m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab, s->d_counts, s->d_model,
                                s->d_inliers, s->d_info, s->d_traj, &s->tp, s->d_dbg, s->have_prev_gray ? 1 : 0, s->st));
     }
     s->n_transforms++;
-    s->last_detected = false;
-    if ((++s->detect_counter % 2) == 0) {                                            // :696-746
-        const int q = pp ^ 1;
-        const int mc = std::min(p.max_corners, 200);
-        StageScope t(s, VS_STAGE_GFTT);
-        S_TRY(s, launch_gftt(s->pyr[c].img[0], s->aw, s->aw, s->ah, mc, 0.02, 15.0, 3, s->gw, s->d_pts[q],
-                             s->d_npts[q], s->st));
-        s->pts_cap[q] = mc;
-        s->pp = q;
-        s->last_detected = true;
-        s->last_detect_pp = q;
-        s->counters.detections++;
-    }
-    s->last_gray_slot = c;
-    s->cur ^= 1;                                                                      // :757-759
-    s->have_prev_gray = true;
+    s->pp = next_pp;
+    s->last_gray_buf = c;
+    s->have_prev_gray = true;                                                         // :757-759
     return VS_OK;
 }
 
-// applyNextSmoothTransform (Stabilizer.cpp:763-1137) into d_out (device)
+// applyNextSmoothTransform (Stabilizer.cpp:763-1137) into d_out (device), on `main`
 int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride) {
     const vs_params_c& p = s->p;
     const int slot = s->q_slot.front(), idx = s->q_idx.front();
     s->q_slot.pop_front(); s->q_idx.pop_front();
     const uint8_t* frame = s->d_ring + (size_t)slot * s->frame_bytes;
+    hipStream_t st = s->st;
     {
-        StageScope t(s, VS_STAGE_TRAJ);
-        S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_dbg, s->st));
+        StageScope t(s, VS_STAGE_TRAJ, st);
+        S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_Minv, s->d_dbg, st));
     }
     int rc = VS_OK;
     int ow, oh;
@@ -378,34 +446,36 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride) {
         // Stabilizer.cpp:774-780: no transform exists for this frame (last frame of a
         // flush): the queued frame is returned as is, at its own size (no border pad).
         if (ow != s->w || oh != s->h)
-            S_HIP(s, hipMemset2DAsync(d_out, out_stride, 0, (size_t)ow * s->cn, oh, s->st));
+            S_HIP(s, hipMemset2DAsync(d_out, out_stride, 0, (size_t)ow * s->cn, oh, st));
         S_HIP(s, hipMemcpy2DAsync(d_out, out_stride, frame, s->row_bytes, s->row_bytes, s->rows_total,
-                                  hipMemcpyDeviceToDevice, s->st));
+                                  hipMemcpyDeviceToDevice, st));
         s->last_out_w = s->w; s->last_out_h = s->h;
     } else if (s->fmt == VS_FMT_NV12) {
-        StageScope t(s, VS_STAGE_WARP);
-        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_M, 1, s->st);
+        StageScope t(s, VS_STAGE_WARP, st);
+        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_Minv, 1, st);
         if (rc == VS_OK)
             rc = launch_warp_affine(frame + (size_t)s->h * s->row_bytes, s->row_bytes, 0, s->w / 2, s->h / 2,
                                     d_out + (size_t)s->h * out_stride, out_stride, 0, s->w / 2, s->h / 2, 2,
-                                    s->d_M + 6, 1, s->st);
+                                    s->d_Minv + 6, 1, st);
     } else if (p.border_size > 0 && !p.crop_n_zoom) {                                 // :981-990
         const int b = p.border_size, bw = s->w + 2 * b, bh = s->h + 2 * b;
-        rc = launch_make_border(frame, s->row_bytes, s->w, s->h, s->cn, s->d_tmp, (size_t)bw * s->cn, b, p.border_type, s->st);
-        StageScope t(s, VS_STAGE_WARP);
+        rc = launch_make_border(frame, s->row_bytes, s->w, s->h, s->cn, s->d_tmp, (size_t)bw * s->cn, b, p.border_type, st);
+        StageScope t(s, VS_STAGE_WARP, st);
         if (rc == VS_OK)
-            rc = launch_warp_affine(s->d_tmp, (size_t)bw * s->cn, 0, bw, bh, d_out, out_stride, 0, bw, bh, s->cn, s->d_M, 1, s->st);
+            rc = launch_warp_affine(s->d_tmp, (size_t)bw * s->cn, 0, bw, bh, d_out, out_stride, 0, bw, bh, s->cn, s->d_Minv, 1, st);
     } else if (p.crop_n_zoom && p.border_size > 0 && s->w - 2 * p.border_size > 0 && s->h - 2 * p.border_size > 0) {  // :1108-1124
         const int b = p.border_size;
-        StageScope t(s, VS_STAGE_WARP);
-        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, s->d_tmp, s->row_bytes, 0, s->w, s->h, s->cn, s->d_M, 1, s->st);
+        StageScope t(s, VS_STAGE_WARP, st);
+        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, s->d_tmp, s->row_bytes, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
         if (rc == VS_OK)
             rc = launch_resize_linear(s->d_tmp + ((size_t)b * s->w + b) * s->cn, s->row_bytes, s->w - 2 * b, s->h - 2 * b,
-                                      s->cn, d_out, out_stride, s->orig_w, s->orig_h, s->st);
+                                      s->cn, d_out, out_stride, s->orig_w, s->orig_h, st);
     } else {                                                                          // :1056-1060
-        StageScope t(s, VS_STAGE_WARP);
-        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, s->cn, s->d_M, 1, s->st);
+        StageScope t(s, VS_STAGE_WARP, st);
+        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
     }
+    // the slot may be overwritten once this warp has read it
+    if (hipEventRecord(s->ev_slot[slot], st) == hipSuccess) s->slot_valid[slot] = true;
     s->free_slots.push_back(slot);
     if (rc != VS_OK) { s->err = get_last_error(); return rc; }
     s->counters.frames_out++;
@@ -425,7 +495,7 @@ int check_params(const vs_params_c* p, std::string* why) {
     return VS_OK;
 }
 
-// Shared body of stabilize(): `d_frame_in_ring` already holds the frame.
+// Shared body of stabilize(): the frame is already on its way into ring slot `slot` (on `pre`).
 int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* produced) {
     const vs_params_c& p = s->p;
     const uint8_t* frame = s->d_ring + (size_t)slot * s->frame_bytes;
@@ -433,9 +503,14 @@ int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* pr
     s->counters.frames_in++;
     if (p.crop_n_zoom && s->orig_w == 0) { s->orig_w = s->w; s->orig_h = s->h; }   // :267-269
     if (s->first) {                                                                  // :271-368
-        S_TRY(s, launch_resize_gray(frame, s->row_bytes, s->w, s->h, s->fmt, s->d_first_gray, 480, 480, 270, s->st));  // :304-305
+        S_TRY(s, launch_resize_gray(frame, s->row_bytes, s->w, s->h, s->fmt, s->d_first_gray, 480, 480, 270, s->st_pre));  // :304-305
+        S_HIP(s, hipEventRecord(s->ev_first, s->st_pre));
+        S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_first, 0));
         S_TRY(s, launch_gftt(s->d_first_gray, 480, 480, 270, p.max_corners, p.quality_level, p.min_distance,
-                             p.block_size, s->gw, s->d_pts[0], s->d_npts[0], s->st));   // :354-358
+                             p.block_size, s->gw, s->d_pts[0], s->d_npts[0], s->st_det));   // :354-358
+        S_HIP(s, hipEventRecord(s->ev_det[0], s->st_det));
+        s->pts_event[0] = s->ev_det[0];
+        s->pts_pending[0] = true;
         s->pp = 0; s->pts_cap[0] = p.max_corners;
         s->last_detected = true; s->last_detect_pp = 0;
         s->counters.detections++;
@@ -445,7 +520,7 @@ int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* pr
         return VS_OK;
     }
     s->q_slot.push_back(slot); s->q_idx.push_back(s->next_index);                   // :376-377
-    S_TRY(s, generate_transform(s, frame));                                         // :380
+    S_TRY(s, generate_transform(s, frame, s->next_index));                          // :380
     if (p.adaptive_smoothing) {
         // params_.smoothingRadius is data dependent in this mode (:1482-1486) and
         // moves the warm-up threshold (:383): read it back (synchronises).
@@ -464,8 +539,8 @@ int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* pr
 
 int take_slot(vs_stab* s, int* slot) {
     if (s->free_slots.empty()) return fail(s, VS_ERR_CAPACITY, "frame ring exhausted");
-    *slot = s->free_slots.back();
-    s->free_slots.pop_back();
+    *slot = s->free_slots.front();
+    s->free_slots.pop_front();
     return VS_OK;
 }
 
@@ -479,6 +554,27 @@ int prepare(vs_stab* s, int w, int h, int fmt, size_t stride) {
     S_HIP(s, hipSetDevice(s->device));
     if (!s->allocated) return allocate(s, w, h, fmt);
     if (w != s->w || h != s->h || fmt != s->fmt) return fail(s, VS_ERR_SIZE_CHANGED, "frame geometry changed; call vs_stab_clean()");
+    return VS_OK;
+}
+
+void destroy_events(vs_stab* s) {
+    auto kill = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };
+    for (auto& e : s->ev_gray) kill(e);
+    for (auto& e : s->ev_pre) kill(e);
+    for (auto& e : s->ev_lk) kill(e);
+    for (auto& e : s->ev_det) kill(e);
+    for (auto& e : s->ev_slot) kill(e);
+    kill(s->ev_first);
+}
+
+int create_events(vs_stab* s) {
+    auto mk = [&](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming); };
+    for (auto& e : s->ev_gray) S_HIP(s, mk(e));
+    for (auto& e : s->ev_pre) S_HIP(s, mk(e));
+    for (auto& e : s->ev_lk) S_HIP(s, mk(e));
+    for (auto& e : s->ev_det) S_HIP(s, mk(e));
+    for (auto& e : s->ev_slot) S_HIP(s, mk(e));
+    S_HIP(s, mk(s->ev_first));
     return VS_OK;
 }
 
@@ -505,7 +601,13 @@ int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
     memset(&s->counters, 0, sizeof s->counters);
     fill_traj_params(s);
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
-    if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); delete s; return VS_ERR_HIP; }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_pre, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_det, hipStreamNonBlocking);
+    if (e != hipSuccess || create_events(s) != VS_OK) {
+        set_last_error(e != hipSuccess ? hipGetErrorString(e) : s->err);
+        vs_stab_destroy(s);
+        return VS_ERR_HIP;
+    }
     *out = s;
     return VS_OK;
 }
@@ -513,22 +615,27 @@ int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
 void vs_stab_destroy(vs_stab* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    if (s->st) (void)hipStreamSynchronize(s->st);   // the destructor may race in-flight work (vsg.cpp:1374)
+    // the destructor may race in-flight work (vsg.cpp:1374): drain all three streams first
+    if (s->st_pre) (void)hipStreamSynchronize(s->st_pre);
+    if (s->st_det) (void)hipStreamSynchronize(s->st_det);
+    if (s->st) (void)hipStreamSynchronize(s->st);
     free_all(s);
     for (auto& pe : s->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    destroy_events(s);
     if (s->st) (void)hipStreamDestroy(s->st);
+    if (s->st_pre) (void)hipStreamDestroy(s->st_pre);
+    if (s->st_det) (void)hipStreamDestroy(s->st_det);
     delete s;
 }
 
 int vs_stab_clean(vs_stab* s) {   // Stabilizer.cpp:221-256
     if (!s) return VS_ERR_INVALID_ARG;
-    (void)hipSetDevice(s->device);
-    if (s->st) S_HIP(s, hipStreamSynchronize(s->st));
+    S_TRY(s, sync_all(s));
     free_all(s);
     s->q_slot.clear(); s->q_idx.clear();
     s->first = true; s->next_index = 0; s->w = s->h = 0; s->orig_w = s->orig_h = 0; s->n_transforms = 0;
-    s->have_prev_gray = false; s->prev_small = false; s->cur = 0; s->pp = 0;
+    s->have_prev_gray = false; s->prev_small = false; s->pp = 0;
     s->host_radius = s->p.smoothing_radius;
     return VS_OK;
 }
@@ -548,13 +655,8 @@ int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride
     if (rc != VS_OK) return rc;
     int slot;
     S_TRY(s, take_slot(s, &slot));
-    {
-        StageScope t(s, VS_STAGE_COPY_IN);
-        S_HIP(s, hipMemcpy2DAsync(s->d_ring + (size_t)slot * s->frame_bytes, s->row_bytes, d_data, stride, s->row_bytes,
-                                  s->rows_total, hipMemcpyDeviceToDevice, s->st));
-    }
-    rc = push_common(s, slot, (uint8_t*)d_out, out_stride, produced);
-    return rc;
+    S_TRY(s, enqueue_copy_in(s, slot, d_data, stride, hipMemcpyDeviceToDevice));
+    return push_common(s, slot, (uint8_t*)d_out, out_stride, produced);
 }
 
 int vs_stab_flush_dev(vs_stab* s, void* d_out, size_t out_stride, int* produced) {   // Stabilizer.cpp:394-400
@@ -576,8 +678,7 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
     if (rc != VS_OK) return rc;
     int slot;
     S_TRY(s, take_slot(s, &slot));
-    S_HIP(s, hipMemcpy2DAsync(s->d_ring + (size_t)slot * s->frame_bytes, s->row_bytes, data, stride, s->row_bytes,
-                              s->rows_total, hipMemcpyHostToDevice, s->st));
+    S_TRY(s, enqueue_copy_in(s, slot, data, stride, hipMemcpyHostToDevice));
     int ow, oh;
     out_size(s, w, h, &ow, &oh);
     const size_t orow = (size_t)ow * s->cn;
@@ -588,6 +689,8 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
         const int orows = fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh;
         S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_out, orow, orow, orows, hipMemcpyDeviceToHost, s->st));
     }
+    // the caller's frame must be consumed and its result delivered before returning
+    S_HIP(s, hipStreamSynchronize(s->st_pre));
     S_HIP(s, hipStreamSynchronize(s->st));
     return VS_OK;
 }
@@ -610,17 +713,14 @@ int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced) {
 
 int vs_stab_sync(vs_stab* s) {
     if (!s) return VS_ERR_INVALID_ARG;
-    S_HIP(s, hipSetDevice(s->device));
-    S_HIP(s, hipStreamSynchronize(s->st));
-    return VS_OK;
+    return sync_all(s);
 }
 
 int vs_stab_get_counters(vs_stab* s, vs_counters* out) {
     if (!s || !out) return VS_ERR_INVALID_ARG;
     *out = s->counters;
     if (s->allocated) {
-        S_HIP(s, hipSetDevice(s->device));
-        S_HIP(s, hipStreamSynchronize(s->st));
+        S_TRY(s, sync_all(s));
         vs_debug_frame d;
         int32_t c[4] = {0, 0, 0, 0};
         S_HIP(s, hipMemcpy(&d, s->d_dbg, sizeof d, hipMemcpyDeviceToHost));
@@ -639,8 +739,7 @@ int vs_stab_get_debug(vs_stab* s, vs_debug_frame* out) {
     memset(out, 0, sizeof *out);
     out->out_index = -1;
     if (!s->allocated) return VS_OK;
-    S_HIP(s, hipSetDevice(s->device));
-    S_HIP(s, hipStreamSynchronize(s->st));
+    S_TRY(s, sync_all(s));
     S_HIP(s, hipMemcpy(out, s->d_dbg, sizeof *out, hipMemcpyDeviceToHost));
     out->detected = s->last_detected ? 1 : 0;
     out->n_detected = 0;
@@ -674,7 +773,7 @@ int vs_stab_get_debug_arrays(vs_stab* s, float* prev_pts, float* curr_pts, uint8
         if (aw) *aw = 480;
         if (ah) *ah = 270;
     } else {
-        if (gray) S_HIP(s, hipMemcpy(gray, s->pyr[s->last_gray_slot].img[0], (size_t)s->aw * s->ah, hipMemcpyDeviceToHost));
+        if (gray) S_HIP(s, hipMemcpy(gray, s->pyr[s->last_gray_buf].img[0], (size_t)s->aw * s->ah, hipMemcpyDeviceToHost));
         if (aw) *aw = s->aw;
         if (ah) *ah = s->ah;
     }
@@ -700,8 +799,7 @@ int vs_stab_get_stage_times(vs_stab* s, double* total_ms, int64_t* launches) {
     if (!s || !total_ms || !launches) return VS_ERR_INVALID_ARG;
     for (int i = 0; i < VS_STAGE_COUNT; i++) { total_ms[i] = 0; launches[i] = 0; }
     if (!s->st) return VS_OK;
-    S_HIP(s, hipSetDevice(s->device));
-    S_HIP(s, hipStreamSynchronize(s->st));
+    S_TRY(s, sync_all(s));
     for (auto& pe : s->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess && pe.stage >= 0 && pe.stage < VS_STAGE_COUNT) {

@@ -54,11 +54,30 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 #endif
 
+// cv::warpAffine's inversion of the forward 2x3 matrix, in double (imgwarp.cpp).  The same
+// IEEE operation sequence on host and device (no FMA contraction in either build).
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline void warp_invert(const float* Mf, double* inv) {
+    double M[6];
+    for (int i = 0; i < 6; i++) M[i] = (double)Mf[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    double b1 = -M[0] * M[2] - M[1] * M[5];
+    double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    for (int i = 0; i < 6; i++) inv[i] = M[i];
+}
+
 // ---- stage launchers (device pointers, asynchronous on `st`) -----------------
-// d_M: batch*6 floats on the DEVICE (forward matrices).
+// d_Minv: batch*6 doubles on the DEVICE: the INVERSE maps (warp_invert of the forward matrices).
 int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                        uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
-                       const float* d_M, int batch, hipStream_t st);
+                       const double* d_Minv, int batch, hipStream_t st);
 int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
                        uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st);
 int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst,
