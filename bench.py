@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "video-stab_amd"))
 
-from vsamd import capi, synth  # noqa: E402
+from vsamd import capi, dist as vsdist, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
 
@@ -98,16 +98,8 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph when available")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    comm = vsdist.Comm()           # nccl (= RCCL) when WORLD_SIZE > 1, nothing otherwise
+    rank, local_rank, world = comm.rank, comm.local_rank, comm.world
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
@@ -120,10 +112,12 @@ def main():
     W, H = args.width, args.height
     fb = W * H * 3
     S = args.streams
-    # synthetic clips: stream j of rank r uses seed base + global stream id
+    # synthetic clips: global stream g (owned by rank g % world) uses seed base + g
     clips, d_in = [], []
-    for j in range(S):
-        seed = synth.SEED_CONFIG2 + (rank * S + j)
+    my_streams = vsdist.streams_of_rank(rank, n_gpus, S * n_gpus)
+    assert len(my_streams) == S
+    for g in my_streams:
+        seed = synth.SEED_CONFIG2 + g
         frames = synth.make_clip(seed, W, H, args.clip_frames)
         clips.append(frames)
         buf = capi.DevBuf(vs, fb * len(frames))
@@ -144,12 +138,9 @@ def main():
     def sync_all():
         for s in stabs:
             s.sync()
-        if torch is not None:
-            torch.cuda.synchronize()
+        comm.device_sync()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = comm.barrier
 
     for i in range(preroll):
         step(i)
@@ -173,10 +164,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = comm.max_over_ranks(elapsed)
 
     # per-stage device time of the timed region (HIP events on the instance streams)
     stage_ms = [0.0] * 8
@@ -188,6 +176,8 @@ def main():
             stage_n[k] += n[k]
     frames_out = sum(s.counters().frames_out for s in stabs)
     assert frames_out >= args.steps * S, "timed steps did not all produce frames"
+    # throughput counters of every rank (the only inter-GPU traffic of the path)
+    per_rank = comm.gather_counters([rank, args.steps * S, frames_out])
 
     if rank == 0:
         warp_bytes = 2.0 * fb                                    # algorithmic bytes per launch
@@ -216,7 +206,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d stream(s)/GPU %dx%d BGR8, 200 corners, 3-level LK 21x21, "
                                    "RANSAC partial affine, warpAffine; frames resident in HBM" % (S, W, H),
-                       "streams_per_gpu": S, "graph": bool(args.graph)},
+                       "streams_per_gpu": S, "graph": bool(args.graph),
+                       "timed_frames_per_rank": [int(r[1]) for r in per_rank]},
             "roofline": {"bound": "hbm", "kernel": "warp_affine_kernel<3>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "bytes_per_launch": warp_bytes,
@@ -232,8 +223,7 @@ def main():
 
     for s in stabs:
         s.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

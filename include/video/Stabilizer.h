@@ -1,0 +1,162 @@
+// vs::Stabilizer for MI355X - source-compatible replacement of the reference's
+// include/video/Stabilizer.h (namespace vs, class Stabilizer, nested Parameters
+// with the same field names, types and defaults: reference Stabilizer.h:25-198).
+//
+// Applications written against the reference (examples/vs.cpp:229,403,560,
+// examples/file-capture.cpp:22-64, examples/vsg.cpp:1243-1289) compile
+// unchanged: same constructor, stabilize()/flush()/clean(), value semantics
+// (move-assignable; `stab = vs::Stabilizer(params)` works).  Everything behind
+// the three calls runs on the GPU through the C ABI in include/vs_stab.h;
+// OpenCV is used for cv::Mat I/O only.  The reference's ~20 private helper
+// declarations (many without a definition) are not part of
+// the interface and are not repeated here.
+#ifndef VIDEO_STABILIZER_HPP
+#define VIDEO_STABILIZER_HPP
+
+#include <opencv2/opencv.hpp>
+
+#include <string>
+
+struct vs_stab;   // opaque C-ABI handle (include/vs_stab.h)
+
+namespace vs {
+
+    // reference Stabilizer.h:28-65
+    struct Transform {
+        float dx = 0.0f;
+        float dy = 0.0f;
+        float da = 0.0f;
+
+        Transform() = default;
+        Transform(float x, float y, float a) : dx(x), dy(y), da(a) {}
+    };
+
+    struct MotionSample {
+        Transform transform;
+        float magnitude = 0.0f;
+        float confidence = 0.0f;
+        int timestamp = 0;
+    };
+
+    enum class MotionType { NORMAL, INTENTIONAL_PAN, CAMERA_SHAKE, WALKING_VIBRATION, VEHICLE_VIBRATION };
+    enum class MotionIntent { NORMAL, DELIBERATE_PAN, SHAKE_REMOVAL, FOLLOW_ACTION };
+    enum class SceneType { NORMAL, SPORT, DRONE, HANDHELD, VEHICLE };
+
+    class Stabilizer
+    {
+    public:
+        // reference Stabilizer.h:76-175 - same names, types and defaults
+        struct Parameters
+        {
+            bool useCuda = false;              ///< ignored: the GPU path is the only path of this build
+            bool logging = false;
+
+            int smoothingRadius = 30;
+            int maxCorners = 200;
+            double qualityLevel = 0.01;
+            double minDistance = 30.0;
+            int blockSize = 3;
+
+            std::string borderType = "black";  ///< "black", "reflect", "reflect_101", "replicate", "wrap", "fade"
+            int borderSize = 0;
+            bool cropNZoom = false;
+
+            std::string smoothingMethod = "box";  ///< "box", "gaussian", "kalman"
+            double gaussianSigma = 2.0;
+            bool motionPrediction = true;
+            bool horizonLock = false;
+
+            enum FeatureDetector { GFTT, ORB, FAST, BRISK };
+            FeatureDetector featureDetector = GFTT;
+            int orbFeatures = 500;
+            int fastThreshold = 10;
+
+            bool useROI = false;
+            cv::Rect roi = cv::Rect();
+
+            bool adaptiveSmoothing = false;
+            int minSmoothingRadius = 5;
+            int maxSmoothingRadius = 50;
+
+            double outlierThreshold = 3.0;
+            double intentionalMotionThreshold = 20.0;
+
+            int stageOneRadius = 10;
+            int stageTwoRadius = 25;
+            bool useTemporalFiltering = false;
+            int temporalWindowSize = 5;
+
+            float fadeAlpha = 0.1f;
+            int fadeDuration = 30;
+
+            float motionThresholdLow = 5.0f;
+            float motionThresholdHigh = 20.0f;
+            float borderScaleFactor = 2.0f;
+
+            bool rollCompensation = true;
+            double rollCompensationFactor = 0.75;
+
+            bool deepStabilization = false;
+            std::string modelPath = "";
+
+            enum JitterFrequency { LOW, MEDIUM, HIGH, ADAPTIVE };
+            JitterFrequency jitterFrequency = ADAPTIVE;
+            bool separateTranslationRotation = true;
+            bool useImuData = false;
+
+            bool enableVirtualCanvas = false;
+            float canvasScaleFactor = 1.5f;
+            int temporalBufferSize = 30;
+            float canvasBlendWeight = 0.7f;
+            bool adaptiveCanvasSize = true;
+            float maxCanvasScale = 2.0f;
+            float minCanvasScale = 1.2f;
+            bool preserveEdgeQuality = true;
+            int edgeBlendRadius = 20;
+
+            bool droneHighFreqMode = false;
+            float hfShakePx = 1.5f;
+            int hfAnalysisMaxWidth = 960;
+            float hfRotLPAlpha = 0.2f;
+            bool enableConditionalCLAHE = true;
+
+            float hfDeadZoneThreshold = 2.0f;
+            int hfFreezeDuration = 10;
+            float hfMotionAccumulatorDecay = 0.9f;
+        };
+
+        explicit Stabilizer(const Parameters &params);
+        ~Stabilizer();
+
+        // The reference class is implicitly copyable; its call sites only ever
+        // assign a freshly constructed temporary (vs.cpp:403,481).  Moves
+        // transfer the GPU instance; a copy starts a new stream with the same
+        // parameters (queued frames are not duplicated).
+        Stabilizer(Stabilizer &&other) noexcept;
+        Stabilizer &operator=(Stabilizer &&other) noexcept;
+        Stabilizer(const Stabilizer &other);
+        Stabilizer &operator=(const Stabilizer &other);
+
+        /// BGR CV_8UC3 frame in; stabilized frame out, or an empty Mat while the
+        /// first clamp(smoothingRadius,5,35)-1 frames are queued (reference Stabilizer.cpp:258-392).
+        cv::Mat stabilize(const cv::Mat &frame);
+
+        /// Next queued frame after the stream ended, or empty (Stabilizer.cpp:394-400).
+        cv::Mat flush();
+
+        /// Back to the first-frame state (Stabilizer.cpp:221-256).
+        void clean();
+
+    private:
+        void logMessage(const std::string &msg, bool isError = false) const;
+        void create();
+
+        Parameters params_;
+        vs_stab *impl_ = nullptr;
+        int device_ = 0;
+        int frameWidth_ = 0, frameHeight_ = 0;   // geometry of the stream (set by the first frame)
+    };
+
+}
+
+#endif // VIDEO_STABILIZER_HPP

@@ -1,0 +1,48 @@
+// Drives vs::Stabilizer exactly like the reference's examples/file-capture.cpp:22-64
+// (construct from Parameters, stabilize() per frame, empty Mat during warm-up),
+// plus the reassignment idiom of examples/vs.cpp:403.  Frames are a synthetic
+// moving pattern; prints "<inputs> <outputs> <flushed> <checksum>".
+#include <cstdio>
+#include <cstdlib>
+#include "video/Stabilizer.h"
+
+static cv::Mat make_frame(int w, int h, int k) {
+    cv::Mat f(h, w, CV_8UC3);
+    for (int y = 0; y < h; y++) {
+        unsigned char *p = f.ptr(y);
+        for (int x = 0; x < w; x++) {
+            int u = x + 2 * k, v = y + (k % 3);
+            unsigned char c = (unsigned char)((((u / 24) + (v / 24)) & 1) ? 200 : 50);
+            p[3 * x] = c; p[3 * x + 1] = (unsigned char)(c / 2 + ((u * 7 + v * 3) & 31)); p[3 * x + 2] = (unsigned char)(255 - c);
+        }
+    }
+    return f;
+}
+
+int main(int argc, char **argv) {
+    const int n = argc > 1 ? std::atoi(argv[1]) : 40;
+    vs::Stabilizer::Parameters stabParams;          // file-capture.cpp:22-29
+    stabParams.smoothingRadius = 20;
+    stabParams.borderType = "reflect";
+    stabParams.useCuda = true;
+    stabParams.logging = false;
+    vs::Stabilizer stab(stabParams);
+    stab = vs::Stabilizer(stabParams);               // vs.cpp:403
+    int outputs = 0, flushed = 0;
+    unsigned long long sum = 0;
+    for (int k = 0; k < n; k++) {
+        cv::Mat frame = make_frame(320, 240, k);
+        cv::Mat stabilized = stab.stabilize(frame); // file-capture.cpp:64
+        if (!stabilized.empty()) {
+            outputs++;
+            for (int y = 0; y < stabilized.rows; y += 16) sum += stabilized.ptr(y)[3 * (y % stabilized.cols)];
+        }
+    }
+    for (;;) {
+        cv::Mat f = stab.flush();
+        if (f.empty()) break;
+        flushed++;
+    }
+    std::printf("%d %d %d %llu\n", n, outputs, flushed, sum);
+    return (outputs == n - 19 && flushed == 19) ? 0 : 1;
+}

@@ -1,0 +1,57 @@
+// TEST-ONLY stand-in for <opencv2/opencv.hpp>: just enough of cv::Mat / cv::Rect /
+// cv::Size for tests/ to compile and run the vs::Stabilizer wrapper in an image
+// that has no OpenCV.  It is NOT used to build or emulate the reference, and it
+// is not part of the product (applications build against the real OpenCV).
+#ifndef MOCK_OPENCV_HPP
+#define MOCK_OPENCV_HPP
+#include <cstddef>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#define CV_8U 0
+#define CV_MAKETYPE(depth, cn) ((depth) + (((cn)-1) << 3))
+#define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
+
+namespace cv {
+struct Size { int width = 0, height = 0; Size() = default; Size(int w, int h) : width(w), height(h) {} };
+struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() = default; Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
+class Mat {
+public:
+    int rows = 0, cols = 0;
+    unsigned char *data = nullptr;
+    size_t step = 0;
+    Mat() = default;
+    Mat(int r, int c, int type) { create(r, c, type); }
+    void create(int r, int c, int type) {
+        type_ = type; rows = r; cols = c;
+        step = (size_t)c * channels();
+        buf_ = std::make_shared<std::vector<unsigned char>>(step * (size_t)r);
+        data = buf_->data();
+    }
+    int type() const { return type_; }
+    int channels() const { return (type_ >> 3) + 1; }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    Size size() const { return Size(cols, rows); }
+    Mat clone() const {
+        Mat m;
+        if (empty()) return m;
+        m.create(rows, cols, type_);
+        for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * channels());
+        return m;
+    }
+    Mat operator()(const Rect &r) const {
+        Mat m = *this;
+        m.data = data + (size_t)r.y * step + (size_t)r.x * channels();
+        m.rows = r.height; m.cols = r.width;
+        return m;
+    }
+    unsigned char *ptr(int y) { return data + (size_t)y * step; }
+    const unsigned char *ptr(int y) const { return data + (size_t)y * step; }
+private:
+    int type_ = CV_8UC3;
+    std::shared_ptr<std::vector<unsigned char>> buf_;
+};
+}  // namespace cv
+#endif

@@ -1,0 +1,50 @@
+"""world_size-2 `gloo` rehearsal of the multi-GPU plumbing bench.py uses (no GPU needed):
+stream sharding is a partition, the timed-region reduction is a MAX over ranks and
+the counter gather returns every rank's vector."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, os.path.join(%r, "video-stab_amd"))
+    from vsamd import dist
+    c = dist.Comm(backend="gloo")
+    mine = dist.streams_of_rank(c.rank, c.world, 7)
+    c.barrier()
+    mx = c.max_over_ranks(1.0 + c.rank)             # elapsed of the slowest rank
+    allc = c.gather_counters([c.rank, len(mine), 100.0 * (c.rank + 1)])
+    if c.rank == 0:
+        print(json.dumps({"world": c.world, "max": mx, "gathered": allc, "mine": mine}))
+    c.close()
+""") % ROOT
+
+
+def test_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["world"] == 2 and out["max"] == 2.0
+    assert out["gathered"] == [[0.0, 4.0, 100.0], [1.0, 3.0, 200.0]]
+    assert out["mine"] == [0, 2, 4, 6]
+
+
+def test_sharding_is_a_partition():
+    sys.path.insert(0, os.path.join(ROOT, "video-stab_amd"))
+    from vsamd import dist
+    for world in (1, 2, 4, 8):
+        for total in (1, 8, 64, 13):
+            owned = [dist.streams_of_rank(r, world, total) for r in range(world)]
+            flat = sorted(g for o in owned for g in o)
+            assert flat == list(range(total))
+            assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1

@@ -1,0 +1,70 @@
+"""Multi-GPU plumbing for the batch-of-streams mode.
+
+Video streams are independent sequential state machines, so the path shards by
+stream with NO data-path collective: global stream g lives on rank g % world
+(static).  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU
+hosts) is used only for the barrier around the timed region, the
+max-over-ranks of the elapsed time and the gather of the per-rank throughput
+counters.
+"""
+import os
+
+
+def env_world():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def streams_of_rank(rank, world, total_streams):
+    """Global stream ids owned by `rank` (round-robin, SURVEY 8e "stream s -> GPU s mod N")."""
+    return [g for g in range(total_streams) if g % world == rank]
+
+
+class Comm:
+    """Thin wrapper so single-process runs need no torch at all."""
+
+    def __init__(self, backend=None):
+        self.rank, self.local_rank, self.world = env_world()
+        self.dist = None
+        self.torch = None
+        self.device = "cpu"
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                self.device = "cuda"
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def device_sync(self):
+        if self.torch is not None and self.device == "cuda":
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, value):
+        if self.dist is None:
+            return float(value)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_counters(self, values):
+        """all_gather of a small fixed-size counter vector -> list (per rank) of lists."""
+        if self.dist is None:
+            return [list(values)]
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.device)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [[float(x) for x in o.tolist()] for o in out]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
