@@ -136,7 +136,26 @@ typedef struct vs_debug_frame {
     double  model[6];             /* refined 2x3 model (double)                */
 } vs_debug_frame;
 
+/* Flat mirror of vs::RollCorrection::Parameters (include/video/RollCorrection.h:16-38). */
+typedef struct vs_roll_params_c {
+    int32_t struct_size;
+    int32_t canny_aperture;          /* 3 (only 3 is supported)                */
+    double  scale_factor;            /* 0.25                                   */
+    double  canny_threshold_low;     /* 50                                     */
+    double  canny_threshold_high;    /* 150                                    */
+    float   hough_rho;               /* 1                                      */
+    float   hough_theta;             /* pi/180                                 */
+    int32_t hough_threshold;         /* 100                                    */
+    int32_t reserved0;
+    double  angle_filter_min;        /* -10 deg                                */
+    double  angle_filter_max;        /* +10 deg                                */
+    double  angle_smoothing_alpha;   /* 0.1                                    */
+    double  angle_decay;             /* 0.995                                  */
+    double  max_angle_change_deg;    /* 0.5                                    */
+} vs_roll_params_c;
+
 typedef struct vs_stab vs_stab;   /* opaque instance (one video stream)        */
+typedef struct vs_roll vs_roll;   /* opaque roll-correction state              */
 
 /* ---- library ------------------------------------------------------------- */
 int          vs_abi_version(void);
@@ -264,6 +283,40 @@ int vs_op_gftt(const void* d_gray, size_t stride, int w, int h, int max_corners,
 int vs_op_estimate_affine_partial2d(const float* d_from, const float* d_to, int n,
                                     double thr, int max_iters, double* d_model,
                                     uint8_t* d_inliers, int32_t* d_info, void* stream);
+
+/* ---- roll correction: vs::RollCorrection (RollCorrection.h:12-50, RollCorrection.cpp:16-155) ---- */
+/* RollCorrection::Parameters defaults, RollCorrection.h:16-38 */
+void vs_roll_params_default(vs_roll_params_c* p);
+/* The function-static sSmoothedAngle / sFirstCall (RollCorrection.cpp:13-14) become
+ * per-object state. */
+int vs_roll_create(const vs_roll_params_c* params, int device, vs_roll** out);
+void vs_roll_destroy(vs_roll* r);
+const char* vs_roll_last_error(const vs_roll* r);
+/* cv::Mat RollCorrection::autoCorrectRoll(const cv::Mat&, const Parameters&),
+ * RollCorrection.cpp:16-155.  BGR8 in, BGR8 out of the same size; synchronous. */
+int vs_roll_correct(vs_roll* r, const uint8_t* data, int w, int h, size_t stride,
+                    uint8_t* out, size_t out_stride);
+/* Same with frames in HBM; the warp is left in flight on the object's stream
+ * (vs_roll_sync to wait). */
+int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t stride,
+                        void* d_out, size_t out_stride);
+int vs_roll_sync(vs_roll* r);
+/* smoothed angle (sSmoothedAngle), the angle detected on the last frame, lines found / used */
+int vs_roll_get_state(const vs_roll* r, double* smoothed_deg, double* detected_deg,
+                      int* n_lines, int* n_used);
+/* cv::Canny(gray, edges, low, high, 3, false) - RollCorrection.cpp:54-61 (there cv::cuda) */
+int vs_op_canny(const void* d_gray, size_t stride, int w, int h, double low, double high,
+                void* d_edges, size_t edges_stride, void* stream);
+/* cv::HoughLines(edges, lines, rho, theta, threshold) - RollCorrection.cpp:66-73.
+ * d_lines: max_lines (rho,theta) float pairs in OpenCV order (votes descending),
+ * d_count: one int32.  At most 8192 peaks are ranked. */
+int vs_op_hough_lines(const void* d_edges, size_t stride, int w, int h, float rho, float theta,
+                      int threshold, float* d_lines, int max_lines, int32_t* d_count, void* stream);
+/* cv::warpAffine(src, dst, M(2x3 double, forward), dsize, INTER_LINEAR, border) -
+ * RollCorrection.cpp:146-149 (BORDER_REPLICATE there).  border: VS_BORDER_BLACK | VS_BORDER_REPLICATE */
+int vs_op_warp_affine_ex(const void* d_src, size_t src_stride, int sw, int sh, void* d_dst,
+                         size_t dst_stride, int dw, int dh, int cn, const double* M, int border,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,20 @@ void vso_stab_get_debug(const vso_stab* s, vs_debug_frame* d);
 int  vso_stab_get_debug_arrays(const vso_stab* s, float* prev_pts, float* curr_pts,
                                uint8_t* status, uint8_t* inliers, float* detected_pts,
                                uint8_t* gray, int* aw, int* ah);
+/* ---- vs::RollCorrection restated (src/RollCorrection.cpp:16-155) --------------- */
+void vso_roll_params_default(vs_roll_params_c* p);
+void vso_sobel16(const uint8_t* g, int w, int h, size_t stride, int16_t* dx, int16_t* dy);
+void vso_canny(const uint8_t* g, int w, int h, size_t stride, double low, double high, uint8_t* edges);
+int  vso_hough_lines(const uint8_t* edges, int w, int h, size_t stride, float rho, float theta, int threshold,
+                     float* out, int max_lines);
+void vso_warp_affine_d(const uint8_t* src, int w, int h, size_t sstride, int cn, uint8_t* dst, size_t dstride,
+                       const double* M, int border);
+typedef struct vso_roll vso_roll;
+vso_roll* vso_roll_create(const vs_roll_params_c* p);
+void vso_roll_destroy(vso_roll* r);
+int  vso_roll_correct(vso_roll* r, const uint8_t* data, int w, int h, size_t stride, uint8_t* out, size_t out_stride);
+void vso_roll_get(const vso_roll* r, double* smoothed, double* detected, int* n_lines, int* n_used);
+
 /* threads used by row/point-parallel stages of vso_stab_push (default 1) */
 void vso_set_threads(int n);
 void vso_params_default(vs_params_c* p);

@@ -197,9 +197,9 @@ struct WarpCoeffs {
     std::vector<int> adelta, bdelta;
 };
 
-void warp_prepare(const float* Mf, int dst_w, WarpCoeffs& c) {
+void warp_prepare(const double* Mfwd, int dst_w, WarpCoeffs& c) {
     double M[6];
-    for (int i = 0; i < 6; i++) M[i] = (double)Mf[i];
+    for (int i = 0; i < 6; i++) M[i] = Mfwd[i];
     double D = M[0] * M[4] - M[1] * M[3];
     D = D != 0 ? 1. / D : 0;
     double A11 = M[4] * D, A22 = M[0] * D;
@@ -228,7 +228,7 @@ static inline void bilinear_tab(int fx, int fy, int w[4]) {
 }
 
 void warp_rows(const uint8_t* src, int sw, int sh, size_t sstride, int cn, uint8_t* dst,
-               int dw, size_t dstride, const WarpCoeffs& c, int y0, int y1) {
+               int dw, size_t dstride, const WarpCoeffs& c, int y0, int y1, int border) {
     for (int y = y0; y < y1; y++) {
         int X0 = sat_int((c.M[1] * y + c.M[2]) * 1024) + 16;
         int Y0 = sat_int((c.M[4] * y + c.M[5]) * 1024) + 16;
@@ -239,6 +239,17 @@ void warp_rows(const uint8_t* src, int sw, int sh, size_t sstride, int cn, uint8
             int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
             int w[4];
             bilinear_tab(X & 31, Y & 31, w);
+            if (border == VS_BORDER_REPLICATE) {
+                // remapBilinear, BORDER_REPLICATE: tap coordinates are clamped into the image
+                auto clip = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+                const int sx0 = clip(sx, sw), sx1 = clip(sx + 1, sw), sy0 = clip(sy, sh), sy1 = clip(sy + 1, sh);
+                for (int k = 0; k < cn; k++) {
+                    int t = src[(size_t)sy0 * sstride + sx0 * cn + k] * w[0] + src[(size_t)sy0 * sstride + sx1 * cn + k] * w[1] +
+                            src[(size_t)sy1 * sstride + sx0 * cn + k] * w[2] + src[(size_t)sy1 * sstride + sx1 * cn + k] * w[3];
+                    d[x * cn + k] = sat_u8((t + (1 << 14)) >> 15);
+                }
+                continue;
+            }
             bool x0in = (unsigned)sx < (unsigned)sw, x1in = (unsigned)(sx + 1) < (unsigned)sw;
             bool y0in = (unsigned)sy < (unsigned)sh, y1in = (unsigned)(sy + 1) < (unsigned)sh;
             for (int k = 0; k < cn; k++) {
@@ -253,22 +264,30 @@ void warp_rows(const uint8_t* src, int sw, int sh, size_t sstride, int cn, uint8
     }
 }
 
-void warp_affine(const uint8_t* src, int w, int h, size_t sstride, int cn, uint8_t* dst,
-                 size_t dstride, const float* M, int nthreads) {
+// forward matrix in double (cv::warpAffine converts its CV_32F / CV_64F argument to double first)
+void warp_affine_d(const uint8_t* src, int sw, int sh, size_t sstride, int cn, uint8_t* dst, int dw, int dh,
+                   size_t dstride, const double* M, int border, int nthreads) {
     WarpCoeffs c;
-    warp_prepare(M, w, c);
+    warp_prepare(M, dw, c);
     if (nthreads <= 1) {
-        warp_rows(src, w, h, sstride, cn, dst, w, dstride, c, 0, h);
+        warp_rows(src, sw, sh, sstride, cn, dst, dw, dstride, c, 0, dh, border);
         return;
     }
     std::vector<std::thread> th;
-    int per = (h + nthreads - 1) / nthreads;
+    int per = (dh + nthreads - 1) / nthreads;
     for (int t = 0; t < nthreads; t++) {
-        int y0 = t * per, y1 = std::min(h, y0 + per);
+        int y0 = t * per, y1 = std::min(dh, y0 + per);
         if (y0 >= y1) break;
-        th.emplace_back([=, &c] { warp_rows(src, w, h, sstride, cn, dst, w, dstride, c, y0, y1); });
+        th.emplace_back([=, &c] { warp_rows(src, sw, sh, sstride, cn, dst, dw, dstride, c, y0, y1, border); });
     }
     for (auto& t : th) t.join();
+}
+
+void warp_affine(const uint8_t* src, int w, int h, size_t sstride, int cn, uint8_t* dst,
+                 size_t dstride, const float* M, int nthreads) {
+    double Md[6];
+    for (int i = 0; i < 6; i++) Md[i] = (double)M[i];
+    warp_affine_d(src, w, h, sstride, cn, dst, w, h, dstride, Md, VS_BORDER_BLACK, nthreads);
 }
 
 }  // namespace vso

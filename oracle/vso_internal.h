@@ -39,6 +39,14 @@ void copy_make_border(const uint8_t* src, int w, int h, size_t sstride, int cn, 
                       size_t dstride, int b, int border);
 void warp_affine(const uint8_t* src, int w, int h, size_t sstride, int cn, uint8_t* dst,
                  size_t dstride, const float* M, int nthreads);
+void warp_affine_d(const uint8_t* src, int sw, int sh, size_t sstride, int cn, uint8_t* dst, int dw, int dh,
+                   size_t dstride, const double* M, int border, int nthreads);
+void sobel16(const uint8_t* g, int w, int h, size_t stride, int16_t* dx, int16_t* dy);
+void canny(const uint8_t* g, int w, int h, size_t stride, double low, double high, uint8_t* edges);
+int hough_lines(const uint8_t* edges, int w, int h, size_t stride, float rho, float theta, int threshold,
+                std::vector<float>& lines);
+void rotation_matrix(float cx, float cy, double angle_deg, double M[6]);
+constexpr double CV_PI_D = 3.1415926535897932384626433832795;
 
 struct Gray {
     int w = 0, h = 0;

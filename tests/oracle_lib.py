@@ -64,6 +64,24 @@ class Oracle:
         lib.vso_adaptive_radius.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int]
         lib.vso_motion_intent.argtypes = [f32p, C.c_int, C.c_int]
         lib.vso_set_threads.argtypes = [C.c_int]
+        from vsamd.capi import VsRollParams
+        self.VsRollParams = VsRollParams
+        lib.vso_roll_params_default.argtypes = [C.POINTER(VsRollParams)]
+        lib.vso_roll_params_default.restype = None
+        lib.vso_sobel16.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i16p, i16p]
+        lib.vso_sobel16.restype = None
+        lib.vso_canny.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_double, u8p]
+        lib.vso_canny.restype = None
+        lib.vso_hough_lines.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float, C.c_int, f32p, C.c_int]
+        lib.vso_warp_affine_d.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_size_t, f64p, C.c_int]
+        lib.vso_warp_affine_d.restype = None
+        lib.vso_roll_create.restype = C.c_void_p
+        lib.vso_roll_create.argtypes = [C.POINTER(VsRollParams)]
+        lib.vso_roll_destroy.argtypes = [C.c_void_p]
+        lib.vso_roll_destroy.restype = None
+        lib.vso_roll_correct.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
+        lib.vso_roll_get.argtypes = [C.c_void_p, f64p, f64p, i32p, i32p]
+        lib.vso_roll_get.restype = None
 
     # ---- primitives -------------------------------------------------------
     def params(self, **kw):
@@ -204,8 +222,79 @@ class Oracle:
         t = np.ascontiguousarray(transforms, np.float32).reshape(-1, 3)
         return self.lib.vso_motion_intent(_p(t, f32p), t.shape[0], frame_index)
 
+    def sobel16(self, g):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        dx = np.empty((h, w), np.int16)
+        dy = np.empty((h, w), np.int16)
+        self.lib.vso_sobel16(_p(g, u8p), w, h, w, _p(dx, i16p), _p(dy, i16p))
+        return dx, dy
+
+    def canny(self, g, low, high):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        e = np.empty((h, w), np.uint8)
+        self.lib.vso_canny(_p(g, u8p), w, h, w, low, high, _p(e, u8p))
+        return e
+
+    def hough_lines(self, edges, rho, theta, threshold, max_lines=65536):
+        edges = np.ascontiguousarray(edges)
+        h, w = edges.shape
+        out = np.empty((max_lines, 2), np.float32)
+        n = self.lib.vso_hough_lines(_p(edges, u8p), w, h, w, rho, theta, threshold, _p(out, f32p), max_lines)
+        return out[:n].copy()
+
+    def warp_affine_d(self, img, M, border=0):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        M = np.ascontiguousarray(M, np.float64).reshape(6)
+        out = np.empty_like(img)
+        self.lib.vso_warp_affine_d(_p(img, u8p), w, h, w * cn, cn, _p(out, u8p), w * cn, _p(M, f64p), border)
+        return out
+
+    def roll_params(self, **kw):
+        p = self.VsRollParams()
+        self.lib.vso_roll_params_default(C.byref(p))
+        for k, v in kw.items():
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+        return p
+
+    def roll_correction(self, params=None):
+        return OracleRoll(self, params or self.roll_params())
+
     def stabilizer(self, params):
         return OracleStab(self, params)
+
+
+class OracleRoll:
+    """vs::RollCorrection::autoCorrectRoll restated on the CPU (oracle/vso_roll.cpp)."""
+
+    def __init__(self, o, params):
+        self.lib = o.lib
+        self.h = self.lib.vso_roll_create(C.byref(params))
+
+    def close(self):
+        if self.h:
+            self.lib.vso_roll_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def correct(self, frame):
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        out = np.empty_like(frame)
+        self.lib.vso_roll_correct(self.h, _p(frame, u8p), w, h, w * 3, _p(out, u8p), w * 3)
+        return out
+
+    def state(self):
+        s, d = C.c_double(), C.c_double()
+        n, u = C.c_int32(), C.c_int32()
+        self.lib.vso_roll_get(self.h, C.byref(s), C.byref(d), C.byref(n), C.byref(u))
+        return s.value, d.value, n.value, u.value
 
 
 class OracleStab:

@@ -1,0 +1,204 @@
+"""Roll correction: oracle known-answer tests (CPU) and HIP-vs-oracle
+parity (GPU) for Canny, HoughLines, warpAffine(BORDER_REPLICATE) and the whole
+RollCorrection::autoCorrectRoll step (RollCorrection.cpp:16-155).
+
+Bar: bit-exact edges, identical line lists (order included), identical corrected frames;
+the smoothed angle is compared bit-exactly too (same double recursion on both sides).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import roll_scene
+
+THETA = np.float32(math.pi / 180.0)
+
+
+# ---------------------------------------------------------------- oracle KATs (CPU)
+def test_sobel_on_ramp(oracle):
+    g = np.tile(np.arange(0, 64, 2, dtype=np.uint8), (16, 1))     # d/dx = 2 per pixel
+    dx, dy = oracle.sobel16(g)
+    assert (dx[:, 1:-1] == 16).all()          # (1+2+1) * (2*2)
+    assert (dx[:, 0] == 8).all() and (dx[:, -1] == 8).all()       # BORDER_REPLICATE halves it
+    assert (dy == 0).all()
+
+
+def test_canny_step_edge_single_line(oracle):
+    g = np.zeros((32, 48), np.uint8)
+    g[16:] = 200
+    e = oracle.canny(g, 50, 150)
+    rows = np.nonzero(e.any(axis=1))[0]
+    assert len(rows) == 1 and rows[0] in (15, 16)      # one-pixel-thin edge
+    assert (e[rows[0]] == 255).all()
+    assert set(np.unique(e)) <= {0, 255}
+
+
+def test_canny_hysteresis_keeps_weak_only_when_connected(oracle):
+    g = np.zeros((40, 80), np.uint8)
+    g[20:, :40] = 200          # strong step (|dy| = 800 > 150)
+    g[20:, 40:] = 25           # weak step (|dy| = 100: between the thresholds), connected to the strong one
+    h = np.zeros((40, 80), np.uint8)
+    h[20:, :] = 25             # the same weak step, nothing strong to attach to
+    e1, e2 = oracle.canny(g, 50, 150), oracle.canny(h, 50, 150)
+    assert e1[:, 45:75].any() and not e2.any()
+
+
+def test_hough_horizontal_and_vertical_lines(oracle):
+    e = np.zeros((100, 160), np.uint8)
+    e[37, :] = 255             # horizontal: theta = 90 deg, rho = 37
+    lines = oracle.hough_lines(e, 1.0, THETA, 100)
+    assert len(lines) >= 1
+    assert lines[0, 0] == 37.0 and lines[0, 1] == np.float32(90) * THETA
+    e = np.zeros((160, 100), np.uint8)
+    e[:, 22] = 255             # vertical: theta = 0, rho = 22
+    lines = oracle.hough_lines(e, 1.0, THETA, 100)
+    assert lines[0, 0] == 22.0 and lines[0, 1] == 0.0
+
+
+def test_hough_orders_by_votes(oracle):
+    e = np.zeros((120, 200), np.uint8)
+    e[30, :] = 255
+    e[80, :150] = 255
+    lines = oracle.hough_lines(e, 1.0, THETA, 100)
+    rhos = [l[0] for l in lines if l[1] == np.float32(90) * THETA]
+    assert rhos[:2] == [30.0, 80.0]
+
+
+def test_warp_replicate_border_translation(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    out = oracle.warp_affine_d(img, [1, 0, 4, 0, 1, -3], border=3)
+    assert (out[:17, 4:] == img[3:, :26]).all()
+    assert (out[:17, :4] == img[3:, :1]).all()          # left columns replicate column 0
+    assert (out[17:, 4:] == img[19:, :26]).all()        # bottom rows replicate the last row
+
+
+def test_roll_converges_to_horizon_tilt(oracle):
+    # horizon dropping to the right by atan(0.05) = 2.86 deg; the loop walks at most 0.5 deg/frame
+    # with alpha 0.1 towards the detected angle and must not overshoot it.
+    f = roll_scene.horizon_frame(640, 360, 51, texture=False)
+    r = oracle.roll_correction()
+    prev = 0.0
+    for i in range(12):
+        r.correct(f)
+        s, d, n, u = r.state()
+        assert n > 0 and u > 0
+        assert abs(d - math.degrees(math.atan(51 / 1024))) < 1.0
+        assert abs(s - prev) <= 0.5 + 1e-12 and abs(s) <= abs(d) + 1e-9 and s * d >= 0
+        prev = s
+    assert abs(prev) > 1.0
+
+
+def test_roll_decays_without_lines(oracle):
+    f = roll_scene.horizon_frame(320, 240, 40, texture=False)
+    r = oracle.roll_correction(oracle.roll_params(hough_threshold=40))
+    for _ in range(5):
+        r.correct(f)
+    s0 = r.state()[0]
+    assert s0 != 0.0
+    flat = np.full((240, 320, 3), 128, np.uint8)
+    out = r.correct(flat)
+    s1, _, n, _ = r.state()
+    assert n == 0 and s1 == s0 * 0.995
+    assert (out == 128).all()
+
+
+def test_roll_params_default_match(oracle, vs):
+    a, b = oracle.roll_params(), vs.roll_params()
+    assert bytes(a) == bytes(b)
+    assert a.scale_factor == 0.25 and a.hough_threshold == 100 and a.angle_decay == 0.995
+
+
+# ---------------------------------------------------------------- HIP parity (GPU)
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,seed", [((135, 240), 1), ((270, 480), 2), ((101, 67), 3), ((8, 8), 4)])
+def test_canny_bit_exact(gpu, oracle, shape, seed):
+    g = roll_scene.noisy_gray(shape[1], shape[0], seed)
+    for lo, hi in ((50, 150), (10, 30), (150, 50)):
+        ref = oracle.canny(g, lo, hi)
+        got = gpu.canny(g, lo, hi)
+        assert np.array_equal(ref, got)
+    assert shape[0] < 32 or oracle.canny(g, 10, 30).any()
+
+
+@pytest.mark.gpu
+def test_canny_on_rendered_frames(gpu, oracle):
+    from vsamd import synth
+    for f in synth.make_clip(synth.SEED_CONFIG1, 320, 240, 3):
+        g = oracle.analysis_gray(f, 480, 360)
+        assert np.array_equal(oracle.canny(g, 50, 150), gpu.canny(g, 50, 150))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("thr", [100, 40, 15])
+def test_hough_lines_exact(gpu, oracle, thr):
+    f = roll_scene.horizon_frame(480, 270, 37, seed=5)
+    g = oracle.bgr2gray(f)
+    e = oracle.canny(g, 50, 150)
+    ref = oracle.hough_lines(e, 1.0, THETA, thr)
+    got = gpu.hough_lines(e, 1.0, THETA, thr)
+    assert len(ref) > 0 and len(ref) < 8192
+    assert ref.shape == got.shape and np.array_equal(ref, got)
+
+
+@pytest.mark.gpu
+def test_hough_other_resolutions(gpu, oracle):
+    e = oracle.canny(roll_scene.noisy_gray(200, 150, 9), 20, 60)
+    for rho, theta, thr in ((2.0, THETA, 30), (1.0, np.float32(math.pi / 90), 25), (0.5, np.float32(math.pi / 360), 20)):
+        ref = oracle.hough_lines(e, rho, theta, thr)
+        got = gpu.hough_lines(e, rho, theta, thr)
+        assert ref.shape == got.shape and np.array_equal(ref, got)
+
+
+@pytest.mark.gpu
+def test_hough_empty_edges(gpu, oracle):
+    e = np.zeros((64, 64), np.uint8)
+    assert len(gpu.hough_lines(e, 1.0, THETA, 10)) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deg", [0.0, 0.7, -2.3, 9.5, 45.0])
+def test_warp_replicate_bit_exact(gpu, oracle, deg):
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (180, 320, 3), dtype=np.uint8)
+    a = math.radians(deg)
+    al, be = math.cos(a), math.sin(a)
+    cx, cy = 160.0, 90.0
+    M = [al, be, (1 - al) * cx - be * cy, -be, al, be * cx + (1 - al) * cy]
+    for border in (0, 3):
+        assert np.array_equal(oracle.warp_affine_d(img, M, border), gpu.warp_affine_ex(img, M, border))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,slope", [((640, 360), 51), ((1280, 720), -33), ((322, 242), 20)])
+def test_roll_correct_matches_oracle(gpu, oracle, size, slope):
+    w, h = size
+    thr = 100 if w >= 640 else 40
+    ro = oracle.roll_correction(oracle.roll_params(hough_threshold=thr))
+    rg = gpu.roll_correction(gpu.roll_params(hough_threshold=thr))
+    moved = False
+    for i in range(8):
+        f = roll_scene.horizon_frame(w, h, slope + i, seed=i, offset=i - 3)
+        a, b = ro.correct(f), rg.correct(f)
+        assert ro.state() == rg.state()
+        assert np.array_equal(a, b)
+        moved |= ro.state()[0] != 0.0
+    assert moved
+    flat = np.full((h, w, 3), 77, np.uint8)
+    assert np.array_equal(ro.correct(flat), rg.correct(flat))      # decay branch
+    assert ro.state() == rg.state()
+
+
+@pytest.mark.gpu
+def test_roll_device_entry_point(gpu, oracle):
+    from vsamd.capi import DevBuf
+    f = roll_scene.horizon_frame(640, 360, 45, seed=2)
+    ro = oracle.roll_correction()
+    rg = gpu.roll_correction()
+    d_in, d_out = DevBuf.from_array(gpu, f), DevBuf(gpu, f.nbytes)
+    for _ in range(3):
+        ref = ro.correct(f)
+        rg.correct_dev(d_in.ptr, 640, 360, 640 * 3, d_out.ptr, 640 * 3)
+        rg.sync()
+        assert np.array_equal(ref, d_out.download(f.shape, np.uint8))

@@ -1,0 +1,534 @@
+// Roll correction for gfx950: device counterpart of vs::RollCorrection::autoCorrectRoll
+// (/root/reference/src/RollCorrection.cpp:16-155).  The reference runs this stage on
+// cv::cuda (resize, cvtColor, CannyEdgeDetector, HoughLinesDetector, remap) and has no
+// CPU branch; this build follows the CPU OpenCV definitions of the same operators
+// (see oracle/vso_roll.cpp), so every intermediate is bit-comparable with the oracle:
+//
+//   resize x0.25 + BGR2GRAY (fused, k_gray.hip)
+//   sobel_kernel      3x3 Sobel, BORDER_REPLICATE -> dx,dy (int16) and L1 magnitude
+//   canny_nms_kernel  non-maximum suppression with the tan(22.5) fixed-point sectors,
+//                     double threshold -> map {0 maybe, 1 no, 2 edge}; strong edges queued
+//   canny_hyst_kernel ONE workgroup, breadth-first growth of the edge set through the
+//                     "maybe" pixels (atomicCAS on the map, frontier in a global queue)
+//   hough_accum_kernel  votes of every (edge pixel, angle) pair, float rho as cv::HoughLines
+//   hough_peaks_kernel  local maxima above the threshold -> (votes, index) keys
+//   hough_select_kernel ONE workgroup: bitonic sort (votes desc, index asc) and the
+//                     sequential angle filter / mean of RollCorrection.cpp:109-125
+//   warp_affine_kernel<3> with BORDER_REPLICATE (k_warp.hip) for the rotation.
+// The smoothed angle (EMA, clamp, decay) is host state of the vs_roll object; it needs
+// one 24-byte read-back per frame (the reference synchronises several times per frame).
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "vs_common.h"
+
+namespace vsd {
+
+int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst, size_t dstride,
+                           int dw, int dh, int cn, const double* h_Minv, int border, hipStream_t st);
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int HOUGH_CAP = 8192;      // peaks kept for the sort (cv::HoughLines has no cap)
+
+__global__ __launch_bounds__(NT) void sobel_kernel(const uint8_t* __restrict__ g, size_t stride, int w, int h,
+                                                   short2* __restrict__ dxy, int* __restrict__ mag, int mw) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
+    const uint8_t* r0 = g + (size_t)(y > 0 ? y - 1 : 0) * stride;
+    const uint8_t* r1 = g + (size_t)y * stride;
+    const uint8_t* r2 = g + (size_t)(y < h - 1 ? y + 1 : h - 1) * stride;
+    const int a = r0[xm], b = r0[x], c = r0[xp], d = r1[xm], f = r1[xp], g0 = r2[xm], h0 = r2[x], i = r2[xp];
+    const int dx = (c + 2 * f + i) - (a + 2 * d + g0);
+    const int dy = (g0 + 2 * h0 + i) - (a + 2 * b + c);
+    dxy[(size_t)y * w + x] = make_short2((short)dx, (short)dy);
+    mag[(size_t)(y + 1) * mw + x + 1] = abs(dx) + abs(dy);
+}
+
+// map/mag are framed with one pixel (map frame = 1, mag frame = 0), row pitch mw = w + 2
+__global__ __launch_bounds__(NT) void canny_nms_kernel(const short2* __restrict__ dxy, const int* __restrict__ mag,
+                                                       int w, int h, int mw, int low, int high, int* __restrict__ map,
+                                                       int* __restrict__ queue, int* __restrict__ counters) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int p = (y + 1) * mw + x + 1;
+    const int m = mag[p];
+    int out = 1;
+    if (m > low) {
+        const short2 d = dxy[(size_t)y * w + x];
+        const int xs = d.x, ys = d.y;
+        const int ax = abs(xs), ay = abs(ys) << 15;
+        const int tg22x = ax * 13573;
+        bool is_max;
+        if (ay < tg22x) {
+            is_max = m > mag[p - 1] && m >= mag[p + 1];
+        } else {
+            const int tg67x = tg22x + (ax << 16);
+            if (ay > tg67x) {
+                is_max = m > mag[p - mw] && m >= mag[p + mw];
+            } else {
+                const int s = (xs ^ ys) < 0 ? 1 : -1;
+                is_max = m > mag[p - mw - s] && m > mag[p + mw + s];
+            }
+        }
+        if (is_max) {
+            if (m > high) { out = 2; queue[atomicAdd(&counters[0], 1)] = p; }
+            else out = 0;
+        }
+    }
+    map[p] = out;
+}
+
+__global__ __launch_bounds__(1024) void canny_hyst_kernel(int* __restrict__ map, int mw, int* __restrict__ queue,
+                                                          int* __restrict__ counters) {
+    __shared__ int s_head, s_tail;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_head = 0; s_tail = counters[0]; }
+    __syncthreads();
+    while (true) {
+        const int head = s_head, tail = s_tail;
+        if (head >= tail) break;
+        __syncthreads();
+        for (int i = head + tid; i < tail; i += 1024) {
+            const int p = __hip_atomic_load(&queue[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int nb[8] = {-mw - 1, -mw, -mw + 1, -1, 1, mw - 1, mw, mw + 1};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int q = p + nb[k];
+                if (atomicCAS(&map[q], 0, 2) == 0) queue[atomicAdd(&counters[0], 1)] = q;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) { s_head = tail; s_tail = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NT) void canny_out_kernel(const int* __restrict__ map, int w, int h, int mw,
+                                                       uint8_t* __restrict__ edges, size_t estride) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    edges[(size_t)y * estride + x] = map[(y + 1) * mw + x + 1] == 2 ? 255 : 0;
+}
+
+__global__ __launch_bounds__(NT) void edge_list_kernel(const uint8_t* __restrict__ edges, size_t stride, int w, int h,
+                                                       int* __restrict__ list, int* __restrict__ counters) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    if (edges[(size_t)y * stride + x] != 0) list[atomicAdd(&counters[1], 1)] = y * w + x;
+}
+
+__global__ __launch_bounds__(NT) void hough_accum_kernel(const int* __restrict__ list, const int* __restrict__ counters,
+                                                         int w, const float* __restrict__ tabSin,
+                                                         const float* __restrict__ tabCos, int numangle, int numrho,
+                                                         int* __restrict__ accum) {
+    const int n_edges = counters[1];
+    const long long total = (long long)n_edges * numangle;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(t / numangle), n = (int)(t - (long long)e * numangle);
+        const int idx = list[e];
+        const int i = idx / w, j = idx - i * w;
+        int r = f_round((float)j * tabCos[n] + (float)i * tabSin[n]);
+        r += (numrho - 1) / 2;
+        atomicAdd(&accum[(size_t)(n + 1) * (numrho + 2) + r + 1], 1);
+    }
+}
+
+__global__ __launch_bounds__(NT) void hough_peaks_kernel(const int* __restrict__ accum, int numangle, int numrho,
+                                                         int threshold, unsigned long long* __restrict__ keys,
+                                                         int* __restrict__ counters) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (r >= numrho || n >= numangle) return;
+    const int base = (n + 1) * (numrho + 2) + r + 1;
+    const int v = accum[base];
+    if (v > threshold && v > accum[base - 1] && v >= accum[base + 1] && v > accum[base - numrho - 2] &&
+        v >= accum[base + numrho + 2]) {
+        const int pos = atomicAdd(&counters[2], 1);
+        // sort key: votes descending, then index ascending (hough_cmp_gt)
+        if (pos < HOUGH_CAP) keys[pos] = ((unsigned long long)(unsigned)v << 32) | (unsigned)(0x7FFFFFFF - base);
+        else counters[3] = 1;
+    }
+}
+
+struct RollResult {
+    double sum_deg;      // sum of the accepted angles (degrees), in cv::HoughLines order
+    int count;           // accepted lines
+    int n_lines;         // lines found
+    int overflow;
+    int pad;
+};
+
+__global__ __launch_bounds__(1024) void hough_select_kernel(unsigned long long* __restrict__ keys,
+                                                            const int* __restrict__ counters, int numrho, float rho,
+                                                            float theta, double amin, double amax,
+                                                            float* __restrict__ lines_out, int max_out,
+                                                            RollResult* __restrict__ res) {
+    __shared__ unsigned long long sk[HOUGH_CAP];
+    const int tid = threadIdx.x;
+    int n = counters[2];
+    n = n < HOUGH_CAP ? n : HOUGH_CAP;
+    int np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += 1024) sk[i] = i < n ? keys[i] : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = sk[i], b = sk[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { sk[i] = b; sk[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // lines in cv::HoughLines order; (rho, theta) as it computes them
+    const double scale = 1. / (numrho + 2);
+    for (int i = tid; i < n && i < max_out; i += 1024) {
+        const int idx = 0x7FFFFFFF - (int)(unsigned)(sk[i] & 0xFFFFFFFFu);
+        const int a = (int)floor(idx * scale) - 1;
+        const int r = idx - (a + 1) * (numrho + 2) - 1;
+        lines_out[2 * i] = ((float)r - (float)(numrho - 1) * 0.5f) * rho;
+        lines_out[2 * i + 1] = 0.f + (float)a * theta;
+    }
+    if (tid == 0) {
+        // RollCorrection.cpp:106-119: angle filter and sum, sequential in double
+        double sum = 0.0;
+        int count = 0;
+        for (int i = 0; i < n; i++) {
+            const int idx = 0x7FFFFFFF - (int)(unsigned)(sk[i] & 0xFFFFFFFFu);
+            const int a = (int)floor(idx * scale) - 1;
+            const float th = 0.f + (float)a * theta;
+            const double deg = ((double)th * 180.0 / 3.1415926535897932384626433832795) - 90.0;
+            if (deg >= amin && deg <= amax) { sum += deg; ++count; }
+        }
+        res->sum_deg = sum; res->count = count; res->n_lines = n; res->overflow = counters[3];
+    }
+}
+
+struct HoughGeom {
+    int numangle, numrho;
+};
+
+HoughGeom hough_geom(int w, int h, float rho, float theta) {
+    HoughGeom g;
+    const double PI = 3.1415926535897932384626433832795;
+    int numangle = (int)std::floor((PI - 0.0) / theta) + 1;
+    if (numangle > 1 && std::fabs(PI - (numangle - 1) * (double)theta) < (double)theta / 2) --numangle;
+    const int max_rho = w + h, min_rho = -max_rho;
+    g.numangle = numangle;
+    g.numrho = (int)lrint(((max_rho - min_rho) + 1) / rho);
+    return g;
+}
+
+}  // namespace
+
+// Device scratch of one roll-correction / Canny+Hough evaluation on a w x h gray image.
+struct RollWork {
+    int w = 0, h = 0, mw = 0;
+    float rho = 0, theta = 0;
+    HoughGeom geom{};
+    uint8_t* base = nullptr;
+    uint8_t* gray = nullptr;
+    uint8_t* edges = nullptr;
+    short2* dxy = nullptr;
+    int* mag = nullptr;
+    int* map = nullptr;
+    int* queue = nullptr;
+    int* list = nullptr;
+    int* accum = nullptr;
+    float* tabSin = nullptr;
+    float* tabCos = nullptr;
+    unsigned long long* keys = nullptr;
+    float* lines = nullptr;
+    int* counters = nullptr;
+    RollResult* res = nullptr;
+    size_t accum_bytes = 0;
+};
+
+static void roll_work_free(RollWork& k) {
+    if (k.base) (void)hipFree(k.base);
+    k = RollWork();
+}
+
+static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hipStream_t st) {
+    if (k.base && k.w == w && k.h == h && k.rho == rho && k.theta == theta) return VS_OK;
+    roll_work_free(k);
+    if (!(rho > 0) || !(theta > 0)) { set_last_error("hough: rho and theta must be positive"); return VS_ERR_INVALID_ARG; }
+    k.w = w; k.h = h; k.mw = w + 2; k.rho = rho; k.theta = theta;
+    k.geom = hough_geom(w, h, rho, theta);
+    const size_t npx = (size_t)w * h, nfr = (size_t)(w + 2) * (h + 2);
+    k.accum_bytes = (size_t)(k.geom.numangle + 2) * (k.geom.numrho + 2) * 4;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; };
+    const size_t o_gray = take(npx), o_edges = take(npx), o_dxy = take(npx * 4), o_mag = take(nfr * 4), o_map = take(nfr * 4);
+    const size_t o_queue = take(npx * 4 + 64), o_list = take(npx * 4 + 64), o_accum = take(k.accum_bytes);
+    const size_t o_sin = take((size_t)k.geom.numangle * 4), o_cos = take((size_t)k.geom.numangle * 4);
+    const size_t o_keys = take((size_t)HOUGH_CAP * 8), o_lines = take((size_t)HOUGH_CAP * 8), o_cnt = take(64), o_res = take(64);
+    VS_HIP_TRY(hipMalloc((void**)&k.base, off));
+    VS_HIP_TRY(hipMemsetAsync(k.base, 0, off, st));
+    uint8_t* b = k.base;
+    k.gray = b + o_gray; k.edges = b + o_edges; k.dxy = (short2*)(b + o_dxy); k.mag = (int*)(b + o_mag);
+    k.map = (int*)(b + o_map); k.queue = (int*)(b + o_queue); k.list = (int*)(b + o_list); k.accum = (int*)(b + o_accum);
+    k.tabSin = (float*)(b + o_sin); k.tabCos = (float*)(b + o_cos); k.keys = (unsigned long long*)(b + o_keys);
+    k.lines = (float*)(b + o_lines); k.counters = (int*)(b + o_cnt); k.res = (RollResult*)(b + o_res);
+    // map frame = 1 ("not an edge"); interior is rewritten every frame.  mag frame stays 0.
+    std::vector<int> frame(nfr, 1);
+    VS_HIP_TRY(hipMemcpyAsync(k.map, frame.data(), nfr * 4, hipMemcpyHostToDevice, st));
+    // createTrigTable: float angle accumulation, sin/cos in double (host libm, as the oracle)
+    std::vector<float> ts(k.geom.numangle), tc(k.geom.numangle);
+    const float irho = 1 / rho;
+    float ang = 0.f;
+    for (int n = 0; n < k.geom.numangle; ang += theta, n++) {
+        ts[n] = (float)(std::sin((double)ang) * irho);
+        tc[n] = (float)(std::cos((double)ang) * irho);
+    }
+    VS_HIP_TRY(hipMemcpyAsync(k.tabSin, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, st));
+    VS_HIP_TRY(hipMemcpyAsync(k.tabCos, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, st));
+    VS_HIP_TRY(hipStreamSynchronize(st));
+    return VS_OK;
+}
+
+// cv::Canny(gray, edges, low, high, 3, false) on device buffers
+static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double low_t, double high_t, uint8_t* d_edges,
+                     size_t estride, hipStream_t st) {
+    if (low_t > high_t) std::swap(low_t, high_t);
+    const int low = (int)std::floor(low_t), high = (int)std::floor(high_t);
+    const int w = k.w, h = k.h;
+    dim3 grid((w + NT - 1) / NT, h);
+    VS_HIP_TRY(hipMemsetAsync(k.counters, 0, 64, st));
+    hipLaunchKernelGGL(sobel_kernel, grid, dim3(NT), 0, st, d_gray, stride, w, h, k.dxy, k.mag, k.mw);
+    hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.map, k.queue, k.counters);
+    hipLaunchKernelGGL(canny_hyst_kernel, dim3(1), dim3(1024), 0, st, k.map, k.mw, k.queue, k.counters);
+    hipLaunchKernelGGL(canny_out_kernel, grid, dim3(NT), 0, st, k.map, w, h, k.mw, d_edges, estride);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// cv::HoughLines(edges, lines, rho, theta, threshold) + the angle statistics of the roll stage
+static int run_hough(RollWork& k, const uint8_t* d_edges, size_t estride, int threshold, double amin, double amax,
+                     hipStream_t st) {
+    const int w = k.w, h = k.h;
+    dim3 grid((w + NT - 1) / NT, h);
+    VS_HIP_TRY(hipMemsetAsync(k.counters + 1, 0, 60, st));
+    VS_HIP_TRY(hipMemsetAsync(k.accum, 0, k.accum_bytes, st));
+    hipLaunchKernelGGL(edge_list_kernel, grid, dim3(NT), 0, st, d_edges, estride, w, h, k.list, k.counters);
+    hipLaunchKernelGGL(hough_accum_kernel, dim3(2048), dim3(NT), 0, st, k.list, k.counters, w, k.tabSin, k.tabCos,
+                       k.geom.numangle, k.geom.numrho, k.accum);
+    dim3 g2((k.geom.numrho + NT - 1) / NT, k.geom.numangle);
+    hipLaunchKernelGGL(hough_peaks_kernel, g2, dim3(NT), 0, st, k.accum, k.geom.numangle, k.geom.numrho, threshold, k.keys, k.counters);
+    hipLaunchKernelGGL(hough_select_kernel, dim3(1), dim3(1024), 0, st, k.keys, k.counters, k.geom.numrho, k.rho, k.theta,
+                       amin, amax, k.lines, HOUGH_CAP, k.res);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+}  // namespace vsd
+
+using namespace vsd;
+
+struct vs_roll {
+    vs_roll_params_c p;
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    RollWork wk;
+    uint8_t* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    size_t io_bytes = 0;
+    bool first = true;
+    double smoothed = 0.0;       // sSmoothedAngle (RollCorrection.cpp:14)
+    double last_detected = 0.0;
+    int last_lines = 0, last_used = 0;
+};
+
+namespace {
+thread_local RollWork g_op_work;   // scratch of the stand-alone vs_op_canny / vs_op_hough_lines
+}
+
+extern "C" {
+
+void vs_roll_params_default(vs_roll_params_c* p) {   // RollCorrection.h:16-38
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->struct_size = (int32_t)sizeof *p;
+    p->scale_factor = 0.25;
+    p->canny_threshold_low = 50.0;
+    p->canny_threshold_high = 150.0;
+    p->canny_aperture = 3;
+    p->hough_rho = 1.0f;
+    p->hough_theta = (float)(3.1415926535897932384626433832795 / 180.0f);
+    p->hough_threshold = 100;
+    p->angle_filter_min = -10.0;
+    p->angle_filter_max = 10.0;
+    p->angle_smoothing_alpha = 0.1;
+    p->angle_decay = 0.995;
+    p->max_angle_change_deg = 0.5;
+}
+
+int vs_op_canny(const void* d_gray, size_t stride, int w, int h, double low, double high, void* d_edges,
+                size_t edges_stride, void* stream) {
+    VS_TRY(ensure_device());
+    if (!d_gray || !d_edges || w <= 0 || h <= 0 || h > 65535) { set_last_error("canny: invalid argument"); return VS_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    VS_TRY(roll_work_alloc(g_op_work, w, h, 1.f, (float)(3.1415926535897932384626433832795 / 180.0f), st));
+    return run_canny(g_op_work, (const uint8_t*)d_gray, stride, low, high, (uint8_t*)d_edges, edges_stride, st);
+}
+
+int vs_op_hough_lines(const void* d_edges, size_t stride, int w, int h, float rho, float theta, int threshold,
+                      float* d_lines, int max_lines, int32_t* d_count, void* stream) {
+    VS_TRY(ensure_device());
+    if (!d_edges || !d_lines || !d_count || w <= 0 || h <= 0 || h > 65535 || max_lines <= 0) {
+        set_last_error("hough_lines: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    VS_TRY(roll_work_alloc(g_op_work, w, h, rho, theta, st));
+    VS_TRY(run_hough(g_op_work, (const uint8_t*)d_edges, stride, threshold, -1e30, 1e30, st));
+    VS_HIP_TRY(hipStreamSynchronize(st));
+    RollResult r;
+    VS_HIP_TRY(hipMemcpy(&r, g_op_work.res, sizeof r, hipMemcpyDeviceToHost));
+    const int n = r.n_lines < max_lines ? r.n_lines : max_lines;
+    if (n > 0) VS_HIP_TRY(hipMemcpy(d_lines, g_op_work.lines, (size_t)n * 8, hipMemcpyDeviceToDevice));
+    VS_HIP_TRY(hipMemcpy(d_count, &n, 4, hipMemcpyHostToDevice));
+    return VS_OK;
+}
+
+int vs_op_warp_affine_ex(const void* d_src, size_t src_stride, int sw, int sh, void* d_dst, size_t dst_stride, int dw,
+                         int dh, int cn, const double* M, int border, void* stream) {
+    VS_TRY(ensure_device());
+    if (!M) return VS_ERR_INVALID_ARG;
+    // cv::warpAffine: the forward matrix is inverted in double
+    double Mi[6];
+    {
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        const double A11 = M[4] * D, A22 = M[0] * D;
+        Mi[0] = A11; Mi[1] = M[1] * -D; Mi[3] = M[3] * -D; Mi[4] = A22;
+        Mi[2] = -Mi[0] * M[2] - Mi[1] * M[5];
+        Mi[5] = -Mi[3] * M[2] - Mi[4] * M[5];
+    }
+    return launch_warp_affine_inv((const uint8_t*)d_src, src_stride, sw, sh, (uint8_t*)d_dst, dst_stride, dw, dh, cn, Mi,
+                                  border, (hipStream_t)stream);
+}
+
+int vs_roll_create(const vs_roll_params_c* params, int device, vs_roll** out) {
+    if (!out) return VS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!params || params->struct_size != (int32_t)sizeof(vs_roll_params_c)) { set_last_error("roll params: struct_size mismatch"); return VS_ERR_INVALID_ARG; }
+    if (params->canny_aperture != 3) { set_last_error("roll: only cannyAperture 3 is supported"); return VS_ERR_UNSUPPORTED; }
+    VS_TRY(ensure_device());
+    VS_HIP_TRY(hipSetDevice(device));
+    vs_roll* r = new (std::nothrow) vs_roll();
+    if (!r) return VS_ERR_HIP;
+    r->p = *params;
+    r->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); delete r; return VS_ERR_HIP; }
+    *out = r;
+    return VS_OK;
+}
+
+void vs_roll_destroy(vs_roll* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->st) (void)hipStreamSynchronize(r->st);
+    roll_work_free(r->wk);
+    if (r->d_in) (void)hipFree(r->d_in);
+    if (r->d_out) (void)hipFree(r->d_out);
+    if (r->st) (void)hipStreamDestroy(r->st);
+    delete r;
+}
+
+const char* vs_roll_last_error(const vs_roll* r) { return r ? r->err.c_str() : ""; }
+
+int vs_roll_get_state(const vs_roll* r, double* smoothed_deg, double* detected_deg, int* n_lines, int* n_used) {
+    if (!r) return VS_ERR_INVALID_ARG;
+    if (smoothed_deg) *smoothed_deg = r->smoothed;
+    if (detected_deg) *detected_deg = r->last_detected;
+    if (n_lines) *n_lines = r->last_lines;
+    if (n_used) *n_used = r->last_used;
+    return VS_OK;
+}
+
+#define R_HIP(r, expr)                                                             \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) { (r)->err = std::string(#expr) + ": " + hipGetErrorString(_e); set_last_error((r)->err); return VS_ERR_HIP; } \
+    } while (0)
+#define R_TRY(r, expr)                                                             \
+    do { int _s = (expr); if (_s != VS_OK) { (r)->err = get_last_error(); return _s; } } while (0)
+
+// autoCorrectRoll on device buffers (BGR8 in, BGR8 out, same size)
+int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t stride, void* d_out, size_t out_stride) {
+    if (!r || !d_data || !d_out || w <= 0 || h <= 0 || stride < (size_t)w * 3 || out_stride < (size_t)w * 3) return VS_ERR_INVALID_ARG;
+    R_HIP(r, hipSetDevice(r->device));
+    const vs_roll_params_c& p = r->p;
+    if (r->first) { r->first = false; r->smoothed = 0.0; }                                       // :24-27
+    int sw = (int)(w * p.scale_factor), sh = (int)(h * p.scale_factor);                         // :35-38
+    if (!(sw > 0 && sh > 0)) { sw = w; sh = h; }                                                 // :40-45
+    R_TRY(r, roll_work_alloc(r->wk, sw, sh, p.hough_rho, p.hough_theta, r->st));
+    RollWork& k = r->wk;
+    // resize + BGR2GRAY (:41,:51), Canny (:54-61), HoughLines (:66-73), angle statistics (:106-119)
+    R_TRY(r, launch_resize_gray((const uint8_t*)d_data, stride, w, h, VS_FMT_BGR8, k.gray, sw, sw, sh, r->st));
+    R_TRY(r, run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, k.edges, sw, r->st));
+    R_TRY(r, run_hough(k, k.edges, sw, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, r->st));
+    RollResult res;
+    R_HIP(r, hipMemcpyAsync(&res, k.res, sizeof res, hipMemcpyDeviceToHost, r->st));
+    R_HIP(r, hipStreamSynchronize(r->st));
+    r->last_lines = res.n_lines; r->last_used = res.count; r->last_detected = 0.0;
+    if (res.n_lines == 0 || res.count == 0) {
+        r->smoothed *= p.angle_decay;                                                             // :76-77,:122-123
+    } else {
+        const double detected = res.sum_deg / res.count;                                          // :125-135
+        r->last_detected = detected;
+        double na = p.angle_smoothing_alpha * detected + (1.0 - p.angle_smoothing_alpha) * r->smoothed;
+        double diff = na - r->smoothed;
+        if (std::fabs(diff) > p.max_angle_change_deg && p.max_angle_change_deg > 0.0) {
+            diff = (diff > 0) ? p.max_angle_change_deg : -p.max_angle_change_deg;
+            na = r->smoothed + diff;
+        }
+        r->smoothed = na;
+    }
+    // cv::getRotationMatrix2D(center, angle, 1.0) (:141-144)
+    const float cx = w / 2.0f, cy = h / 2.0f;
+    const double a = r->smoothed * 3.1415926535897932384626433832795 / 180;
+    const double alpha = std::cos(a), beta = std::sin(a);
+    const double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
+    return vs_op_warp_affine_ex(d_data, stride, w, h, d_out, out_stride, w, h, 3, M, VS_BORDER_REPLICATE, r->st);   // :146-149
+}
+
+int vs_roll_sync(vs_roll* r) {
+    if (!r) return VS_ERR_INVALID_ARG;
+    R_HIP(r, hipSetDevice(r->device));
+    R_HIP(r, hipStreamSynchronize(r->st));
+    return VS_OK;
+}
+
+int vs_roll_correct(vs_roll* r, const uint8_t* data, int w, int h, size_t stride, uint8_t* out, size_t out_stride) {
+    if (!r || !data || !out || w <= 0 || h <= 0) return VS_ERR_INVALID_ARG;
+    R_HIP(r, hipSetDevice(r->device));
+    const size_t row = (size_t)w * 3, bytes = row * h;
+    if (r->io_bytes < bytes) {
+        if (r->d_in) (void)hipFree(r->d_in);
+        if (r->d_out) (void)hipFree(r->d_out);
+        r->d_in = r->d_out = nullptr;
+        R_HIP(r, hipMalloc((void**)&r->d_in, bytes));
+        R_HIP(r, hipMalloc((void**)&r->d_out, bytes));
+        r->io_bytes = bytes;
+    }
+    R_HIP(r, hipMemcpy2DAsync(r->d_in, row, data, stride, row, h, hipMemcpyHostToDevice, r->st));
+    int rc = vs_roll_correct_dev(r, r->d_in, w, h, row, r->d_out, row);
+    if (rc != VS_OK) return rc;
+    R_HIP(r, hipMemcpy2DAsync(out, out_stride, r->d_out, row, row, h, hipMemcpyDeviceToHost, r->st));
+    R_HIP(r, hipStreamSynchronize(r->st));
+    return VS_OK;
+}
+
+}  // extern "C"

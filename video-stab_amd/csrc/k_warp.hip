@@ -45,12 +45,18 @@ struct WarpArgs {
     int src_aligned, dst_aligned;
     const double* Minv_dev;      // batch*6 doubles on the device (inverse maps), or nullptr
     double Minv_val[MAXB * 6];   // used when Minv_dev == nullptr
+    int border;                  // VS_BORDER_BLACK (constant 0) or VS_BORDER_REPLICATE
 };
 
+// One source pixel as a dword; outside the image: 0 (BORDER_CONSTANT) or the nearest
+// edge pixel (BORDER_REPLICATE, remapBilinear's clip()).
 template <int CN>
 __device__ __forceinline__ uint32_t load_px_checked(const uint8_t* src, size_t sstride, int sw,
-                                                    int sh, int sx, int sy) {
-    if ((unsigned)sx >= (unsigned)sw || (unsigned)sy >= (unsigned)sh) return 0u;
+                                                    int sh, int sx, int sy, int border = VS_BORDER_BLACK) {
+    if (border == VS_BORDER_REPLICATE) {
+        sx = sx < 0 ? 0 : (sx >= sw ? sw - 1 : sx);
+        sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+    } else if ((unsigned)sx >= (unsigned)sw || (unsigned)sy >= (unsigned)sh) return 0u;
     const uint8_t* p = src + (size_t)sy * sstride + (size_t)sx * CN;
     uint32_t v = p[0];
     if (CN > 1) v |= (uint32_t)p[1] << 8;
@@ -95,8 +101,8 @@ struct __attribute__((aligned(4))) U3 { uint32_t a, b, c; };
 template <int CN>
 __device__ __forceinline__ uint4 stage_group(const WarpArgs& a, const uint8_t* __restrict__ src, int sx, int sy) {
     uint4 px = make_uint4(0u, 0u, 0u, 0u);
-    if ((unsigned)sy < (unsigned)a.sh) {
-        if (a.src_aligned && sx >= 0 && sx + 3 < a.sw) {
+    if ((unsigned)sy < (unsigned)a.sh || a.border == VS_BORDER_REPLICATE) {
+        if (a.src_aligned && sx >= 0 && sx + 3 < a.sw && (unsigned)sy < (unsigned)a.sh) {
             const uint8_t* p = src + (size_t)sy * a.sstride + (size_t)sx * CN;
             if (CN == 3) {
                 const U3 d = *reinterpret_cast<const U3*>(p);
@@ -112,10 +118,10 @@ __device__ __forceinline__ uint4 stage_group(const WarpArgs& a, const uint8_t* _
                 px.x = d.x & 0xFFFFu; px.y = d.x >> 16; px.z = d.y & 0xFFFFu; px.w = d.y >> 16;
             }
         } else {
-            px.x = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy);
-            px.y = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy);
-            px.z = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 2, sy);
-            px.w = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 3, sy);
+            px.x = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy, a.border);
+            px.y = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy, a.border);
+            px.z = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 2, sy, a.border);
+            px.w = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 3, sy, a.border);
         }
     }
     return px;
@@ -150,10 +156,10 @@ __device__ __forceinline__ void emit_rows(const WarpArgs& a, const uint8_t* __re
                 p00[i] = tile[idx]; p01[i] = tile[idx + 1];
                 p10[i] = tile[idx + bw]; p11[i] = tile[idx + bw + 1];
             } else {
-                p00[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy);
-                p01[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy);
-                p10[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy + 1);
-                p11[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy + 1);
+                p00[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy, a.border);
+                p01[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy, a.border);
+                p10[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx, sy + 1, a.border);
+                p11[i] = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, sx + 1, sy + 1, a.border);
             }
         }
 #pragma unroll
@@ -299,6 +305,7 @@ void fill_common(WarpArgs& a, const uint8_t* d_src, size_t sstride, size_t sfram
     a.src = d_src; a.dst = d_dst;
     a.sstride = sstride; a.sframe = sframe; a.dstride = dstride; a.dframe = dframe;
     a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;
+    a.border = VS_BORDER_BLACK;
     const int galign = cn == 2 ? 8 : 4;
     a.src_aligned = ((uintptr_t)d_src % galign == 0) && (sstride % galign == 0) && (sframe % galign == 0);
     a.dst_aligned = ((uintptr_t)d_dst % galign == 0) && (dstride % galign == 0) && (dframe % galign == 0);
@@ -356,6 +363,28 @@ int launch_warp_affine_hostM(const uint8_t* d_src, size_t sstride, size_t sframe
         else launch_one<2>(a, grid, st);
         VS_HIP_TRY(hipGetLastError());
     }
+    return VS_OK;
+}
+
+// One frame, inverse map given on the host in double, selectable border: used by the
+// roll-correction rotate (cv::warpAffine(..., BORDER_REPLICATE)) and AutoZoomCrop's scale.
+int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst, size_t dstride,
+                           int dw, int dh, int cn, const double* h_Minv, int border, hipStream_t st) {
+    if (bad_args(d_src, d_dst, h_Minv, sstride, sw, sh, dstride, dw, dh, cn, 1) ||
+        (border != VS_BORDER_BLACK && border != VS_BORDER_REPLICATE)) {
+        set_last_error("warp_affine: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    WarpArgs a;
+    fill_common(a, d_src, sstride, 0, sw, sh, d_dst, dstride, 0, dw, dh, cn);
+    a.Minv_dev = nullptr;
+    a.border = border;
+    for (int i = 0; i < MAXB * 6; i++) a.Minv_val[i] = i < 6 ? h_Minv[i] : 0.;
+    dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, 1);
+    if (cn == 3) launch_one<3>(a, grid, st);
+    else if (cn == 1) launch_one<1>(a, grid, st);
+    else launch_one<2>(a, grid, st);
+    VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
 

@@ -59,6 +59,16 @@ class VsDebugFrame(C.Structure):
     ]
 
 
+class VsRollParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("canny_aperture", C.c_int32), ("scale_factor", C.c_double),
+        ("canny_threshold_low", C.c_double), ("canny_threshold_high", C.c_double),
+        ("hough_rho", C.c_float), ("hough_theta", C.c_float), ("hough_threshold", C.c_int32),
+        ("reserved0", C.c_int32), ("angle_filter_min", C.c_double), ("angle_filter_max", C.c_double),
+        ("angle_smoothing_alpha", C.c_double), ("angle_decay", C.c_double), ("max_angle_change_deg", C.c_double),
+    ]
+
+
 class VsError(RuntimeError):
     pass
 
@@ -160,6 +170,22 @@ class VsLib:
         L.vs_op_gftt.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                  vp, vp, vp, vp]
         L.vs_op_estimate_affine_partial2d.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
+        L.vs_roll_params_default.argtypes = [C.POINTER(VsRollParams)]
+        L.vs_roll_params_default.restype = None
+        L.vs_roll_create.argtypes = [C.POINTER(VsRollParams), C.c_int, C.POINTER(vp)]
+        L.vs_roll_destroy.argtypes = [vp]
+        L.vs_roll_destroy.restype = None
+        L.vs_roll_last_error.argtypes = [vp]
+        L.vs_roll_last_error.restype = C.c_char_p
+        L.vs_roll_correct.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
+        L.vs_roll_correct_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
+        L.vs_roll_sync.argtypes = [vp]
+        L.vs_roll_get_state.argtypes = [vp, f64p, f64p, i32p, i32p]
+        L.vs_op_canny.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.c_size_t, vp]
+        L.vs_op_hough_lines.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp,
+                                        C.c_int, vp, vp]
+        L.vs_op_warp_affine_ex.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_int,
+                                           C.c_int, f64p, C.c_int, vp]
 
     # ---- helpers ----------------------------------------------------------
     def check(self, status, inst=None):
@@ -292,8 +318,100 @@ class VsLib:
         info = d_info.download((4,), np.int32)
         return (int(info[0]), d_model.download((6,), np.float64), d_inl.download((max(n, 1),), np.uint8)[:n], info)
 
+    def canny(self, g, low, high):
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        d_in = DevBuf.from_array(self, g)
+        d_out = DevBuf(self, w * h)
+        self.check(self.lib.vs_op_canny(d_in.ptr, w, w, h, low, high, d_out.ptr, w, None))
+        self.sync()
+        return d_out.download((h, w), np.uint8)
+
+    def hough_lines(self, edges, rho, theta, threshold, max_lines=8192):
+        edges = np.ascontiguousarray(edges)
+        h, w = edges.shape
+        d_in = DevBuf.from_array(self, edges)
+        d_lines = DevBuf(self, max_lines * 8)
+        d_cnt = DevBuf(self, 16)
+        self.check(self.lib.vs_op_hough_lines(d_in.ptr, w, w, h, rho, theta, threshold, d_lines.ptr, max_lines,
+                                              d_cnt.ptr, None))
+        self.sync()
+        n = int(d_cnt.download((1,), np.int32)[0])
+        return d_lines.download((max_lines, 2), np.float32)[:n].copy()
+
+    def warp_affine_ex(self, img, M, border=BORDER_BLACK, dsize=None):
+        """cv::warpAffine with a double 2x3 forward matrix and a border mode."""
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        dw, dh = dsize if dsize else (w, h)
+        M = np.ascontiguousarray(M, np.float64).reshape(6)
+        d_in = DevBuf.from_array(self, img)
+        d_out = DevBuf(self, dw * dh * cn)
+        self.check(self.lib.vs_op_warp_affine_ex(d_in.ptr, w * cn, w, h, d_out.ptr, dw * cn, dw, dh, cn,
+                                                 _p(M, f64p), border, None))
+        self.sync()
+        return d_out.download((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+
+    def roll_params(self, **kw):
+        p = VsRollParams()
+        self.lib.vs_roll_params_default(C.byref(p))
+        for k, v in kw.items():
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+        return p
+
+    def roll_correction(self, params=None, device=0):
+        return RollCorrection(self, params or self.roll_params(), device)
+
     def stabilizer(self, params, device=0):
         return Stabilizer(self, params, device)
+
+
+class RollCorrection:
+    """C-ABI mirror of vs::RollCorrection::autoCorrectRoll (RollCorrection.cpp:16-155)."""
+
+    def __init__(self, vs, params, device=0):
+        self.vs = vs
+        self.lib = vs.lib
+        h = C.c_void_p()
+        vs.check(self.lib.vs_roll_create(C.byref(params), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.vs_roll_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status):
+        if status != 0:
+            raise VsError("%s: %s" % (self.lib.vs_status_string(status).decode(),
+                                      (self.lib.vs_roll_last_error(self.h) or b"").decode()))
+
+    def correct(self, frame):
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        out = np.empty_like(frame)
+        self._check(self.lib.vs_roll_correct(self.h, _p(frame, u8p), w, h, w * 3, _p(out, u8p), w * 3))
+        return out
+
+    def correct_dev(self, d_in, w, h, stride, d_out, out_stride):
+        self._check(self.lib.vs_roll_correct_dev(self.h, d_in, w, h, stride, d_out, out_stride))
+
+    def sync(self):
+        self._check(self.lib.vs_roll_sync(self.h))
+
+    def state(self):
+        s, d = C.c_double(), C.c_double()
+        n, u = C.c_int32(), C.c_int32()
+        self._check(self.lib.vs_roll_get_state(self.h, C.byref(s), C.byref(d), C.byref(n), C.byref(u)))
+        return s.value, d.value, n.value, u.value
 
 
 class Stabilizer:
