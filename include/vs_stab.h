@@ -292,6 +292,9 @@ void vs_roll_params_default(vs_roll_params_c* p);
 int vs_roll_create(const vs_roll_params_c* params, int device, vs_roll** out);
 void vs_roll_destroy(vs_roll* r);
 const char* vs_roll_last_error(const vs_roll* r);
+/* Parameters travel with every autoCorrectRoll call while the smoothed angle persists
+ * (RollCorrection.cpp:16-19): replaces the parameters, keeps the state. */
+int vs_roll_set_params(vs_roll* r, const vs_roll_params_c* params);
 /* cv::Mat RollCorrection::autoCorrectRoll(const cv::Mat&, const Parameters&),
  * RollCorrection.cpp:16-155.  BGR8 in, BGR8 out of the same size; synchronous. */
 int vs_roll_correct(vs_roll* r, const uint8_t* data, int w, int h, size_t stride,
@@ -317,6 +320,36 @@ int vs_op_hough_lines(const void* d_edges, size_t stride, int w, int h, float rh
 int vs_op_warp_affine_ex(const void* d_src, size_t src_stride, int sw, int sh, void* d_dst,
                          size_t dst_stride, int dw, int dh, int cn, const double* M, int border,
                          void* stream);
+
+/* ---- auto zoom/crop: vs::AutoZoomCrop (AutoZoomCrop.h:7-17, AutoZoomCrop.cpp:102-283) ---- */
+typedef struct vs_azc vs_azc;
+int vs_azc_create(int device, vs_azc** out);
+void vs_azc_destroy(vs_azc* a);
+const char* vs_azc_last_error(const vs_azc* a);
+/* cv::Mat AutoZoomCrop::autoZoomCrop(const cv::Mat& corrected, double marginPercent)
+ * (marginPercent is ignored by the reference, AutoZoomCrop.cpp:102).  BGR8 (cn 3) or gray
+ * (cn 1).  `out` must hold max(w*h, 640*360)*cn bytes and receives packed rows; the
+ * result is 640x360, or the unchanged w x h frame on the reference's fall-back paths
+ * (no contour :149-152, empty crop :238-249).  Synchronous. */
+int vs_azc_apply(vs_azc* a, const uint8_t* data, int w, int h, size_t stride, int cn,
+                 uint8_t* out, int* out_w, int* out_h);
+/* Same with the frame in HBM; out_stride >= max(w,640)*cn.  The scaled crop is left in
+ * flight on the object's stream (vs_azc_sync). */
+int vs_azc_apply_dev(vs_azc* a, const void* d_data, int w, int h, size_t stride, int cn,
+                     void* d_out, size_t out_stride, int* out_w, int* out_h);
+int vs_azc_sync(vs_azc* a);
+/* info8 = {n_contours, contour_points, crop_x, crop_y, crop_w, crop_h, iterations, cropped} */
+int vs_azc_get_info(const vs_azc* a, int32_t* info8);
+/* cvtColor + threshold(gray,1,255,BINARY) + morphologyEx(MORPH_CLOSE, 5x5 ellipse) -
+ * AutoZoomCrop.cpp:111-139 (there cv::cuda) */
+int vs_op_content_mask(const void* d_src, size_t stride, int w, int h, int cn, void* d_mask,
+                       size_t mask_stride, void* stream);
+/* Host part of the stage: findContours(EXTERNAL, SIMPLE) -> largest contour -> filled mask ->
+ * interior rectangle -> aspect fix (AutoZoomCrop.cpp:141-228) on a HOST mask (the reference
+ * also runs this on the CPU, :141-147).  filled_out (optional, w*h bytes) receives the
+ * drawContours(FILLED) mask.  Needs no device. */
+int vs_azc_crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, int32_t* info8,
+                          uint8_t* filled_out);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,21 @@ void vso_roll_destroy(vso_roll* r);
 int  vso_roll_correct(vso_roll* r, const uint8_t* data, int w, int h, size_t stride, uint8_t* out, size_t out_stride);
 void vso_roll_get(const vso_roll* r, double* smoothed, double* detected, int* n_lines, int* n_used);
 
+/* ---- vs::AutoZoomCrop restated (src/AutoZoomCrop.cpp:10-283) ------------------- */
+/* gray -> threshold(>1) -> MORPH_CLOSE 5x5 ellipse  (:111-139) */
+void vso_content_mask(const uint8_t* src, int w, int h, size_t stride, int cn, uint8_t* mask);
+/* cv::findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) (:146-147); flattened output */
+int  vso_find_contours(const uint8_t* mask, int w, int h, size_t stride, int32_t* counts, int max_contours,
+                       int32_t* xy, int max_points);
+/* cv::drawContours(..., FILLED) of one contour (:167-168) */
+void vso_fill_contour(const int32_t* xy, int n, int w, int h, uint8_t* mask);
+/* contours -> largest -> interior rectangle -> aspect fix (:141-228);
+ * info = {n_contours, contour_points, x, y, w, h, iterations, valid} */
+void vso_azc_crop_rect(const uint8_t* content_mask, int w, int h, int32_t* info);
+int  vso_azc_apply(const uint8_t* src, int w, int h, size_t stride, int cn, uint8_t* out, int32_t* out_w,
+                   int32_t* out_h, int32_t* info);
+
+
 /* threads used by row/point-parallel stages of vso_stab_push (default 1) */
 void vso_set_threads(int n);
 void vso_params_default(vs_params_c* p);

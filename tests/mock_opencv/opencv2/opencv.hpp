@@ -13,6 +13,7 @@
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn)-1) << 3))
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
 #define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
+#define CV_PI 3.1415926535897932384626433832795
 
 namespace cv {
 struct Size { int width = 0, height = 0; Size() = default; Size(int w, int h) : width(w), height(h) {} };

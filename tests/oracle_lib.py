@@ -75,6 +75,14 @@ class Oracle:
         lib.vso_hough_lines.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float, C.c_int, f32p, C.c_int]
         lib.vso_warp_affine_d.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_size_t, f64p, C.c_int]
         lib.vso_warp_affine_d.restype = None
+        lib.vso_content_mask.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p]
+        lib.vso_content_mask.restype = None
+        lib.vso_find_contours.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i32p, C.c_int, i32p, C.c_int]
+        lib.vso_fill_contour.argtypes = [i32p, C.c_int, C.c_int, C.c_int, u8p]
+        lib.vso_fill_contour.restype = None
+        lib.vso_azc_crop_rect.argtypes = [u8p, C.c_int, C.c_int, i32p]
+        lib.vso_azc_crop_rect.restype = None
+        lib.vso_azc_apply.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, i32p, i32p, i32p]
         lib.vso_roll_create.restype = C.c_void_p
         lib.vso_roll_create.argtypes = [C.POINTER(VsRollParams)]
         lib.vso_roll_destroy.argtypes = [C.c_void_p]
@@ -252,6 +260,52 @@ class Oracle:
         out = np.empty_like(img)
         self.lib.vso_warp_affine_d(_p(img, u8p), w, h, w * cn, cn, _p(out, u8p), w * cn, _p(M, f64p), border)
         return out
+
+    def content_mask(self, img):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else 3
+        m = np.empty((h, w), np.uint8)
+        self.lib.vso_content_mask(_p(img, u8p), w, h, w * cn, cn, _p(m, u8p))
+        return m
+
+    def find_contours(self, mask):
+        """cv::findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) -> list of (n,2) int arrays."""
+        mask = np.ascontiguousarray(mask)
+        h, w = mask.shape
+        counts = np.zeros(w * h // 2 + 4, np.int32)
+        xy = np.zeros((2 * w * h + 16, 2), np.int32)
+        n = self.lib.vso_find_contours(_p(mask, u8p), w, h, w, _p(counts, i32p), len(counts), _p(xy, i32p), len(xy))
+        assert n >= 0
+        out, k = [], 0
+        for i in range(n):
+            out.append(xy[k:k + counts[i]].copy())
+            k += counts[i]
+        return out
+
+    def fill_contour(self, pts, w, h):
+        pts = np.ascontiguousarray(pts, np.int32).reshape(-1, 2)
+        m = np.empty((h, w), np.uint8)
+        self.lib.vso_fill_contour(_p(pts, i32p), len(pts), w, h, _p(m, u8p))
+        return m
+
+    def azc_crop_rect(self, cmask):
+        cmask = np.ascontiguousarray(cmask)
+        h, w = cmask.shape
+        info = np.zeros(8, np.int32)
+        self.lib.vso_azc_crop_rect(_p(cmask, u8p), w, h, _p(info, i32p))
+        return info
+
+    def auto_zoom_crop(self, frame):
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        cn = 1 if frame.ndim == 2 else 3
+        buf = np.empty(max(w * h, 640 * 360) * cn, np.uint8)
+        ow, oh = C.c_int32(), C.c_int32()
+        info = np.zeros(8, np.int32)
+        self.lib.vso_azc_apply(_p(frame, u8p), w, h, w * cn, cn, _p(buf, u8p), C.byref(ow), C.byref(oh), _p(info, i32p))
+        shape = (oh.value, ow.value) if cn == 1 else (oh.value, ow.value, 3)
+        return buf[:oh.value * ow.value * cn].reshape(shape).copy(), info
 
     def roll_params(self, **kw):
         p = self.VsRollParams()

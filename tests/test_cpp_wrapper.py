@@ -39,3 +39,32 @@ def test_wrapper_runs_file_capture_loop(gpu):
     assert r.returncode == 0, r.stdout + r.stderr
     n, outs, flushed, _ = r.stdout.split()
     assert (int(n), int(outs), int(flushed)) == (40, 21, 19)     # radius 20 -> 19 warm-up empties
+
+
+ROLL_EXE = os.path.join(ROOT, "tests", "cpp", "_build", "roll_smoke")
+
+
+def build_roll():
+    os.makedirs(os.path.dirname(ROLL_EXE), exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "tests", "mock_opencv"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "roll_smoke.cpp"), os.path.join(ROOT, "video-stab_amd", "host", "RollCorrection.cpp"),
+           "-L" + CSRC, "-lvideo-stab", "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", ROLL_EXE]
+    subprocess.check_call(cmd)
+
+
+def test_roll_wrapper_compiles_and_fails_loudly_without_gpu(vs):
+    build_roll()
+    if vs.lib.vs_device_count() > 0:
+        return
+    r = subprocess.run([ROLL_EXE, "2"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_roll_wrapper_runs_example_loop(gpu):
+    """examples/roll-correction-file.cpp:52-70 through the C++ classes."""
+    build_roll()
+    r = subprocess.run([ROLL_EXE, "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    n, ow, oh, _ = r.stdout.split()
+    assert (int(n), int(ow), int(oh)) == (6, 640, 360)

@@ -1,0 +1,435 @@
+// Auto zoom/crop for gfx950: counterpart of vs::AutoZoomCrop::autoZoomCrop
+// (/root/reference/src/AutoZoomCrop.cpp:102-283).
+//
+// Split of the work (the reference has the same split, AutoZoomCrop.cpp:141-147: the mask is
+// downloaded for cv::findContours on the CPU):
+//   device  content_mask_kernel : BGR2GRAY + threshold(>1) + MORPH_CLOSE(5x5 ellipse) fused in one
+//                                 pass over the frame (tile + halo in LDS), 3 B/px read, 1 B/px written
+//   host    crop_from_mask      : border following of the 1 B/px mask (pointer chasing along one
+//                                 contour: serial by nature), filled interior as row spans, the
+//                                 shrink loop of :189-205 on per-row/column prefix counts
+//   device  warp_affine_kernel  : crop + scale to 640x360 (cv::warpAffine semantics, k_warp.hip)
+// Only the mask (w*h bytes) crosses PCIe between the two device stages; the frame stays in HBM.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "vs_common.h"
+
+namespace vsd {
+
+int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst, size_t dstride,
+                           int dw, int dh, int cn, const double* h_Minv, int border, hipStream_t st);
+
+namespace {
+
+constexpr int TW = 64, TH = 16;                 // output tile
+constexpr int W0 = TW + 8, H0 = TH + 8;         // thresholded mask, halo 4
+constexpr int W1 = TW + 4, H1 = TH + 4;         // dilated mask, halo 2
+
+// 5x5 MORPH_ELLIPSE: rows -1..1 are full, rows -2 and +2 hold the centre only
+template <int CN>
+__global__ __launch_bounds__(256) void content_mask_kernel(const uint8_t* __restrict__ src, size_t stride, int w, int h,
+                                                           uint8_t* __restrict__ mask, size_t mstride) {
+    __shared__ uint8_t m0[H0][W0 + 4];
+    __shared__ uint8_t m1[H1][W1 + 4];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    for (int i = tid; i < W0 * H0; i += 256) {
+        const int ly = i / W0, lx = i - ly * W0;
+        const int x = x0 + lx - 4, y = y0 + ly - 4;
+        uint8_t v = 0;                           // outside pixels never win a max
+        if ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) {
+            const uint8_t* p = src + (size_t)y * stride + (size_t)x * CN;
+            uint32_t g;
+            if (CN == 3) g = (p[0] * 3735u + p[1] * 19235u + p[2] * 9798u + (1u << 14)) >> 15;   // BGR2GRAY
+            else g = p[0];
+            v = g > 1 ? 1 : 0;                   // threshold(gray, 1, 255, THRESH_BINARY)
+        }
+        m0[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < W1 * H1; i += 256) {   // dilate
+        const int ly = i / W1, lx = i - ly * W1;
+        const int x = x0 + lx - 2, y = y0 + ly - 2;
+        uint8_t v = 1;                           // outside pixels never win a min
+        if ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) {
+            const int cy = ly + 2, cx = lx + 2;
+            v = m0[cy - 2][cx] | m0[cy + 2][cx];
+#pragma unroll
+            for (int ky = -1; ky <= 1; ky++)
+#pragma unroll
+                for (int kx = -2; kx <= 2; kx++) v |= m0[cy + ky][cx + kx];
+        }
+        m1[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < TW * TH; i += 256) {   // erode
+        const int ly = i / TW, lx = i - ly * TW;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= w || y >= h) continue;
+        const int cy = ly + 2, cx = lx + 2;
+        uint8_t v = m1[cy - 2][cx] & m1[cy + 2][cx];
+#pragma unroll
+        for (int ky = -1; ky <= 1; ky++)
+#pragma unroll
+            for (int kx = -2; kx <= 2; kx++) v &= m1[cy + ky][cx + kx];
+        mask[(size_t)y * mstride + x] = v ? 255 : 0;
+    }
+}
+
+int launch_content_mask(const uint8_t* d_src, size_t stride, int w, int h, int cn, uint8_t* d_mask, size_t mstride,
+                        hipStream_t st) {
+    if (!d_src || !d_mask || w <= 0 || h <= 0 || (cn != 1 && cn != 3)) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
+    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH);
+    if (grid.y > 65535) { set_last_error("content_mask: image too tall"); return VS_ERR_INVALID_ARG; }
+    if (cn == 3) hipLaunchKernelGGL(content_mask_kernel<3>, grid, dim3(256), 0, st, d_src, stride, w, h, d_mask, mstride);
+    else hipLaunchKernelGGL(content_mask_kernel<1>, grid, dim3(256), 0, st, d_src, stride, w, h, d_mask, mstride);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// ------------------------------------------------------------------ host side of :141-228
+struct P2 { int x, y; };
+
+// Scratch kept between frames so that the per-frame host work allocates nothing.
+struct CropScratch {
+    std::vector<int8_t> img;          // labelled copy of the mask inside a zero frame
+    std::vector<P2> best, cur;        // SIMPLE points of the largest / current contour
+    std::vector<int> chain_best, chain_cur;   // every border pixel (frame coordinates) of the same
+    std::vector<int> row_cnt, col_cnt;        // prefix counts of filled pixels
+    std::vector<int> sx, sy, cross;
+    std::vector<std::vector<int>> rows;       // crossings per row
+};
+
+// Follows the outer borders of `mask` the way cv::findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
+// numbers them and keeps the one with the most points (first wins ties, AutoZoomCrop.cpp:155-164).
+// Returns the number of contours.
+int trace_largest(const uint8_t* mask, int w, int h, size_t stride, CropScratch& S) {
+    const int W = w + 2;
+    S.img.assign((size_t)W * (h + 2), 0);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* m = mask + (size_t)y * stride;
+        int8_t* d = &S.img[(size_t)(y + 1) * W + 1];
+        for (int x = 0; x < w; x++) d[x] = m[x] != 0;
+    }
+    int8_t* img = S.img.data();
+    // 8 directions counter-clockwise from east, image y pointing down
+    static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1}, DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    int off[16];
+    for (int i = 0; i < 16; i++) off[i] = DY[i & 7] * W + DX[i & 7];
+    const int8_t LEFT_MARK = 2, RIGHT_MARK = (int8_t)0x82;
+    S.best.clear(); S.chain_best.clear();
+    int n_contours = 0;
+    for (int y = 1; y <= h; y++) {
+        int8_t* row = img + (size_t)y * W;
+        int last_label_x = 0;                    // last labelled pixel met on this row (column 0 = frame)
+        int before = 0;
+        for (int x = 1; x <= w; x++) {
+            const int v = row[x];
+            if (v == before) continue;
+            const bool outer_start = before == 0 && v == 1 && row[last_label_x] <= 0;
+            if (!outer_start) {
+                before = v;
+                if (v & ~1) last_label_x = x;
+                continue;
+            }
+            ++n_contours;
+            S.cur.clear(); S.chain_cur.clear();
+            const int start = y * W + x;
+            // first neighbour clockwise from west
+            int dir = 4, second = -1;
+            for (int k = 0; k < 7; k++) {
+                dir = (dir + 7) & 7;
+                if (img[start + off[dir]] != 0) { second = start + off[dir]; break; }
+            }
+            if (second < 0) {
+                img[start] = RIGHT_MARK;
+                S.cur.push_back({x - 1, y - 1});
+                S.chain_cur.push_back(start);
+            } else {
+                int at = start, last_dir = dir ^ 4;
+                P2 pos{x - 1, y - 1};
+                while (true) {
+                    const int from = dir;
+                    int next;
+                    do { next = at + off[++dir]; } while (img[next] == 0);
+                    dir &= 7;
+                    const bool passed_east = (unsigned)(dir - 1) < (unsigned)from;
+                    if (passed_east) img[at] = RIGHT_MARK;
+                    else if (img[at] == 1) img[at] = LEFT_MARK;
+                    S.chain_cur.push_back(at);
+                    if (dir != last_dir) { S.cur.push_back(pos); last_dir = dir; }
+                    pos.x += DX[dir]; pos.y += DY[dir];
+                    if (next == start && at == second) break;
+                    at = next;
+                    dir = (dir + 4) & 7;
+                }
+            }
+            if (S.cur.size() > S.best.size()) { S.best.swap(S.cur); S.chain_best.swap(S.chain_cur); }
+            before = row[x];
+            last_label_x = x;
+        }
+    }
+    return n_contours;
+}
+
+// Prefix counts of the filled contour (cv::drawContours FILLED): interior by the even-odd rule on the
+// border chain (each chain step that changes row is one crossing of the upper of its two rows) plus
+// the border pixels themselves.  row_cnt[y*(w+1)+x] = filled pixels in row y left of x; col_cnt likewise.
+void fill_counts(int w, int h, CropScratch& S, std::vector<uint8_t>* dump) {
+    const int W = w + 2;
+    std::vector<uint8_t> filled((size_t)w * h, 0);
+    S.rows.resize(h);
+    for (auto& r : S.rows) r.clear();
+    const size_t n = S.chain_best.size();
+    for (size_t i = 0; i < n; i++) {
+        const int a = S.chain_best[i], b = S.chain_best[(i + 1) % n];
+        const int ay = a / W - 1, ax = a % W - 1, by = b / W - 1, bx = b % W - 1;
+        filled[(size_t)ay * w + ax] = 255;
+        if (ay == by) continue;
+        if (ay < by) S.rows[ay].push_back(ax); else S.rows[by].push_back(bx);
+    }
+    for (int y = 0; y < h; y++) {
+        std::vector<int>& r = S.rows[y];
+        if (r.empty()) continue;
+        std::sort(r.begin(), r.end());
+        for (size_t k = 0; k + 1 < r.size(); k += 2)
+            if (r[k + 1] > r[k]) memset(&filled[(size_t)y * w + r[k]], 255, (size_t)(r[k + 1] - r[k] + 1));
+    }
+    S.row_cnt.assign((size_t)h * (w + 1), 0);
+    S.col_cnt.assign((size_t)w * (h + 1), 0);
+    for (int y = 0; y < h; y++) {
+        int* rc = &S.row_cnt[(size_t)y * (w + 1)];
+        const uint8_t* f = &filled[(size_t)y * w];
+        for (int x = 0; x < w; x++) rc[x + 1] = rc[x] + (f[x] != 0);
+    }
+    for (int y = 0; y < h; y++) {
+        const uint8_t* f = &filled[(size_t)y * w];
+        for (int x = 0; x < w; x++) S.col_cnt[(size_t)x * (h + 1) + y + 1] = S.col_cnt[(size_t)x * (h + 1) + y] + (f[x] != 0);
+    }
+    if (dump) dump->swap(filled);
+}
+
+// info = {n_contours, contour_points, x, y, w, h, iterations, valid}
+void crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, CropScratch& S, int32_t info[8],
+                    std::vector<uint8_t>* filled_dump) {
+    for (int i = 0; i < 8; i++) info[i] = 0;
+    info[0] = trace_largest(mask, w, h, stride, S);
+    if (info[0] == 0) return;
+    info[1] = (int)S.best.size();
+    fill_counts(w, h, S, filled_dump);
+    S.sx.clear(); S.sy.clear();
+    for (const P2& p : S.best) { S.sx.push_back(p.x); S.sy.push_back(p.y); }
+    std::sort(S.sx.begin(), S.sx.end());
+    std::sort(S.sy.begin(), S.sy.end());
+    auto row_zeros = [&](int y, int xa, int xb) {   // zeros in row y, columns [xa, xb)
+        const int* rc = &S.row_cnt[(size_t)y * (w + 1)];
+        return (xb - xa) - (rc[xb] - rc[xa]);
+    };
+    auto col_zeros = [&](int x, int ya, int yb) {
+        const int* cc = &S.col_cnt[(size_t)x * (h + 1)];
+        return (yb - ya) - (cc[yb] - cc[ya]);
+    };
+    size_t lo_x = 0, hi_x = S.sx.size() - 1, lo_y = 0, hi_y = S.sy.size() - 1;
+    int bx = 0, by = 0, bw = 0, bh = 0, iters = 0;
+    while (lo_x < hi_x && lo_y < hi_y) {
+        bx = S.sx[lo_x]; by = S.sy[lo_y]; bw = S.sx[hi_x] - bx; bh = S.sy[hi_y] - by;
+        ++iters;
+        if (bw <= 0 || bh <= 0) break;              // degenerate rectangle: nothing to test
+        const int top = row_zeros(by, bx, bx + bw), bottom = row_zeros(by + bh - 1, bx, bx + bw);
+        const int left = col_zeros(bx, by, by + bh), right = col_zeros(bx + bw - 1, by, by + bh);
+        if (!(top | bottom | left | right)) break;
+        // which side gives way (AutoZoomCrop.cpp:57-77)
+        bool mv_top = false, mv_bottom = false, mv_left = false, mv_right = false;
+        if (top > bottom) mv_top = top > left && top > right;
+        else mv_bottom = bottom > left && bottom > right;
+        if (left >= right) mv_left = left >= bottom && left >= top;
+        else mv_right = right >= top && right >= bottom;
+        if (mv_left) ++lo_x;
+        if (mv_right) --hi_x;
+        if (mv_top) ++lo_y;
+        if (mv_bottom) --hi_y;
+    }
+    const double ar = (double)w / h;
+    const int new_w = (int)(bh * ar);
+    const int centre = bx + bw / 2;
+    bw = new_w;
+    bx = centre - new_w / 2;
+    if (bx < 0) bx = 0;
+    if (bx + bw > w) bx = w - bw;
+    const int x1 = std::max(bx, 0), y1 = std::max(by, 0), x2 = std::min(bx + bw, w), y2 = std::min(by + bh, h);
+    info[6] = iters;
+    if (x2 <= x1 || y2 <= y1) return;
+    info[2] = x1; info[3] = y1; info[4] = x2 - x1; info[5] = y2 - y1; info[7] = 1;
+}
+
+}  // namespace
+}  // namespace vsd
+
+using namespace vsd;
+
+struct vs_azc {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    uint8_t* d_mask = nullptr;
+    uint8_t* h_mask = nullptr;        // pinned
+    uint8_t* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    size_t mask_bytes = 0, io_bytes = 0;
+    CropScratch scratch;
+    int32_t info[8] = {0};
+};
+
+#define A_HIP(a, expr)                                                             \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) { (a)->err = std::string(#expr) + ": " + hipGetErrorString(_e); set_last_error((a)->err); return VS_ERR_HIP; } \
+    } while (0)
+#define A_TRY(a, expr)                                                             \
+    do { int _s = (expr); if (_s != VS_OK) { (a)->err = get_last_error(); return _s; } } while (0)
+
+extern "C" {
+
+int vs_op_content_mask(const void* d_src, size_t stride, int w, int h, int cn, void* d_mask, size_t mask_stride,
+                       void* stream) {
+    VS_TRY(ensure_device());
+    return launch_content_mask((const uint8_t*)d_src, stride, w, h, cn, (uint8_t*)d_mask, mask_stride, (hipStream_t)stream);
+}
+
+// Host logic only (no device needed): :141-228 on a host mask.
+int vs_azc_crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, int32_t* info, uint8_t* filled_out) {
+    if (!mask || !info || w <= 0 || h <= 0 || stride < (size_t)w) return VS_ERR_INVALID_ARG;
+    CropScratch S;
+    std::vector<uint8_t> filled;
+    crop_from_mask(mask, w, h, stride, S, info, filled_out ? &filled : nullptr);
+    if (filled_out) {
+        if (filled.empty()) memset(filled_out, 0, (size_t)w * h);
+        else memcpy(filled_out, filled.data(), (size_t)w * h);
+    }
+    return VS_OK;
+}
+
+int vs_azc_create(int device, vs_azc** out) {
+    if (!out) return VS_ERR_INVALID_ARG;
+    *out = nullptr;
+    VS_TRY(ensure_device());
+    VS_HIP_TRY(hipSetDevice(device));
+    vs_azc* a = new (std::nothrow) vs_azc();
+    if (!a) return VS_ERR_HIP;
+    a->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&a->st, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); delete a; return VS_ERR_HIP; }
+    *out = a;
+    return VS_OK;
+}
+
+void vs_azc_destroy(vs_azc* a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    if (a->st) (void)hipStreamSynchronize(a->st);
+    if (a->d_mask) (void)hipFree(a->d_mask);
+    if (a->h_mask) (void)hipHostFree(a->h_mask);
+    if (a->d_in) (void)hipFree(a->d_in);
+    if (a->d_out) (void)hipFree(a->d_out);
+    if (a->st) (void)hipStreamDestroy(a->st);
+    delete a;
+}
+
+const char* vs_azc_last_error(const vs_azc* a) { return a ? a->err.c_str() : ""; }
+
+int vs_azc_get_info(const vs_azc* a, int32_t* info8) {
+    if (!a || !info8) return VS_ERR_INVALID_ARG;
+    memcpy(info8, a->info, sizeof a->info);
+    return VS_OK;
+}
+
+int vs_azc_sync(vs_azc* a) {
+    if (!a) return VS_ERR_INVALID_ARG;
+    A_HIP(a, hipSetDevice(a->device));
+    A_HIP(a, hipStreamSynchronize(a->st));
+    return VS_OK;
+}
+
+// Mask on the device, contour logic on the host: fills a->info (:111-228).
+static int azc_plan(vs_azc* a, const void* d_data, int w, int h, size_t stride, int cn) {
+    const size_t mb = (size_t)w * h;
+    if (a->mask_bytes < mb) {
+        if (a->d_mask) (void)hipFree(a->d_mask);
+        if (a->h_mask) (void)hipHostFree(a->h_mask);
+        a->d_mask = a->h_mask = nullptr; a->mask_bytes = 0;
+        A_HIP(a, hipMalloc((void**)&a->d_mask, mb));
+        A_HIP(a, hipHostMalloc((void**)&a->h_mask, mb, hipHostMallocDefault));
+        a->mask_bytes = mb;
+    }
+    A_TRY(a, launch_content_mask((const uint8_t*)d_data, stride, w, h, cn, a->d_mask, w, a->st));      // :111-139
+    A_HIP(a, hipMemcpyAsync(a->h_mask, a->d_mask, mb, hipMemcpyDeviceToHost, a->st));                 // :142-143
+    A_HIP(a, hipStreamSynchronize(a->st));
+    crop_from_mask(a->h_mask, w, h, w, a->scratch, a->info, nullptr);                                 // :146-228
+    return VS_OK;
+}
+
+// Crop + scale (:246-270) or the unchanged frame (:149-152, :238-249), left in flight on a->st.
+static int azc_emit(vs_azc* a, const void* d_data, int w, int h, size_t stride, int cn, void* d_out, size_t out_stride) {
+    if (!a->info[7]) {
+        if (out_stride < (size_t)w * cn) return VS_ERR_INVALID_ARG;
+        A_HIP(a, hipMemcpy2DAsync(d_out, out_stride, d_data, stride, (size_t)w * cn, h, hipMemcpyDeviceToDevice, a->st));
+        return VS_OK;
+    }
+    if (out_stride < (size_t)640 * cn) return VS_ERR_INVALID_ARG;
+    const int cx = a->info[2], cy = a->info[3], cw = a->info[4], ch = a->info[5];
+    // M = [sx 0 0; 0 sy 0] held as CV_32F (:261-262); cv::warpAffine inverts it in double
+    const float Mf[6] = {(float)(640.0 / cw), 0.f, 0.f, 0.f, (float)(360.0 / ch), 0.f};
+    double Mi[6];
+    warp_invert(Mf, Mi);
+    const uint8_t* roi = (const uint8_t*)d_data + (size_t)cy * stride + (size_t)cx * cn;
+    A_TRY(a, launch_warp_affine_inv(roi, stride, cw, ch, (uint8_t*)d_out, out_stride, 640, 360, cn, Mi, VS_BORDER_BLACK, a->st));
+    return VS_OK;
+}
+
+// Frame in HBM -> 640x360 crop in HBM (or an unchanged copy on the fallback paths).  out_stride must fit
+// either outcome (>= max(w, 640) * cn).  The result is left in flight on the object's stream (vs_azc_sync).
+int vs_azc_apply_dev(vs_azc* a, const void* d_data, int w, int h, size_t stride, int cn, void* d_out, size_t out_stride,
+                     int* out_w, int* out_h) {
+    if (!a || !d_data || !d_out || !out_w || !out_h || w <= 0 || h <= 0 || (cn != 1 && cn != 3) || stride < (size_t)w * cn ||
+        out_stride < (size_t)std::max(w, 640) * cn)
+        return VS_ERR_INVALID_ARG;
+    A_HIP(a, hipSetDevice(a->device));
+    int rc = azc_plan(a, d_data, w, h, stride, cn);
+    if (rc != VS_OK) return rc;
+    rc = azc_emit(a, d_data, w, h, stride, cn, d_out, out_stride);
+    if (rc != VS_OK) return rc;
+    *out_w = a->info[7] ? 640 : w;
+    *out_h = a->info[7] ? 360 : h;
+    return VS_OK;
+}
+
+// cv::Mat autoZoomCrop(const cv::Mat&, double) on host buffers.  `out` must hold max(w*h, 640*360)*cn bytes and
+// receives packed rows of *out_w * cn bytes.
+int vs_azc_apply(vs_azc* a, const uint8_t* data, int w, int h, size_t stride, int cn, uint8_t* out, int* out_w, int* out_h) {
+    if (!a || !data || !out || !out_w || !out_h || w <= 0 || h <= 0 || (cn != 1 && cn != 3) || stride < (size_t)w * cn)
+        return VS_ERR_INVALID_ARG;
+    A_HIP(a, hipSetDevice(a->device));
+    const size_t row = (size_t)w * cn, bytes = std::max(row * h, (size_t)640 * 360 * cn);
+    if (a->io_bytes < bytes) {
+        if (a->d_in) (void)hipFree(a->d_in);
+        if (a->d_out) (void)hipFree(a->d_out);
+        a->d_in = a->d_out = nullptr; a->io_bytes = 0;
+        A_HIP(a, hipMalloc((void**)&a->d_in, bytes));
+        A_HIP(a, hipMalloc((void**)&a->d_out, bytes));
+        a->io_bytes = bytes;
+    }
+    A_HIP(a, hipMemcpy2DAsync(a->d_in, row, data, stride, row, h, hipMemcpyHostToDevice, a->st));
+    int rc = azc_plan(a, a->d_in, w, h, row, cn);
+    if (rc != VS_OK) return rc;
+    const int ow = a->info[7] ? 640 : w, oh = a->info[7] ? 360 : h;
+    rc = azc_emit(a, a->d_in, w, h, row, cn, a->d_out, (size_t)ow * cn);
+    if (rc != VS_OK) return rc;
+    A_HIP(a, hipMemcpyAsync(out, a->d_out, (size_t)ow * cn * oh, hipMemcpyDeviceToHost, a->st));
+    A_HIP(a, hipStreamSynchronize(a->st));
+    *out_w = ow; *out_h = oh;
+    return VS_OK;
+}
+
+}  // extern "C"

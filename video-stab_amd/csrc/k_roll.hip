@@ -448,6 +448,14 @@ void vs_roll_destroy(vs_roll* r) {
 
 const char* vs_roll_last_error(const vs_roll* r) { return r ? r->err.c_str() : ""; }
 
+// The reference passes Parameters on every call while the smoothed angle persists (RollCorrection.cpp:13-19).
+int vs_roll_set_params(vs_roll* r, const vs_roll_params_c* params) {
+    if (!r || !params || params->struct_size != (int32_t)sizeof(vs_roll_params_c)) return VS_ERR_INVALID_ARG;
+    if (params->canny_aperture != 3) { r->err = "roll: only cannyAperture 3 is supported"; set_last_error(r->err); return VS_ERR_UNSUPPORTED; }
+    r->p = *params;
+    return VS_OK;
+}
+
 int vs_roll_get_state(const vs_roll* r, double* smoothed_deg, double* detected_deg, int* n_lines, int* n_used) {
     if (!r) return VS_ERR_INVALID_ARG;
     if (smoothed_deg) *smoothed_deg = r->smoothed;

@@ -184,7 +184,20 @@ class VsLib:
         L.vs_op_canny.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.c_size_t, vp]
         L.vs_op_hough_lines.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp,
                                         C.c_int, vp, vp]
-        L.vs_op_warp_affine_ex.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_int,
+        L.vs_azc_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.vs_azc_destroy.argtypes = [vp]
+        L.vs_azc_destroy.restype = None
+        L.vs_azc_last_error.argtypes = [vp]
+        L.vs_azc_last_error.restype = C.c_char_p
+        L.vs_azc_apply.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]
+        L.vs_azc_apply_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, C.c_size_t,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vs_azc_sync.argtypes = [vp]
+        L.vs_azc_get_info.argtypes = [vp, i32p]
+        L.vs_op_content_mask.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        L.vs_azc_crop_from_mask.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i32p, u8p]
+        L.vs_op_warp_affine_ex.argtypes =[vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_int,
                                            C.c_int, f64p, C.c_int, vp]
 
     # ---- helpers ----------------------------------------------------------
@@ -353,6 +366,29 @@ class VsLib:
         self.sync()
         return d_out.download((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
 
+    def content_mask(self, img):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else 3
+        d_in = DevBuf.from_array(self, img)
+        d_out = DevBuf(self, w * h)
+        self.check(self.lib.vs_op_content_mask(d_in.ptr, w * cn, w, h, cn, d_out.ptr, w, None))
+        self.sync()
+        return d_out.download((h, w), np.uint8)
+
+    def azc_crop_from_mask(self, mask, want_filled=False):
+        """Host logic of AutoZoomCrop (no device needed): info8 [, filled mask]."""
+        mask = np.ascontiguousarray(mask)
+        h, w = mask.shape
+        info = np.zeros(8, np.int32)
+        filled = np.empty((h, w), np.uint8) if want_filled else None
+        self.check(self.lib.vs_azc_crop_from_mask(_p(mask, u8p), w, h, w, _p(info, i32p),
+                                                  _p(filled, u8p) if want_filled else None))
+        return (info, filled) if want_filled else info
+
+    def auto_zoom_crop(self, device=0):
+        return AutoZoomCrop(self, device)
+
     def roll_params(self, **kw):
         p = VsRollParams()
         self.lib.vs_roll_params_default(C.byref(p))
@@ -366,6 +402,58 @@ class VsLib:
 
     def stabilizer(self, params, device=0):
         return Stabilizer(self, params, device)
+
+
+class AutoZoomCrop:
+    """C-ABI mirror of vs::AutoZoomCrop::autoZoomCrop (AutoZoomCrop.cpp:102-283)."""
+
+    def __init__(self, vs, device=0):
+        self.vs = vs
+        self.lib = vs.lib
+        h = C.c_void_p()
+        vs.check(self.lib.vs_azc_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.vs_azc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status):
+        if status != 0:
+            raise VsError("%s: %s" % (self.lib.vs_status_string(status).decode(),
+                                      (self.lib.vs_azc_last_error(self.h) or b"").decode()))
+
+    def apply(self, frame):
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        cn = 1 if frame.ndim == 2 else 3
+        buf = np.empty(max(w * h, 640 * 360) * cn, np.uint8)
+        ow, oh = C.c_int(), C.c_int()
+        self._check(self.lib.vs_azc_apply(self.h, _p(frame, u8p), w, h, w * cn, cn, _p(buf, u8p),
+                                          C.byref(ow), C.byref(oh)))
+        shape = (oh.value, ow.value) if cn == 1 else (oh.value, ow.value, 3)
+        return buf[:oh.value * ow.value * cn].reshape(shape).copy()
+
+    def apply_dev(self, d_in, w, h, stride, cn, d_out, out_stride):
+        ow, oh = C.c_int(), C.c_int()
+        self._check(self.lib.vs_azc_apply_dev(self.h, d_in, w, h, stride, cn, d_out, out_stride,
+                                              C.byref(ow), C.byref(oh)))
+        return ow.value, oh.value
+
+    def sync(self):
+        self._check(self.lib.vs_azc_sync(self.h))
+
+    def info(self):
+        info = np.zeros(8, np.int32)
+        self._check(self.lib.vs_azc_get_info(self.h, _p(info, i32p)))
+        return info
 
 
 class RollCorrection:
