@@ -10,16 +10,20 @@
 //
 // HBM-bound stage: 2 x frame bytes of algorithmic traffic per frame.  One
 // workgroup = one 128x16 output tile:
-//   1. 144 lanes evaluate the double-precision column/row coordinate terms of
-//      the tile once (adelta/bdelta per column, X0/Y0 per row) into LDS;
-//   2. the source bounding box of the tile is staged into LDS with coalesced
-//      12-byte/lane loads, one dword per pixel, zeros outside the image
-//      (= BORDER_CONSTANT), so taps need no bounds logic;
-//   3. each lane produces 4 consecutive pixels of 2 rows: taps from LDS,
-//      horizontal lerps with v_dot4_u32_u8 on byte-permuted tap pairs, vertical
-//      lerp in 24-bit multiplies, one 12-byte store per 4 pixels.
-// Tiles whose bounding box does not fit the LDS budget (large rotation /
-// scale) take a direct global-load path with the same arithmetic.
+//   1. every wave evaluates, in ONE double-precision pass, its share of the tile's
+//      coordinate terms (adelta/bdelta of 32 columns, X0/Y0 of 4 rows -> LDS) and, in four
+//      spare lanes, the terms of the tile corners, from which the source bounding box of
+//      the tile follows by v_readlane (the maps are monotone in x and in y);
+//   2. the box is staged into LDS with coalesced 12-byte/lane loads, one dword per pixel;
+//      tiles whose box lies inside the image take a branch-free version of this;
+//   3. fast path (box at most 136 x 28, i.e. rotations up to ~4 degrees at scale ~1): lane L
+//      of a 32-lane row blends the pixels L, L+32, L+64, L+96 (neighbouring lanes read
+//      neighbouring LDS dwords: no bank conflicts), taps at immediate offsets of one
+//      multiply-add address, horizontal lerps with v_dot4_u32_u8 on byte-permuted tap pairs,
+//      vertical lerp in 24-bit multiply-adds whose byte 2 is the rounded result; the row is
+//      transposed through a per-wave LDS buffer so that each lane stores 12 contiguous bytes;
+//   4. other tiles: a generic LDS path (variable pitch) or, when the box does not fit the
+//      LDS budget (large rotation / scale), direct global loads - the same arithmetic.
 #include "vs_common.h"
 
 namespace vsd {
@@ -32,10 +36,16 @@ constexpr int PX = 4;        // consecutive output pixels per lane
 constexpr int NT = 256;      // threads per workgroup
 constexpr int TXN = TW / PX; // 32 lanes along x
 constexpr int TYN = NT / TXN;// 8 lane-rows
-constexpr int LDS_PX = 3072; // 12 KiB of staged pixels per workgroup
 constexpr int MAXB = 16;     // matrices passed by value per launch
-constexpr int SGW = 48;      // staging: 4-pixel groups handled per row pass (fast mapping)
-constexpr int SROWS = 5;     // staging: row passes held in registers (5 rows per pass)
+// fast path (near-identity maps): the source box of a tile is staged with a FIXED row pitch, so
+// the lower taps sit at an immediate offset and the tap address is one multiply-add
+constexpr int FPITCH = 136;  // staged row pitch in pixels (128 + tap + shear + 12-byte alignment slack)
+constexpr int FROWS = 28;    // staged rows
+constexpr int LDS_PX = FPITCH * FROWS;   // 14.9 KiB of staged pixels per workgroup
+constexpr int SG = FPITCH / 4;           // 34 four-pixel groups per staged row
+constexpr int SR = 7;                    // rows per staging pass (34 x 7 = 238 lanes)
+constexpr int SPASS = FROWS / SR;        // 4 staging passes held in registers
+constexpr int OBUF = (NT / 64) * 2 * TW; // per wave: two output rows, one dword per pixel
 
 struct WarpArgs {
     const uint8_t* src;
@@ -193,105 +203,202 @@ __device__ __forceinline__ void emit_rows(const WarpArgs& a, const uint8_t* __re
     }
 }
 
-// hal::warpAffine / WarpAffineInvoker coordinate terms (1/1024 px; +16 = round_delta)
-__device__ __forceinline__ void col_terms(const double* m, int x, int& ad, int& bd) {
-    ad = d_round(m[0] * x * 1024);
-    bd = d_round(m[3] * x * 1024);
+// a*b + c as ONE v_mad_u32_u24.  The empty asm pins the accumulator, so the two multiply-adds of
+// a vertical lerp are not re-associated into mul, mul, add3.  (A real asm mad must not be used
+// here: its source is a v_dot4 result and gfx950 needs wait states between the two that only
+// the compiler's hazard recogniser inserts.)
+__device__ __forceinline__ uint32_t mad24u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d = __umul24(a, b) + c;
+    asm("" : "+v"(d));
+    return d;
 }
-__device__ __forceinline__ void row_terms(const double* m, int y, int& X0, int& Y0) {
-    X0 = d_round((m[1] * y + m[2]) * 1024) + 16;
-    Y0 = d_round((m[4] * y + m[5]) * 1024) + 16;
+
+// Fast-path blend.  SX, SY: source coordinates in 1/1024 px.  The horizontal weights carry a
+// factor 2 and the vertical ones a factor 32 (= the bits of SY that hold the fraction, taken in
+// place), so that the rounded 8-bit result of a channel is byte 2 of its accumulator:
+//   (t*wy0 + b*wy1 + 512) >> 10  ==  ((2t)*(32 wy0) + (2b)*(32 wy1) + 32768) >> 16
+// and the three channels are gathered with two byte permutes instead of shifts and ors.
+__device__ __forceinline__ uint32_t blend3_fast(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, int SX, int SY) {
+    const uint32_t fx = ((uint32_t)SX >> 5) & 31u;
+    const uint32_t wlo = mad24u(fx, 510u, 64u);           // (64-2fx) | 2fx<<8
+    const uint32_t whi = wlo << 16;
+    const uint32_t wy1 = (uint32_t)SY & 0x3E0u, wy0 = 1024u - wy1;
+    const uint32_t x0 = __builtin_amdgcn_perm(p01, p00, 0x05010400u);
+    const uint32_t x1 = __builtin_amdgcn_perm(p11, p10, 0x05010400u);
+    const uint32_t y0 = __builtin_amdgcn_perm(p01, p00, 0x0C0C0602u);
+    const uint32_t y1 = __builtin_amdgcn_perm(p11, p10, 0x0C0C0602u);
+    uint32_t c0 = mad24u(__builtin_amdgcn_udot4(x0, wlo, 0u, false), wy0, 32768u);
+    c0 = mad24u(__builtin_amdgcn_udot4(x1, wlo, 0u, false), wy1, c0);
+    uint32_t c1 = mad24u(__builtin_amdgcn_udot4(x0, whi, 0u, false), wy0, 32768u);
+    c1 = mad24u(__builtin_amdgcn_udot4(x1, whi, 0u, false), wy1, c1);
+    uint32_t c2 = mad24u(__builtin_amdgcn_udot4(y0, wlo, 0u, false), wy0, 32768u);
+    c2 = mad24u(__builtin_amdgcn_udot4(y1, wlo, 0u, false), wy1, c2);
+    const uint32_t bg = __builtin_amdgcn_perm(c1, c0, 0x0C0C0602u);      // (c0.b2, c1.b2, 0, 0)
+    return __builtin_amdgcn_perm(c2, bg, 0x0C060100u);                     // (B, G, R, 0)
 }
+
+// Fast-path output (BGR8).  Lane L of a 32-lane row handles the pixels L, L+32, L+64, L+96 of its
+// row, so that neighbouring lanes read neighbouring LDS dwords (no bank conflicts; with 4
+// consecutive pixels per lane the taps of a wave fall on 8 of the 32 banks).  The results are
+// transposed through a small per-wave LDS buffer so that every lane still stores 4 consecutive
+// pixels = 12 contiguous bytes.  `base` = -(by0*FPITCH + bx0a).
+__device__ __forceinline__ void emit_fast(const WarpArgs& a, uint8_t* __restrict__ dst, const uint32_t* tile,
+                                          uint32_t* obuf, const int* s_ad, const int* s_bd, const int* s_x0,
+                                          const int* s_y0, int x0, int y0, int x1, int y1, int base) {
+    const int tid = threadIdx.x;
+    const int L = tid & 31, ty = tid >> 5;
+    uint32_t* wb = obuf + (tid >> 6) * (2 * TW) + ((tid >> 5) & 1) * TW;
+    int ad[4], bd[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ad[i] = s_ad[L + 32 * i]; bd[i] = s_bd[L + 32 * i]; }
+#pragma unroll
+    for (int r = 0; r < TH / TYN; r++) {
+        const int yl = ty + TYN * r;
+        const int X0 = s_x0[yl], Y0 = s_y0[yl];
+        uint32_t p00[4], p01[4], p10[4], p11[4];
+        int SX[4], SY[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            SX[i] = X0 + ad[i]; SY[i] = Y0 + bd[i];              // 1/1024 px
+            // byte address of the upper-left tap: one multiply-add and one shift-add
+            int rowb = __mul24(SY[i] >> 10, FPITCH * 4) + 4 * base;
+            asm("" : "+v"(rowb));
+            int sxi = SX[i] >> 10;
+            asm("" : "+v"(sxi));
+            const uint32_t* t = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile) + ((sxi << 2) + rowb));
+            p00[i] = t[0]; p01[i] = t[1];
+            p10[i] = t[FPITCH]; p11[i] = t[FPITCH + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) wb[L + 32 * i] = blend3_fast(p00[i], p01[i], p10[i], p11[i], SX[i], SY[i]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint4 q = *reinterpret_cast<const uint4*>(&wb[4 * L]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int y = y0 + yl, x = x0 + 4 * L;
+        if (y <= y1 && x <= x1) {
+            uint8_t* d = dst + (size_t)y * a.dstride + (size_t)x * 3;
+            if (a.dst_aligned && x + 3 <= x1) {
+                U3 v;
+                v.a = __builtin_amdgcn_perm(q.y, q.x, 0x04020100u);
+                v.b = __builtin_amdgcn_perm(q.z, q.y, 0x05040201u);
+                v.c = __builtin_amdgcn_perm(q.w, q.z, 0x06050402u);
+                *reinterpret_cast<U3*>(d) = v;
+            } else {
+                const uint32_t o[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (x + i > x1) break;
+                    d[3 * i] = (uint8_t)o[i]; d[3 * i + 1] = (uint8_t)(o[i] >> 8); d[3 * i + 2] = (uint8_t)(o[i] >> 16);
+                }
+            }
+        }
+    }
+}
+
+// hal::warpAffine / WarpAffineInvoker coordinate terms in one form: round((p*v + q) * 1024)
+// (columns: adelta = round(M0*x*1024) with q = 0; rows: round((M1*y + M2)*1024) + round_delta).
+__device__ __forceinline__ int coord_term(double p, double q, double v) { return d_round((p * v + q) * 1024); }
 
 template <int CN>
 __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_PX];
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[OBUF];
     __shared__ int s_ad[TW], s_bd[TW], s_x0[TH], s_y0[TH];
     const int bz = blockIdx.z;
     const uint8_t* __restrict__ src = a.src + (size_t)bz * a.sframe;
     uint8_t* __restrict__ dst = a.dst + (size_t)bz * a.dframe;
-    double m[6];   // inverse map of this frame (wave-uniform)
-    {
-        const double* mp = a.Minv_dev ? a.Minv_dev + 6 * bz : a.Minv_val + 6 * bz;
+    double m[6];   // inverse map of this frame (wave-uniform, scalar loads)
+    if (a.Minv_dev) {
+        const __attribute__((address_space(4))) double* mp =
+            (const __attribute__((address_space(4))) double*)(a.Minv_dev + 6 * bz);
 #pragma unroll
         for (int i = 0; i < 6; i++) m[i] = mp[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) m[i] = a.Minv_val[6 * bz + i];
     }
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int x1 = min(x0 + TW, a.dw) - 1, y1 = min(y0 + TH, a.dh) - 1;
 
-    // ---- 1. source bounding box.  The maps are monotone in x and in y separately, so the
-    // extremes are at the tile corners: lane 0 evaluates (x0,y0), lane 1 (x1,y1), and the
-    // eight terms are broadcast with v_readlane (no LDS, no barrier before the loads).
+    // ---- 1. coordinate terms of the tile, once per workgroup: waves 0 and 1 the 128 columns
+    // (adelta, bdelta), 16 lanes of wave 2 the rows (X0, Y0).  Columns and rows past the image repeat
+    // the last one, so every lane of a partial tile stays inside the box.
+    if (wave < 2) {
+        const double dv = (double)min(x0 + tid, x1);
+        s_ad[tid] = coord_term(m[0], 0.0, dv);
+        s_bd[tid] = coord_term(m[3], 0.0, dv);
+    } else if (tid < 2 * 64 + TH) {
+        const double dv = (double)min(y0 + (tid - 128), y1);
+        s_x0[tid - 128] = coord_term(m[1], m[2], dv) + 16;
+        s_y0[tid - 128] = coord_term(m[4], m[5], dv) + 16;
+    }
+    __syncthreads();
+    // The maps are monotone in x and in y separately, so the source bounding box of the tile follows
+    // from the terms of its first/last column and row (scalar arithmetic on broadcast LDS reads).
     int bx0, bx1, by0, by1;
+    bool saturated;
     {
-        int ad, bd, X0, Y0;
-        col_terms(m, (lane & 1) ? x1 : x0, ad, bd);
-        row_terms(m, (lane & 1) ? y1 : y0, X0, Y0);
-        const int ad0 = __builtin_amdgcn_readlane(ad, 0), ad1 = __builtin_amdgcn_readlane(ad, 1);
-        const int bd0 = __builtin_amdgcn_readlane(bd, 0), bd1 = __builtin_amdgcn_readlane(bd, 1);
-        const int Xa = __builtin_amdgcn_readlane(X0, 0), Xb = __builtin_amdgcn_readlane(X0, 1);
-        const int Ya = __builtin_amdgcn_readlane(Y0, 0), Yb = __builtin_amdgcn_readlane(Y0, 1);
-        const int sx00 = sat_s16((Xa + ad0) >> 10), sx01 = sat_s16((Xa + ad1) >> 10);
-        const int sx10 = sat_s16((Xb + ad0) >> 10), sx11 = sat_s16((Xb + ad1) >> 10);
-        const int sy00 = sat_s16((Ya + bd0) >> 10), sy01 = sat_s16((Ya + bd1) >> 10);
-        const int sy10 = sat_s16((Yb + bd0) >> 10), sy11 = sat_s16((Yb + bd1) >> 10);
-        bx0 = min(min(sx00, sx01), min(sx10, sx11));
-        bx1 = max(max(sx00, sx01), max(sx10, sx11)) + 1;
-        by0 = min(min(sy00, sy01), min(sy10, sy11));
-        by1 = max(max(sy00, sy01), max(sy10, sy11)) + 1;
+        const int cl = x1 - x0, rl = y1 - y0;
+        const int ad0 = __builtin_amdgcn_readfirstlane(s_ad[0]), ad1 = __builtin_amdgcn_readfirstlane(s_ad[cl]);
+        const int bd0 = __builtin_amdgcn_readfirstlane(s_bd[0]), bd1 = __builtin_amdgcn_readfirstlane(s_bd[cl]);
+        const int Xa = __builtin_amdgcn_readfirstlane(s_x0[0]), Xb = __builtin_amdgcn_readfirstlane(s_x0[rl]);
+        const int Ya = __builtin_amdgcn_readfirstlane(s_y0[0]), Yb = __builtin_amdgcn_readfirstlane(s_y0[rl]);
+        const int sx00 = (Xa + ad0) >> 10, sx01 = (Xa + ad1) >> 10, sx10 = (Xb + ad0) >> 10, sx11 = (Xb + ad1) >> 10;
+        const int sy00 = (Ya + bd0) >> 10, sy01 = (Ya + bd1) >> 10, sy10 = (Yb + bd0) >> 10, sy11 = (Yb + bd1) >> 10;
+        const int rx0 = min(min(sx00, sx01), min(sx10, sx11)), rx1 = max(max(sx00, sx01), max(sx10, sx11));
+        const int ry0 = min(min(sy00, sy01), min(sy10, sy11)), ry1 = max(max(sy00, sy01), max(sy10, sy11));
+        saturated = rx0 < -32768 || ry0 < -32768 || rx1 > 32767 || ry1 > 32767;   // saturate_cast<short> acts
+        bx0 = max(rx0, -32768); bx1 = min(rx1, 32767) + 1;                        // (values past the other end
+        by0 = max(ry0, -32768); by1 = min(ry1, 32767) + 1;                        //  only occur when saturated)
     }
     const int bx0a = bx0 & ~3;                       // 4-pixel (12-byte) aligned start
     const int bw = (bx1 - bx0a + 1 + 3) & ~3;        // staged width, multiple of 4
     const int bh = by1 - by0 + 1;
-    const bool use_lds = (long long)bw * bh <= LDS_PX;
-    const int gpr = bw >> 2;                         // 4-pixel groups per staged row
-    const bool fast_stage = use_lds && gpr <= SGW && bh <= 5 * SROWS;
+    const bool fast = CN == 3 && !saturated && bw <= FPITCH && bh <= FROWS;
+    const bool use_lds = fast || (!saturated && (long long)bw * bh <= LDS_PX);
+    const bool interior = fast && a.src_aligned && bx0a >= 0 && bx0a + bw <= a.sw && by0 >= 0 && by0 + bh <= a.sh;
 
-    // ---- 2. staging loads are issued first (5 rows x 48 groups per pass, no runtime division) ...
-    const int ly = tid / SGW, lx = tid - ly * SGW;
-    const bool stager = tid < 5 * SGW && lx < gpr;
-    uint4 staged[SROWS];
-    if (fast_stage && stager) {
+    // ---- 2. staging
+    if (interior) {
+        // branch-free: 4 passes of 7 rows x 34 groups; rows past the box repeat its last row
+        const int ly = tid / SG, lx = tid - ly * SG;
+        if (tid < SG * SR && 4 * lx < bw) {
+            // wave-uniform base + 32-bit lane offset (the box spans < 2^24 bytes of rows)
+            const uint8_t* box = src + (size_t)bx0a * 3 + (size_t)by0 * a.sstride;
+            const uint32_t stride32 = (uint32_t)a.sstride, col = 12u * lx;
+            U3 d[SPASS];
 #pragma unroll
-        for (int k = 0; k < SROWS; k++) {
-            const int row = ly + 5 * k;
-            staged[k] = row < bh ? stage_group<CN>(a, src, bx0a + 4 * lx, by0 + row) : make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
-    // ---- ... the per-column / per-row coordinate terms of the tile are computed while those
-    // loads are in flight (adelta/bdelta per column, X0/Y0 per row, once per tile) ...
-    if (tid < TW) {
-        int ad, bd;
-        col_terms(m, x0 + tid, ad, bd);
-        s_ad[tid] = ad; s_bd[tid] = bd;
-    } else if (tid < TW + TH) {
-        int X0, Y0;
-        row_terms(m, y0 + (tid - TW), X0, Y0);
-        s_x0[tid - TW] = X0; s_y0[tid - TW] = Y0;
-    }
-    // ---- ... and then the staged pixels go to LDS (one dword per pixel, zeros outside the image)
-    if (fast_stage) {
-        if (stager) {
+            for (int k = 0; k < SPASS; k++)
+                if (SR * k < bh)       // tile-uniform: small rotations need 3 passes (21 rows)
+                    d[k] = *reinterpret_cast<const U3*>(box + (__umul24((uint32_t)min(ly + SR * k, bh - 1), stride32) + col));
 #pragma unroll
-            for (int k = 0; k < SROWS; k++) {
-                const int row = ly + 5 * k;
-                if (row < bh) *reinterpret_cast<uint4*>(&tile[row * bw + 4 * lx]) = staged[k];
+            for (int k = 0; k < SPASS; k++) {
+                // byte 3 of a staged pixel is never read by the blend, so it may hold the next pixel's B
+                if (SR * k < bh)
+                    *reinterpret_cast<uint4*>(&tile[(ly + SR * k) * FPITCH + 4 * lx]) =
+                        make_uint4(d[k].a, __builtin_amdgcn_alignbit(d[k].b, d[k].a, 24),
+                                   __builtin_amdgcn_alignbit(d[k].c, d[k].b, 16), d[k].c >> 8);
             }
         }
     } else if (use_lds) {
+        const int pitch = fast ? FPITCH : bw;
+        const int gpr = bw >> 2;
         const int total = gpr * bh;
         for (int g = tid; g < total; g += NT) {
             const int row = g / gpr, gx = g - row * gpr;
             const uint4 px = stage_group<CN>(a, src, bx0a + 4 * gx, by0 + row);
-            *reinterpret_cast<uint4*>(&tile[row * bw + 4 * gx]) = px;
+            *reinterpret_cast<uint4*>(&tile[row * pitch + 4 * gx]) = px;
         }
     }
     __syncthreads();
 
-    // ---- 3. output: 4 consecutive pixels x 2 rows per lane (the LDS / direct choice is
-    // tile-uniform: two straight-line bodies, so all taps of a lane are in flight together)
-    if (use_lds) emit_rows<CN, true>(a, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw);
+    // ---- 3. output (the choice is tile-uniform)
+    if (CN == 3 && fast) emit_fast(a, dst, tile, obuf, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, -(by0 * FPITCH + bx0a));
+    else if (use_lds) emit_rows<CN, true>(a, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw);
     else emit_rows<CN, false>(a, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw);
 }
 
