@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-stages", action="store_true", help="time every stage (adds event records)")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph when available")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="batch mode: analysis stages of this many consecutive pushes run as one launch each (1 = per-frame pipeline)")
+    ap.add_argument("--warp-batch", type=int, default=8,
+                    help="deferred output: results of this many consecutive pushes are warped by one launch (1 = one launch per push)")
     args = ap.parse_args()
 
     comm = vsdist.Comm()           # nccl (= RCCL) when WORLD_SIZE > 1, nothing otherwise
@@ -124,8 +128,13 @@ def main():
         for i, f in enumerate(frames):
             buf.upload(f, i * fb)
         d_in.append(buf)
-    d_out = [capi.DevBuf(vs, fb) for _ in range(S)]
+    BT = max(1, min(16, args.batch))
+    WB = max(1, min(16, args.warp_batch if BT == 1 else BT))
+    d_out = [[capi.DevBuf(vs, fb) for _ in range(2 * WB)] for _ in range(S)]   # a result stays untouched for >= WB pushes
     stabs = [vs.stabilizer(make_params(vs), device=local_rank) for _ in range(S)]
+    for s in stabs:
+        s.set_batch(BT)
+        s.set_warp_batch(WB)
 
     preroll = 64   # past the 29-frame warm-up of smoothingRadius 30: every timed step produces a frame
     total = preroll + args.warmup + args.steps
@@ -133,7 +142,7 @@ def main():
 
     def step(i):
         for j in range(S):
-            stabs[j].push_dev(d_in[j].ptr + order[i] * fb, W, H, W * 3, capi.FMT_BGR8, d_out[j].ptr, W * 3)
+            stabs[j].push_dev(d_in[j].ptr + order[i] * fb, W, H, W * 3, capi.FMT_BGR8, d_out[j][i % (2 * WB)].ptr, W * 3)
 
     def sync_all():
         for s in stabs:
@@ -156,6 +165,7 @@ def main():
     sync_all()
     barrier()
     sync_all()
+    frames_before = sum(s.counters().frames_out for s in stabs)
     t0 = time.perf_counter()
     for i in range(preroll + args.warmup, total):
         step(i)
@@ -175,12 +185,14 @@ def main():
             stage_ms[k] += ms[k]
             stage_n[k] += n[k]
     frames_out = sum(s.counters().frames_out for s in stabs)
-    assert frames_out >= args.steps * S, "timed steps did not all produce frames"
+    frames_out_timed = frames_out - frames_before
+    assert frames_out_timed == args.steps * S, "timed steps did not all produce frames"
     # throughput counters of every rank (the only inter-GPU traffic of the path)
     per_rank = comm.gather_counters([rank, args.steps * S, frames_out])
 
     if rank == 0:
-        warp_bytes = 2.0 * fb                                    # algorithmic bytes per launch
+        frames_per_launch = frames_out_timed / max(stage_n[7], 1)   # WB when every launch is full
+        warp_bytes = 2.0 * fb * frames_per_launch                # algorithmic bytes per launch (2 x frame bytes per frame)
         warp_avg_ms = stage_ms[7] / max(stage_n[7], 1)
         achieved = warp_bytes / (warp_avg_ms * 1e-3) / 1e9 if warp_avg_ms > 0 else 0.0
         traffic = None
@@ -206,11 +218,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d stream(s)/GPU %dx%d BGR8, 200 corners, 3-level LK 21x21, "
                                    "RANSAC partial affine, warpAffine; frames resident in HBM" % (S, W, H),
-                       "streams_per_gpu": S, "graph": bool(args.graph),
+                       "streams_per_gpu": S, "graph": bool(args.graph), "batch": BT, "warp_batch": WB,
                        "timed_frames_per_rank": [int(r[1]) for r in per_rank]},
             "roofline": {"bound": "hbm", "kernel": "warp_affine_kernel<3>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "bytes_per_launch": warp_bytes,
+                         "frames_per_launch": round(frames_per_launch, 3),
                          "avg_launch_us": round(warp_avg_ms * 1e3, 3), "launches": stage_n[7]},
         }
         if args.profile_stages:

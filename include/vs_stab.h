@@ -208,6 +208,22 @@ void*       vs_stab_stream(vs_stab* s);    /* hipStream_t of the instance     */
 /* capture one steady-state push_dev into a hipGraph and replay it from then
  * on (two variants: with / without re-detection).  0 disables. */
 int vs_stab_enable_graph(vs_stab* s, int enable);
+/* Deferred output for vs_stab_push_dev / vs_stab_flush_dev (batch / file-to-file use): the
+ * warps of up to `frames` (1..16) consecutive results are issued as ONE kernel launch, each
+ * result into the d_out its push named.  Results are complete after vs_stab_sync(); with
+ * frames > 1 every push must be given its own d_out until then.  frames = 1 (default):
+ * every push issues its own warp.  The host entry points (vs_stab_push / vs_stab_flush)
+ * always deliver their result before returning. */
+int vs_stab_set_warp_batch(vs_stab* s, int frames);
+/* Batch mode for vs_stab_push_dev / vs_stab_flush_dev: the analysis of `frames` (1..16)
+ * consecutive pushes - goodFeaturesToTrack, calcOpticalFlowPyrLK and the RANSAC
+ * hypothesis scoring, all latency-bound on one frame - runs as ONE launch per stage over
+ * the whole group; the ordered part (hypothesis selection + trajectory append, smoothing)
+ * stays per frame, and the warps go out together as with vs_stab_set_warp_batch(frames).
+ * Results are bit-identical to frames = 1 and complete after vs_stab_sync(); every push must
+ * be given its own d_out until then.  Must be chosen before the first frame (or after
+ * vs_stab_clean).  NV12, border/crop modes and adaptive smoothing keep the per-frame path. */
+int vs_stab_set_batch(vs_stab* s, int frames);
 
 /* Per-stage device timing with HIP events recorded on the instance stream
  * (SURVEY.md section 5 "Tracing").  mode 0 = off, 1 = warp stage only,

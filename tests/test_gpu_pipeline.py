@@ -171,6 +171,98 @@ def test_device_resident_push_matches_host_push(gpu):
     s2.close()
 
 
+@pytest.mark.parametrize("batch", [2, 5, 16])
+def test_deferred_warp_batches_match_immediate_output(gpu, batch):
+    """vs_stab_set_warp_batch: the warps of `batch` consecutive results go out as one launch, each
+    into its own buffer; after sync they equal what one launch per push produces, flush included."""
+    n = 40
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 11, 320, 240, n)
+    p = gpu.params(smoothing_radius=7)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_warp_batch(batch)
+    fb = clip[0].nbytes
+    d_in = capi.DevBuf(gpu, fb * n)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, fb * (n + 8)), capi.DevBuf(gpu, fb * (n + 8))
+    k1 = k2 = 0
+    for i in range(n):
+        k1 += s1.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_ref.ptr + k1 * fb, 320 * 3)
+        k2 += s2.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr + k2 * fb, 320 * 3)
+    while s1.flush_dev(d_ref.ptr + k1 * fb, 320 * 3):
+        k1 += 1
+    while s2.flush_dev(d_got.ptr + k2 * fb, 320 * 3):
+        k2 += 1
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n
+    ref = d_ref.download((k1, 240, 320, 3), np.uint8)
+    got = d_got.download((k2, 240, 320, 3), np.uint8)
+    assert np.array_equal(ref, got)
+    assert s2.counters().frames_out == n
+    # a host push in between drains what is pending and still delivers synchronously
+    s3 = gpu.stabilizer(p)
+    s3.set_warp_batch(batch)
+    outs = []
+    for i in range(12):
+        if i % 3 == 2:
+            r = s3.push(clip[i])
+            if r is not None:
+                outs.append(r)
+        else:
+            if s3.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr + i * fb, 320 * 3):
+                s3.sync()
+                outs.append(d_got.download((240, 320, 3), np.uint8, offset=i * fb))
+    assert len(outs) == 6 and all(np.array_equal(outs[j], ref[j]) for j in range(6))
+    for s in (s1, s2, s3):
+        s.close()
+
+
+@pytest.mark.parametrize("batch,radius,n", [(2, 7, 30), (8, 7, 45), (16, 12, 61), (5, 30, 80)])
+def test_batch_mode_matches_per_frame_pipeline(gpu, batch, radius, n):
+    """vs_stab_set_batch: GFTT / LK / RANSAC scoring of `batch` frames per launch; outputs (flush included),
+    the last frame's debug record and the counters equal the per-frame pipeline's."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 21, 320, 240, 24)
+    order = [i % 24 if (i // 24) % 2 == 0 else 23 - i % 24 for i in range(n)]
+    p = gpu.params(smoothing_radius=radius, lk_win_size=21)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(batch)
+    fb = clip[0].nbytes
+    d_in = capi.DevBuf(gpu, fb * 24)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, fb * (n + 4)), capi.DevBuf(gpu, fb * (n + 4))
+    k1 = k2 = 0
+    for i in range(n):
+        k1 += s1.push_dev(d_in.ptr + order[i] * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_ref.ptr + k1 * fb, 320 * 3)
+        k2 += s2.push_dev(d_in.ptr + order[i] * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr + k2 * fb, 320 * 3)
+        assert k1 == k2
+    s1.sync(); s2.sync()
+    da, db = s1.debug(), s2.debug()
+    for name, _ in da._fields_:
+        va, vb = getattr(da, name), getattr(db, name)
+        assert (list(va) == list(vb)) if hasattr(va, "__len__") else (va == vb), name
+    while s1.flush_dev(d_ref.ptr + k1 * fb, 320 * 3):
+        k1 += 1
+    while s2.flush_dev(d_got.ptr + k2 * fb, 320 * 3):
+        k2 += 1
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n
+    ref = d_ref.download((k1, 240, 320, 3), np.uint8)
+    got = d_got.download((k2, 240, 320, 3), np.uint8)
+    assert np.array_equal(ref, got)
+    c1, c2 = s1.counters(), s2.counters()
+    assert (c1.frames_in, c1.frames_out, c1.detections) == (c2.frames_in, c2.frames_out, c2.detections)
+    # the host entry point still delivers synchronously in batch mode
+    s3 = gpu.stabilizer(p)
+    s3.set_batch(batch)
+    outs = [o for o in (s3.push(clip[order[i]]) for i in range(radius + 3)) if o is not None]
+    assert len(outs) == 4 and all(np.array_equal(outs[j], ref[j]) for j in range(4))
+    with pytest.raises(capi.VsError):
+        s3.set_batch(2)                      # only before the first frame
+    for s in (s1, s2, s3):
+        s.close()
+
+
 def test_errors_are_loud(gpu):
     with pytest.raises(capi.VsError):
         gpu.stabilizer(gpu.params(enable_virtual_canvas=1))

@@ -23,6 +23,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <cstring>
+
 #include "vs_common.h"
 
 namespace vsd {
@@ -48,9 +50,9 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __uint_as_float(b);
 }
 
-__global__ __launch_bounds__(NT) void min_eigen_kernel(const uint8_t* __restrict__ gray, size_t stride, int w,
-                                                       int h, int bs, float f1, float* __restrict__ eig,
-                                                       uint32_t* __restrict__ max_key) {
+__device__ __forceinline__ void min_eigen_tile(const uint8_t* __restrict__ gray, size_t stride, int w,
+                                               int h, int bs, float f1, float* __restrict__ eig,
+                                               uint32_t* __restrict__ max_key) {
     __shared__ uint8_t g[GH_MAX][GW_MAX + 2];
     __shared__ float cxx[CH_MAX][CW_MAX + 1], cxy[CH_MAX][CW_MAX + 1], cyy[CH_MAX][CW_MAX + 1];
     __shared__ uint32_t smax[NT / 64];
@@ -125,10 +127,16 @@ __global__ __launch_bounds__(NT) void min_eigen_kernel(const uint8_t* __restrict
     }
 }
 
-__global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ eig, int w, int h, double quality,
-                                                 const uint32_t* __restrict__ max_key,
-                                                 unsigned long long* __restrict__ cand, int cap,
-                                                 int32_t* __restrict__ counters) {
+__global__ __launch_bounds__(NT) void min_eigen_kernel(const uint8_t* __restrict__ gray, size_t stride, int w,
+                                                       int h, int bs, float f1, float* __restrict__ eig,
+                                                       uint32_t* __restrict__ max_key) {
+    min_eigen_tile(gray, stride, w, h, bs, f1, eig, max_key);
+}
+
+__device__ __forceinline__ void nms_row(const float* __restrict__ eig, int w, int h, double quality,
+                                        const uint32_t* __restrict__ max_key,
+                                        unsigned long long* __restrict__ cand, int cap,
+                                        int32_t* __restrict__ counters) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
@@ -152,6 +160,13 @@ __global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ eig, 
     else counters[2] = 1;
 }
 
+__global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ eig, int w, int h, double quality,
+                                                 const uint32_t* __restrict__ max_key,
+                                                 unsigned long long* __restrict__ cand, int cap,
+                                                 int32_t* __restrict__ counters) {
+    nms_row(eig, w, h, quality, max_key, cand, cap, counters);
+}
+
 struct SelArgs {
     const unsigned long long* cand;
     int32_t* counters;
@@ -163,7 +178,7 @@ struct SelArgs {
     int32_t* out_count;
 };
 
-__global__ __launch_bounds__(SEL_NT) void select_kernel(SelArgs a) {
+__device__ __forceinline__ void select_corners(const SelArgs& a) {
     __shared__ unsigned long long keys[SORT_CAP];
     __shared__ uint32_t cell_cnt[CELLS_MAX];
     __shared__ uint32_t cell_pts[CELLS_MAX * SLOTS];
@@ -360,7 +375,88 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(SelArgs a) {
     }
 }
 
+__global__ __launch_bounds__(SEL_NT) void select_kernel(SelArgs a) { select_corners(a); }
+
+// ---- several images per launch (blockIdx.z / blockIdx.x selects the image's block in a device table)
+struct GfttItem {
+    const uint8_t* gray;
+    size_t stride;
+    int w, h, bs;
+    float f1;
+    double quality;
+    float* eig;
+    int32_t* counters;
+    SelArgs sel;
+};
+
+__global__ __launch_bounds__(64) void gftt_zero_batch_kernel(const GfttItem* __restrict__ table) {
+    if (threadIdx.x < 16) table[blockIdx.x].counters[threadIdx.x] = 0;
+}
+__global__ __launch_bounds__(NT) void min_eigen_batch_kernel(const GfttItem* __restrict__ table) {
+    const GfttItem& it = table[blockIdx.z];
+    min_eigen_tile(it.gray, it.stride, it.w, it.h, it.bs, it.f1, it.eig, (uint32_t*)&it.counters[1]);
+}
+__global__ __launch_bounds__(NT) void nms_batch_kernel(const GfttItem* __restrict__ table) {
+    const GfttItem& it = table[blockIdx.z];
+    nms_row(it.eig, it.w, it.h, it.quality, (const uint32_t*)&it.counters[1], (unsigned long long*)it.sel.cand, it.sel.cap,
+            it.counters);
+}
+__global__ __launch_bounds__(SEL_NT) void select_batch_kernel(const GfttItem* __restrict__ table) {
+    select_corners(table[blockIdx.x].sel);
+}
+
+bool gftt_bad_args(const uint8_t* d_gray, const float* d_pts, const int32_t* d_count, int w, int h, int max_corners,
+                   int block_size, const GfttWork& wk) {
+    return !d_gray || !d_pts || !d_count || w < 3 || h < 3 || w > 65535 || h > 65535 || max_corners <= 0 ||
+           max_corners > ACC_MAX || block_size < 1 || block_size > MAX_BS || !wk.eig || !wk.cand || !wk.counters ||
+           wk.cap <= 0;
+}
+
+void fill_sel_args(SelArgs& a, int w, int h, int max_corners, double min_distance, const GfttWork& wk, float* d_pts,
+                   int32_t* d_count) {
+    a.cand = (const unsigned long long*)wk.cand;
+    a.counters = wk.counters;
+    a.cap = wk.cap; a.w = w; a.h = h; a.max_corners = max_corners;
+    a.use_dist = min_distance >= 1 ? 1 : 0;
+    a.min_dist2_i = (int)std::ceil(std::min(min_distance * min_distance, 2.0e9));
+    a.cell = a.use_dist ? (int)lrint(min_distance) : 1;
+    a.gw = (w + a.cell - 1) / a.cell;
+    a.gh = (h + a.cell - 1) / a.cell;
+    a.out_pts = d_pts; a.out_count = d_count;
+}
+
 }  // namespace
+
+size_t gftt_item_bytes() { return sizeof(GfttItem); }
+
+int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
+                   double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count) {
+    if (!host_item || gftt_bad_args(d_gray, d_pts, d_count, w, h, max_corners, block_size, wk)) {
+        set_last_error("gftt: invalid argument (1 <= blockSize <= 7, 0 < maxCorners <= 4096)");
+        return VS_ERR_INVALID_ARG;
+    }
+    GfttItem& it = *static_cast<GfttItem*>(host_item);
+    memset(&it, 0, sizeof it);
+    it.gray = d_gray; it.stride = stride; it.w = w; it.h = h; it.bs = block_size;
+    double scale = (double)(1 << 2) * block_size * 255.0;
+    it.f1 = (float)(1.0 / scale);
+    it.quality = quality;
+    it.eig = wk.eig; it.counters = wk.counters;
+    fill_sel_args(it.sel, w, h, max_corners, min_distance, wk, d_pts, d_count);
+    return VS_OK;
+}
+
+// items images of one size (w x h), one launch per stage
+int launch_gftt_batch(const void* d_table, int items, int w, int h, hipStream_t st) {
+    if (!d_table || items < 1 || items > 65535 || w < 3 || h < 3) { set_last_error("gftt_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
+    const GfttItem* t = static_cast<const GfttItem*>(d_table);
+    hipLaunchKernelGGL(gftt_zero_batch_kernel, dim3(items), dim3(64), 0, st, t);
+    hipLaunchKernelGGL(min_eigen_batch_kernel, dim3((w + TW - 1) / TW, (h + TH - 1) / TH, items), dim3(NT), 0, st, t);
+    hipLaunchKernelGGL(nms_batch_kernel, dim3((w + NT - 1) / NT, h, items), dim3(NT), 0, st, t);
+    hipLaunchKernelGGL(select_batch_kernel, dim3(items), dim3(SEL_NT), 0, st, t);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
 
 size_t gftt_work_bytes(int w, int h, int cap) {
     return (size_t)w * h * 4 + (size_t)cap * 8 + 64 + 256;
@@ -379,9 +475,7 @@ void gftt_work_carve(void* base, int w, int h, int cap, GfttWork* out) {
 int launch_gftt(const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
                 double min_distance, int block_size, const GfttWork& wk, float* d_pts,
                 int32_t* d_count, hipStream_t st) {
-    if (!d_gray || !d_pts || !d_count || w < 3 || h < 3 || w > 65535 || h > 65535 || max_corners <= 0 ||
-        max_corners > ACC_MAX || block_size < 1 || block_size > MAX_BS || !wk.eig || !wk.cand ||
-        !wk.counters || wk.cap <= 0) {
+    if (gftt_bad_args(d_gray, d_pts, d_count, w, h, max_corners, block_size, wk)) {
         set_last_error("gftt: invalid argument (1 <= blockSize <= 7, 0 < maxCorners <= 4096)");
         return VS_ERR_INVALID_ARG;
     }
@@ -396,15 +490,7 @@ int launch_gftt(const uint8_t* d_gray, size_t stride, int w, int h, int max_corn
     hipLaunchKernelGGL(nms_kernel, g2, dim3(NT), 0, st, wk.eig, w, h, quality, (const uint32_t*)&wk.counters[1],
                        (unsigned long long*)wk.cand, wk.cap, wk.counters);
     SelArgs a;
-    a.cand = (const unsigned long long*)wk.cand;
-    a.counters = wk.counters;
-    a.cap = wk.cap; a.w = w; a.h = h; a.max_corners = max_corners;
-    a.use_dist = min_distance >= 1 ? 1 : 0;
-    a.min_dist2_i = (int)std::ceil(std::min(min_distance * min_distance, 2.0e9));
-    a.cell = a.use_dist ? (int)lrint(min_distance) : 1;
-    a.gw = (w + a.cell - 1) / a.cell;
-    a.gh = (h + a.cell - 1) / a.cell;
-    a.out_pts = d_pts; a.out_count = d_count;
+    fill_sel_args(a, w, h, max_corners, min_distance, wk, d_pts, d_count);
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_NT), 0, st, a);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;

@@ -115,14 +115,13 @@ __device__ __forceinline__ void divmod_small(int i, int d, float inv_d, int& q, 
 }
 
 template <int NPX>
-__global__ __launch_bounds__(64) void lk_kernel(LKArgs a) {
+__device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
     // Per level everything the wave will touch is staged into LDS with ONE round of
     // global loads: the template patch of the previous image, its derivative patch,
     // and the search region of the next image (pyramid padding already applied).
     __shared__ uint8_t pI[LK_PW_MAX * LK_PW_MAX];
     __shared__ short2 pD[LK_PW_MAX * LK_PW_MAX];
     __shared__ uint8_t region[LK_REG_MAX * LK_REG_MAX];
-    const int pt = blockIdx.x;
     const int lane = threadIdx.x;
     int n = a.n;
     if (a.d_n) { int dn = *a.d_n; n = dn < n ? dn : n; }
@@ -323,18 +322,22 @@ __global__ __launch_bounds__(64) void lk_kernel(LKArgs a) {
     }
 }
 
-}  // namespace
+template <int NPX>
+__global__ __launch_bounds__(64) void lk_kernel(LKArgs a) { lk_track<NPX>(a, blockIdx.x); }
 
-int launch_pyr_lk(const LKLevel* levels, int max_level, const float* d_prev_pts, int n,
-                  const int32_t* d_n, float* d_next_pts, uint8_t* d_status, float* d_err, int win,
-                  int max_iters, double eps, hipStream_t st) {
+// Several frames per launch: blockIdx.y selects the frame's argument block in a device table.
+template <int NPX>
+__global__ __launch_bounds__(64) void lk_batch_kernel(const LKArgs* __restrict__ table) {
+    lk_track<NPX>(table[blockIdx.y], blockIdx.x);
+}
+
+int fill_lk_args(LKArgs& a, const LKLevel* levels, int max_level, const float* d_prev_pts, int n, const int32_t* d_n,
+                 float* d_next_pts, uint8_t* d_status, float* d_err, int win, int max_iters, double eps) {
     if (!levels || max_level < 0 || max_level >= MAX_LEVELS || n < 0 || win < 3 || win > 31 ||
         !d_prev_pts || !d_next_pts || !d_status || !d_err) {
         set_last_error("pyr_lk: invalid argument (3 <= win <= 31, max_level < 8)");
         return VS_ERR_INVALID_ARG;
     }
-    if (n == 0) return VS_OK;
-    LKArgs a;
     for (int i = 0; i <= max_level; i++) a.levels[i] = levels[i];
     for (int i = max_level + 1; i < MAX_LEVELS; i++) a.levels[i] = levels[max_level];
     a.max_level = max_level;
@@ -344,6 +347,44 @@ int launch_pyr_lk(const LKLevel* levels, int max_level, const float* d_prev_pts,
     a.max_count = max_iters < 0 ? 0 : (max_iters > 100 ? 100 : max_iters);
     double e = eps < 0 ? 0. : (eps > 10. ? 10. : eps);
     a.eps2 = e * e;
+    return VS_OK;
+}
+
+}  // namespace
+
+// ---- batched form: one argument block per frame in a device table (see stabilizer.cpp) ----
+size_t lk_item_bytes() { return sizeof(LKArgs); }
+
+int lk_fill_item(void* host_item, const LKLevel* levels, int max_level, const float* d_prev_pts, int n,
+                 const int32_t* d_n, float* d_next_pts, uint8_t* d_status, float* d_err, int win, int max_iters,
+                 double eps) {
+    return fill_lk_args(*static_cast<LKArgs*>(host_item), levels, max_level, d_prev_pts, n, d_n, d_next_pts, d_status,
+                        d_err, win, max_iters, eps);
+}
+
+// items frames, at most n_max points each, all with the same window
+int launch_pyr_lk_batch(const void* d_table, int items, int n_max, int win, hipStream_t st) {
+    if (!d_table || items < 1 || items > 65535 || n_max < 0 || win < 3 || win > 31) {
+        set_last_error("pyr_lk_batch: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    if (n_max == 0) return VS_OK;
+    const LKArgs* t = static_cast<const LKArgs*>(d_table);
+    const int npx = (win * win + 63) / 64;
+    dim3 grid(n_max, items), block(64);
+    if (npx <= 4) hipLaunchKernelGGL(lk_batch_kernel<4>, grid, block, 0, st, t);
+    else if (npx <= 7) hipLaunchKernelGGL(lk_batch_kernel<7>, grid, block, 0, st, t);
+    else hipLaunchKernelGGL(lk_batch_kernel<16>, grid, block, 0, st, t);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_pyr_lk(const LKLevel* levels, int max_level, const float* d_prev_pts, int n,
+                  const int32_t* d_n, float* d_next_pts, uint8_t* d_status, float* d_err, int win,
+                  int max_iters, double eps, hipStream_t st) {
+    LKArgs a;
+    VS_TRY(fill_lk_args(a, levels, max_level, d_prev_pts, n, d_n, d_next_pts, d_status, d_err, win, max_iters, eps));
+    if (n == 0) return VS_OK;
     const int npx = (win * win + 63) / 64;
     dim3 grid(n), block(64);
     if (npx <= 4) hipLaunchKernelGGL(lk_kernel<4>, grid, block, 0, st, a);

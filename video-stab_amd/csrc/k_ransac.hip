@@ -207,11 +207,11 @@ __device__ __forceinline__ int compact_to_lds(const RansacArgs& a, int n, float2
     return m;
 }
 
-__global__ __launch_bounds__(64) void ransac_score_kernel(RansacArgs a) {
+__device__ __forceinline__ void ransac_score(const RansacArgs& a, const int k) {
     extern __shared__ float2 s_pts[];          // [2][a.n]: compacted from / to
     float2* sf = s_pts;
     float2* st = s_pts + a.n;
-    const int k = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const int n = device_count(a);
     const int m = compact_to_lds(a, n, sf, st, lane);
     __syncthreads();
@@ -237,6 +237,13 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(RansacArgs a) {
         good += __popcll(__ballot(in));
     }
     if (lane == 0) a.counts[k] = good;
+}
+
+__global__ __launch_bounds__(64) void ransac_score_kernel(RansacArgs a) { ransac_score(a, blockIdx.x); }
+
+// Several frames per launch: blockIdx.y selects the frame's argument block in a device table.
+__global__ __launch_bounds__(64) void ransac_score_batch_kernel(const RansacArgs* __restrict__ table) {
+    ransac_score(table[blockIdx.y], blockIdx.x);
 }
 
 __device__ __forceinline__ double wave_butterfly_sum(double v) {
@@ -353,6 +360,65 @@ __global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) {
 
 }  // namespace
 
+static void fill_ransac_args(RansacArgs& a, const float* d_from, const float* d_to, const uint8_t* d_status, int n,
+                             const int32_t* d_n, float* d_vp, float* d_vc, int32_t* d_m, int min_points, double thr,
+                             int iters, const RansacTables* tab, int32_t* d_counts, double* d_model, uint8_t* d_inliers,
+                             int32_t* d_info, TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg,
+                             int have_prev_gray) {
+    memset(&a, 0, sizeof a);
+    a.from = d_from; a.to = d_to; a.status = d_status; a.n = n; a.d_n = d_n;
+    a.vp = d_vp; a.vc = d_vc; a.d_m = d_m; a.min_points = min_points;
+    a.t = (float)(thr * thr);
+    a.iters = iters; a.pairs = tab->d_pairs; a.update = tab->d_update; a.table_max_m = tab->max_m;
+    a.counts = d_counts; a.model = d_model; a.inliers = d_inliers; a.info = d_info;
+    a.traj = traj; a.dbg = dbg; a.have_prev_gray = have_prev_gray;
+    if (tp) a.tp = *tp;
+}
+
+static bool bad_ransac_args(const float* d_from, const float* d_to, const uint8_t* d_status, int n, float* d_vp, float* d_vc,
+                            int32_t* d_m, int iters, const RansacTables* tab, int32_t* d_counts, double* d_model,
+                            uint8_t* d_inliers, int32_t* d_info, TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg) {
+    return !d_from || !d_to || n < 0 || n > MAX_PTS || !tab || !d_counts || !d_model || !d_inliers || !d_info ||
+           iters != tab->iters || n > tab->max_m || (d_status && (!d_vp || !d_vc || !d_m)) || (traj && (!tp || !dbg));
+}
+
+// ---- batched form (see stabilizer.cpp): the hypotheses of several frames are scored by one launch from a
+// device table of argument blocks; the selection (and the fused trajectory append, which is ordered) is then
+// launched per frame from the host copy of its block.
+size_t ransac_item_bytes() { return sizeof(RansacArgs); }
+
+int ransac_fill_item(void* host_item, const float* d_from, const float* d_to, const uint8_t* d_status, int n,
+                     const int32_t* d_n, float* d_vp, float* d_vc, int32_t* d_m, int min_points, double thr, int iters,
+                     const RansacTables* tab, int32_t* d_counts, double* d_model, uint8_t* d_inliers, int32_t* d_info,
+                     TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg, int have_prev_gray) {
+    if (!host_item || bad_ransac_args(d_from, d_to, d_status, n, d_vp, d_vc, d_m, iters, tab, d_counts, d_model, d_inliers,
+                                      d_info, traj, tp, dbg)) {
+        set_last_error("ransac: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    fill_ransac_args(*static_cast<RansacArgs*>(host_item), d_from, d_to, d_status, n, d_n, d_vp, d_vc, d_m, min_points, thr,
+                     iters, tab, d_counts, d_model, d_inliers, d_info, traj, tp, dbg, have_prev_gray);
+    return VS_OK;
+}
+
+int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_max, hipStream_t st) {
+    if (!d_table || items < 1 || items > 65535 || iters < 1 || n_max < 0 || n_max > MAX_PTS) {
+        set_last_error("ransac_score_batch: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    hipLaunchKernelGGL(ransac_score_batch_kernel, dim3(iters, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
+                       static_cast<const RansacArgs*>(d_table));
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_ransac_select_item(const void* host_item, hipStream_t st) {
+    if (!host_item) return VS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, st, *static_cast<const RansacArgs*>(host_item));
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
 // counts: device scratch of `iters` int32.  d_n (optional) = device count.
 // status != nullptr: (d_from,d_to,status) are the raw LK arrays; vp/vc/d_m receive
 // the compacted pairs.  traj != nullptr: the measured transform is appended too.
@@ -367,14 +433,8 @@ int launch_ransac(const float* d_from, const float* d_to, const uint8_t* d_statu
         return VS_ERR_INVALID_ARG;
     }
     RansacArgs a;
-    memset(&a, 0, sizeof a);
-    a.from = d_from; a.to = d_to; a.status = d_status; a.n = n; a.d_n = d_n;
-    a.vp = d_vp; a.vc = d_vc; a.d_m = d_m; a.min_points = min_points;
-    a.t = (float)(thr * thr);
-    a.iters = iters; a.pairs = tab->d_pairs; a.update = tab->d_update; a.table_max_m = tab->max_m;
-    a.counts = d_counts; a.model = d_model; a.inliers = d_inliers; a.info = d_info;
-    a.traj = traj; a.dbg = dbg; a.have_prev_gray = have_prev_gray;
-    if (tp) a.tp = *tp;
+    fill_ransac_args(a, d_from, d_to, d_status, n, d_n, d_vp, d_vc, d_m, min_points, thr, iters, tab, d_counts, d_model,
+                     d_inliers, d_info, traj, tp, dbg, have_prev_gray);
     if (n > 2 || d_status)
         hipLaunchKernelGGL(ransac_score_kernel, dim3(iters), dim3(64), (size_t)(n > 0 ? n : 1) * 16, st, a);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, st, a);

@@ -53,9 +53,13 @@ struct WarpArgs {
     size_t sstride, sframe, dstride, dframe;
     int sw, sh, dw, dh;
     int src_aligned, dst_aligned;
-    const double* Minv_dev;      // batch*6 doubles on the device (inverse maps), or nullptr
+    const double* Minv_dev;      // inverse maps on the device (minv_stride doubles apart), or nullptr
     double Minv_val[MAXB * 6];   // used when Minv_dev == nullptr
     int border;                  // VS_BORDER_BLACK (constant 0) or VS_BORDER_REPLICATE
+    int minv_stride;             // doubles between the maps of consecutive frames in Minv_dev
+    int use_list;                // frames given one by one (srcs/dsts) instead of base + k*frame
+    const uint8_t* srcs[MAXB];
+    uint8_t* dsts[MAXB];
 };
 
 // One source pixel as a dword; outside the image: 0 (BORDER_CONSTANT) or the nearest
@@ -308,12 +312,12 @@ __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t obuf[OBUF];
     __shared__ int s_ad[TW], s_bd[TW], s_x0[TH], s_y0[TH];
     const int bz = blockIdx.z;
-    const uint8_t* __restrict__ src = a.src + (size_t)bz * a.sframe;
-    uint8_t* __restrict__ dst = a.dst + (size_t)bz * a.dframe;
+    const uint8_t* __restrict__ src = a.use_list ? a.srcs[bz] : a.src + (size_t)bz * a.sframe;
+    uint8_t* __restrict__ dst = a.use_list ? a.dsts[bz] : a.dst + (size_t)bz * a.dframe;
     double m[6];   // inverse map of this frame (wave-uniform, scalar loads)
     if (a.Minv_dev) {
         const __attribute__((address_space(4))) double* mp =
-            (const __attribute__((address_space(4))) double*)(a.Minv_dev + 6 * bz);
+            (const __attribute__((address_space(4))) double*)(a.Minv_dev + a.minv_stride * bz);
 #pragma unroll
         for (int i = 0; i < 6; i++) m[i] = mp[i];
     } else {
@@ -413,6 +417,9 @@ void fill_common(WarpArgs& a, const uint8_t* d_src, size_t sstride, size_t sfram
     a.sstride = sstride; a.sframe = sframe; a.dstride = dstride; a.dframe = dframe;
     a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;
     a.border = VS_BORDER_BLACK;
+    a.minv_stride = 6;
+    a.use_list = 0;
+    for (int i = 0; i < MAXB; i++) { a.srcs[i] = nullptr; a.dsts[i] = nullptr; }
     const int galign = cn == 2 ? 8 : 4;
     a.src_aligned = ((uintptr_t)d_src % galign == 0) && (sstride % galign == 0) && (sframe % galign == 0);
     a.dst_aligned = ((uintptr_t)d_dst % galign == 0) && (dstride % galign == 0) && (dframe % galign == 0);
@@ -438,6 +445,34 @@ int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int 
     fill_common(a, d_src, sstride, sframe, sw, sh, d_dst, dstride, dframe, dw, dh, cn);
     a.Minv_dev = d_Minv;
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, batch);
+    if (cn == 3) launch_one<3>(a, grid, st);
+    else if (cn == 1) launch_one<1>(a, grid, st);
+    else launch_one<2>(a, grid, st);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// Frames given one by one (deferred output of a stream: each result goes to its caller's buffer);
+// all share one geometry.  d_Minv: inverse maps on the device, minv_stride doubles apart.
+int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
+                            size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, hipStream_t st) {
+    if (n < 1 || n > MAXB || !srcs || !dsts || bad_args(srcs[0], dsts[0], d_Minv, sstride, sw, sh, dstride, dw, dh, cn, n)) {
+        set_last_error("warp_affine_list: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    WarpArgs a;
+    fill_common(a, srcs[0], sstride, 0, sw, sh, dsts[0], dstride, 0, dw, dh, cn);
+    const int galign = cn == 2 ? 8 : 4;
+    for (int i = 0; i < MAXB; i++) {
+        a.srcs[i] = srcs[i < n ? i : 0]; a.dsts[i] = dsts[i < n ? i : 0];
+        if (!a.srcs[i] || !a.dsts[i]) { set_last_error("warp_affine_list: null frame"); return VS_ERR_INVALID_ARG; }
+        if ((uintptr_t)a.srcs[i] % galign) a.src_aligned = 0;
+        if ((uintptr_t)a.dsts[i] % galign) a.dst_aligned = 0;
+    }
+    a.use_list = 1;
+    a.Minv_dev = d_Minv;
+    a.minv_stride = minv_stride;
+    dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, n);
     if (cn == 3) launch_one<3>(a, grid, st);
     else if (cn == 1) launch_one<1>(a, grid, st);
     else launch_one<2>(a, grid, st);

@@ -19,6 +19,7 @@
 // triple-buffered and the frame ring has spare slots so that `pre` of the next
 // frame never waits for `main` of the current one.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <deque>
 #include <new>
@@ -36,6 +37,22 @@ int launch_ransac(const float* d_from, const float* d_to, const uint8_t* d_statu
                   const RansacTables* tab, int32_t* d_counts, double* d_model, uint8_t* d_inliers,
                   int32_t* d_info, TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg,
                   int have_prev_gray, hipStream_t st);
+size_t lk_item_bytes();
+int lk_fill_item(void* host_item, const LKLevel* levels, int max_level, const float* d_prev_pts, int n,
+                 const int32_t* d_n, float* d_next_pts, uint8_t* d_status, float* d_err, int win, int max_iters,
+                 double eps);
+int launch_pyr_lk_batch(const void* d_table, int items, int n_max, int win, hipStream_t st);
+size_t ransac_item_bytes();
+int ransac_fill_item(void* host_item, const float* d_from, const float* d_to, const uint8_t* d_status, int n,
+                     const int32_t* d_n, float* d_vp, float* d_vc, int32_t* d_m, int min_points, double thr, int iters,
+                     const RansacTables* tab, int32_t* d_counts, double* d_model, uint8_t* d_inliers, int32_t* d_info,
+                     TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg, int have_prev_gray);
+int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_max, hipStream_t st);
+int launch_ransac_select_item(const void* host_item, hipStream_t st);
+size_t gftt_item_bytes();
+int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
+                   double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
+int launch_gftt_batch(const void* d_table, int items, int w, int h, hipStream_t st);
 int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
                      hipStream_t st);
 int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st);
@@ -44,10 +61,12 @@ int launch_make_border(const uint8_t* src, size_t sstride, int w, int h, int cn,
 int launch_resize_linear(const uint8_t* d_src, size_t sstride, int sw, int sh, int cn, uint8_t* d_dst,
                          size_t dstride, int dw, int dh, hipStream_t st);
 
-constexpr int FRAME_RING = 40;      // <= 35 queued frames (clamp(smoothingRadius,5,35)) + slack so that a
+constexpr int FRAME_RING = 96;      // <= 35 queued frames (clamp(smoothingRadius,5,35)) + slack so that a
                                     // slot is reused several frames after the warp that released it
 constexpr int MAX_PYR = 8;
 constexpr int NPYR = 3;             // pyramid buffers: frame k writes k%3 while LK(k-1) still reads (k-1)%3,(k-2)%3
+constexpr int WARP_BATCH_MAX = 16;   // = the warp kernel's frames per launch (k_warp.hip MAXB)
+constexpr int BATCH_MAX = 16;        // frames analysed per launch in batch mode (vs_stab_set_batch)
 constexpr int EVR = 4;              // per-frame event ring
 
 struct Pyramid {
@@ -65,6 +84,7 @@ struct vs_stab {
     hipStream_t st = nullptr;       // main
     hipStream_t st_pre = nullptr;
     hipStream_t st_det = nullptr;
+    hipStream_t st_warp = nullptr;  // deferred (batched) warps, high priority
     std::string err;
     // geometry, fixed by the first frame
     bool allocated = false;
@@ -87,14 +107,16 @@ struct vs_stab {
     int host_radius = 30;
     // analysis images
     uint8_t* d_first_gray = nullptr;     // 480x270 (Stabilizer.cpp:277)
-    Pyramid pyr[NPYR];
+    std::vector<Pyramid> pyr;           // ring: NPYR buffers, 2*batch+2 in batch mode
+    int npyr = NPYR;
     bool prev_small = false;
     bool have_prev_gray = false;
     // keypoints (ping-pong: LK reads pts[pp], a re-detection writes pts[pp^1])
     int ncap = 0;
-    float* d_pts[2] = {nullptr, nullptr};
-    int32_t* d_npts[2] = {nullptr, nullptr};
-    int pts_cap[2] = {0, 0};
+    // keypoint buffers: [0],[1] ping-pong per frame; batch mode cycles through all of them
+    std::vector<float*> d_pts;
+    std::vector<int32_t*> d_npts;
+    std::vector<int> pts_cap;
     int pp = 0;
     int last_lk_pp = 0;
     float *d_next = nullptr, *d_err = nullptr, *d_vp = nullptr, *d_vc = nullptr;
@@ -128,6 +150,44 @@ struct vs_stab {
     bool slot_valid[FRAME_RING] = {};
     hipEvent_t pts_event[2] = {nullptr, nullptr};   // recorded by the detection that filled pts[i]
     bool pts_pending[2] = {false, false};
+    // deferred output (vs_stab_set_warp_batch): warps of consecutive outputs wait for each other and
+    // go out as ONE launch over up to WARP_BATCH_MAX frames, each into its caller's buffer
+    int warp_batch = 1;
+    struct PendWarp { const uint8_t* src; uint8_t* dst; int slot; };
+    std::vector<PendWarp> pend;
+    size_t pend_stride = 0;
+    double* d_MinvB[2] = {nullptr, nullptr};   // inverse maps of the pending frames, 12 doubles each; two sets
+    int pend_set = 0;
+    hipEvent_t ev_emit = nullptr, ev_warp[2] = {nullptr, nullptr};
+    bool warp_valid[2] = {false, false};
+    // batch mode (vs_stab_set_batch): the latency-bound analysis stages (GFTT, LK, RANSAC scoring) of `batch`
+    // consecutive frames run as ONE launch each; the ordered tail (selection + trajectory append, emit) stays
+    // per frame; the warps go out through the deferred list above.
+    int batch = 1;
+    bool batch_active = false;
+    struct BFrame {
+        int f, c, pv;
+        bool detect; int det_buf;
+        int lk_buf, lk_cap;
+        bool out_due; int out_slot, out_idx; uint8_t* d_out; size_t out_stride;
+        int have_prev_gray;
+    };
+    std::vector<BFrame> bq;
+    int batch_id = 0;
+    int kp_cur = 0, kp_next = 1;
+    std::vector<GfttWork> gws;                       // one GFTT scratch per detection of a batch
+    struct ItemBufs { float *next, *err, *vp, *vc; uint8_t *status, *inliers; int32_t *m, *info, *counts; double* model; };
+    std::vector<ItemBufs> items;
+    std::vector<uint8_t> h_lk, h_rs, h_gf;           // host images of the argument tables
+    uint8_t *d_lk_table = nullptr, *d_rs_table = nullptr, *d_gf_table = nullptr;
+    hipEvent_t ev_bpre = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
+    bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
+    int last_det_batch = -1;
+    // what the debug getters read (last analysed frame)
+    const float* dbg_prev_pts = nullptr; const float* dbg_next = nullptr;
+    const uint8_t *dbg_status = nullptr, *dbg_inliers = nullptr;
+    const float* dbg_det_pts = nullptr; const int32_t* dbg_det_n = nullptr;
+    const int32_t* dbg_gftt_counters = nullptr;
     // stage profiling (HIP events on the stream the stage runs on)
     int prof_mode = 0;
     struct Pending { hipEvent_t a, b; int stage; };
@@ -188,8 +248,14 @@ void out_size(const vs_stab* s, int w, int h, int* ow, int* oh) {
     *ow = w; *oh = h;   // crop+zoom resizes back to origSize_ == frame size
 }
 
+int flush_warps(vs_stab* s);
+int run_batch(vs_stab* s);
+
 int sync_all(vs_stab* s) {
     S_HIP(s, hipSetDevice(s->device));
+    S_TRY(s, run_batch(s));
+    S_TRY(s, flush_warps(s));
+    if (s->st_warp) S_HIP(s, hipStreamSynchronize(s->st_warp));
     if (s->st_pre) S_HIP(s, hipStreamSynchronize(s->st_pre));
     if (s->st_det) S_HIP(s, hipStreamSynchronize(s->st_det));
     if (s->st) S_HIP(s, hipStreamSynchronize(s->st));
@@ -236,6 +302,15 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
             if (sw <= s->p.lk_win_size || sh <= s->p.lk_win_size) break;
         }
     }
+    s->batch_active = s->batch > 1 && fmt != VS_FMT_NV12 && s->p.border_size <= 0 && !s->p.adaptive_smoothing;
+    const int B = s->batch_active ? s->batch : 1;
+    s->npyr = s->batch_active ? 2 * B + 2 : NPYR;
+    const int nkp = s->batch_active ? B / 2 + 4 : 2, ngw = s->batch_active ? B / 2 + 1 : 1;
+    s->pyr.assign(s->npyr, Pyramid());
+    s->d_pts.assign(nkp, nullptr); s->d_npts.assign(nkp, nullptr); s->pts_cap.assign(nkp, 0);
+    s->items.assign(B, vs_stab::ItemBufs());
+    s->bq.clear(); s->batch_id = 0; s->kp_cur = 0; s->kp_next = 1; s->last_det_batch = -1;
+    for (auto& v : s->bdet_valid) v = false;
     S_HIP(s, hipMalloc((void**)&s->d_ring, s->frame_bytes * FRAME_RING));
     s->free_slots.clear();
     for (int i = 0; i < FRAME_RING; i++) { s->free_slots.push_back(i); s->slot_valid[i] = false; }
@@ -245,40 +320,63 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t o_first = take((size_t)480 * 270);
-    size_t o_img[NPYR][MAX_PYR], o_der[NPYR][MAX_PYR];
-    for (int k = 0; k < NPYR; k++)
+    std::vector<std::array<size_t, MAX_PYR>> o_img(s->npyr), o_der(s->npyr);
+    for (int k = 0; k < s->npyr; k++)
         for (int l = 0; l <= s->levels; l++) {
             o_img[k][l] = take((size_t)s->lw[l] * s->lh[l]);
             o_der[k][l] = take((size_t)s->lw[l] * s->lh[l] * 4);
         }
-    size_t o_pts[2] = {take((size_t)ncap * 8), take((size_t)ncap * 8)};
-    size_t o_npts[2] = {take(16), take(16)};
-    size_t o_next = take((size_t)ncap * 8), o_err = take((size_t)ncap * 4);
-    size_t o_vp = take((size_t)ncap * 8), o_vc = take((size_t)ncap * 8);
-    size_t o_status = take(ncap), o_inl = take(ncap);
-    size_t o_m = take(16), o_info = take(16), o_counts = take((size_t)s->p.ransac_max_iters * 4);
-    size_t o_model = take(48), o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
+    std::vector<size_t> o_pts(nkp), o_npts(nkp);
+    for (int k = 0; k < nkp; k++) { o_pts[k] = take((size_t)ncap * 8); o_npts[k] = take(16); }
+    struct ItemOff { size_t next, err, vp, vc, status, inl, m, info, counts, model; };
+    std::vector<ItemOff> o_it(B);
+    for (int k = 0; k < B; k++) {
+        o_it[k].next = take((size_t)ncap * 8); o_it[k].err = take((size_t)ncap * 4);
+        o_it[k].vp = take((size_t)ncap * 8); o_it[k].vc = take((size_t)ncap * 8);
+        o_it[k].status = take(ncap); o_it[k].inl = take(ncap);
+        o_it[k].m = take(16); o_it[k].info = take(16); o_it[k].counts = take((size_t)s->p.ransac_max_iters * 4);
+        o_it[k].model = take(48);
+    }
+    const size_t o_lkt = take(lk_item_bytes() * B), o_rst = take(ransac_item_bytes() * B), o_gft = take(gftt_item_bytes() * ngw);
+    size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
+    size_t o_MinvB[2] = {take((size_t)WARP_BATCH_MAX * 96), take((size_t)WARP_BATCH_MAX * 96)};
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
     S_HIP(s, hipMemsetAsync(s->d_all, 0, off, s->st));
     uint8_t* b = s->d_all;
     s->d_first_gray = b + o_first;
-    for (int k = 0; k < NPYR; k++)
+    for (int k = 0; k < s->npyr; k++)
         for (int l = 0; l <= s->levels; l++) {
             s->pyr[k].img[l] = b + o_img[k][l];
             s->pyr[k].der[l] = (int16_t*)(b + o_der[k][l]);
         }
-    for (int k = 0; k < 2; k++) { s->d_pts[k] = (float*)(b + o_pts[k]); s->d_npts[k] = (int32_t*)(b + o_npts[k]); }
-    s->d_next = (float*)(b + o_next); s->d_err = (float*)(b + o_err);
-    s->d_vp = (float*)(b + o_vp); s->d_vc = (float*)(b + o_vc);
-    s->d_status = b + o_status; s->d_inliers = b + o_inl;
-    s->d_m = (int32_t*)(b + o_m); s->d_info = (int32_t*)(b + o_info); s->d_counts = (int32_t*)(b + o_counts);
-    s->d_model = (double*)(b + o_model); s->d_traj = (TrajState*)(b + o_traj);
+    for (int k = 0; k < nkp; k++) { s->d_pts[k] = (float*)(b + o_pts[k]); s->d_npts[k] = (int32_t*)(b + o_npts[k]); }
+    for (int k = 0; k < B; k++) {
+        vs_stab::ItemBufs& it = s->items[k];
+        it.next = (float*)(b + o_it[k].next); it.err = (float*)(b + o_it[k].err);
+        it.vp = (float*)(b + o_it[k].vp); it.vc = (float*)(b + o_it[k].vc);
+        it.status = b + o_it[k].status; it.inliers = b + o_it[k].inl;
+        it.m = (int32_t*)(b + o_it[k].m); it.info = (int32_t*)(b + o_it[k].info); it.counts = (int32_t*)(b + o_it[k].counts);
+        it.model = (double*)(b + o_it[k].model);
+    }
+    // the per-frame path works on item 0
+    s->d_next = s->items[0].next; s->d_err = s->items[0].err; s->d_vp = s->items[0].vp; s->d_vc = s->items[0].vc;
+    s->d_status = s->items[0].status; s->d_inliers = s->items[0].inliers;
+    s->d_m = s->items[0].m; s->d_info = s->items[0].info; s->d_counts = s->items[0].counts; s->d_model = s->items[0].model;
+    s->d_lk_table = b + o_lkt; s->d_rs_table = b + o_rst; s->d_gf_table = b + o_gft;
+    s->h_lk.assign(lk_item_bytes() * B, 0); s->h_rs.assign(ransac_item_bytes() * B, 0); s->h_gf.assign(gftt_item_bytes() * ngw, 0);
+    s->d_traj = (TrajState*)(b + o_traj);
     s->d_M = (float*)(b + o_M); s->d_Minv = (double*)(b + o_Minv); s->d_dbg = (vs_debug_frame*)(b + o_dbg);
+    s->d_MinvB[0] = (double*)(b + o_MinvB[0]); s->d_MinvB[1] = (double*)(b + o_MinvB[1]);
+    s->pend.clear(); s->pend_set = 0; s->warp_valid[0] = s->warp_valid[1] = false;
     // GFTT scratch sized for the larger of the two detection images
     const int gmaxw = std::max(s->aw, 480), gmaxh = std::max(s->ah, 270);
     const int cap = gmaxw * gmaxh / 4 + 64;
-    S_HIP(s, hipMalloc(&s->d_gftt_scratch, gftt_work_bytes(gmaxw, gmaxh, cap)));
-    gftt_work_carve(s->d_gftt_scratch, gmaxw, gmaxh, cap, &s->gw);
+    const size_t gwb = (gftt_work_bytes(gmaxw, gmaxh, cap) + 255) & ~(size_t)255;
+    S_HIP(s, hipMalloc(&s->d_gftt_scratch, gwb * ngw));
+    s->gws.assign(ngw, GfttWork());
+    for (int k = 0; k < ngw; k++) gftt_work_carve((uint8_t*)s->d_gftt_scratch + gwb * k, gmaxw, gmaxh, cap, &s->gws[k]);
+    s->gw = s->gws[0];
+    s->dbg_gftt_counters = s->gw.counters;
     S_TRY(s, get_ransac_tables(ncap, s->p.ransac_max_iters, &s->tab));
     int ow, oh;
     out_size(s, w, h, &ow, &oh);
@@ -391,6 +489,7 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame, int f) {
         next_pp = q;
         s->last_detected = true;
         s->last_detect_pp = q;
+        s->dbg_det_pts = s->d_pts[q]; s->dbg_det_n = s->d_npts[q];
         s->counters.detections++;
     }
 
@@ -420,6 +519,7 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame, int f) {
                                s->d_m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab, s->d_counts, s->d_model,
                                s->d_inliers, s->d_info, s->d_traj, &s->tp, s->d_dbg, s->have_prev_gray ? 1 : 0, s->st));
     }
+    s->dbg_prev_pts = s->d_pts[pp]; s->dbg_next = s->d_next; s->dbg_status = s->d_status; s->dbg_inliers = s->d_inliers;
     s->n_transforms++;
     s->pp = next_pp;
     s->last_gray_buf = c;
@@ -427,21 +527,74 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame, int f) {
     return VS_OK;
 }
 
+// One launch for all pending warps, on the warp stream; releases their ring slots.
+int flush_warps(vs_stab* s) {
+    if (s->pend.empty()) return VS_OK;
+    const int n = (int)s->pend.size(), set = s->pend_set;
+    const uint8_t* srcs[WARP_BATCH_MAX];
+    uint8_t* dsts[WARP_BATCH_MAX];
+    for (int i = 0; i < n; i++) { srcs[i] = s->pend[i].src; dsts[i] = s->pend[i].dst; }
+    S_HIP(s, hipEventRecord(s->ev_emit, s->st));                 // the maps of this batch are written on `main`
+    S_HIP(s, hipStreamWaitEvent(s->st_warp, s->ev_emit, 0));
+    int rc;
+    {
+        StageScope t(s, VS_STAGE_WARP, s->st_warp);
+        rc = launch_warp_affine_list(srcs, dsts, n, s->row_bytes, s->w, s->h, s->pend_stride, s->w, s->h, s->cn,
+                                     s->d_MinvB[set], 12, s->st_warp);
+    }
+    if (hipEventRecord(s->ev_warp[set], s->st_warp) == hipSuccess) s->warp_valid[set] = true;
+    for (int i = 0; i < n; i++) {
+        const int slot = s->pend[i].slot;
+        if (hipEventRecord(s->ev_slot[slot], s->st_warp) == hipSuccess) s->slot_valid[slot] = true;
+        s->free_slots.push_back(slot);
+    }
+    s->pend.clear();
+    s->pend_set = set ^ 1;
+    if (rc != VS_OK) { s->err = get_last_error(); return rc; }
+    return VS_OK;
+}
+
+// Deferred output: only the map of output `idx` is computed now (on `main`, in trajectory order); its warp
+// joins the next batched launch.
+int defer_output(vs_stab* s, int idx, const uint8_t* frame, uint8_t* d_out, size_t out_stride, int slot) {
+    hipStream_t st = s->st;
+    if (!s->pend.empty() && s->pend_stride != out_stride) S_TRY(s, flush_warps(s));
+    const int set = s->pend_set, j = (int)s->pend.size();
+    if (j == 0 && s->warp_valid[set]) {      // the previous user of this set of maps must have read them
+        S_HIP(s, hipStreamWaitEvent(st, s->ev_warp[set], 0));
+        s->warp_valid[set] = false;
+    }
+    {
+        StageScope t(s, VS_STAGE_TRAJ, st);
+        S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_MinvB[set] + 12 * j, s->d_dbg, st));
+    }
+    s->pend.push_back({frame, d_out, slot});
+    s->pend_stride = out_stride;
+    if ((int)s->pend.size() >= s->warp_batch) S_TRY(s, flush_warps(s));
+    return VS_OK;
+}
+
 // applyNextSmoothTransform (Stabilizer.cpp:763-1137) into d_out (device), on `main`
-int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride) {
+int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
     const vs_params_c& p = s->p;
     const int slot = s->q_slot.front(), idx = s->q_idx.front();
     s->q_slot.pop_front(); s->q_idx.pop_front();
     const uint8_t* frame = s->d_ring + (size_t)slot * s->frame_bytes;
     hipStream_t st = s->st;
+    int ow, oh;
+    out_size(s, s->w, s->h, &ow, &oh);
+    s->last_out_w = ow; s->last_out_h = oh;
+    const bool plain = idx < s->n_transforms && s->fmt != VS_FMT_NV12 && p.border_size <= 0;
+    if (may_defer && plain && s->warp_batch > 1) {
+        S_TRY(s, defer_output(s, idx, frame, d_out, out_stride, slot));
+        s->counters.frames_out++;
+        return VS_OK;
+    }
     {
         StageScope t(s, VS_STAGE_TRAJ, st);
         S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_Minv, s->d_dbg, st));
     }
     int rc = VS_OK;
-    int ow, oh;
-    out_size(s, s->w, s->h, &ow, &oh);
-    s->last_out_w = ow; s->last_out_h = oh;
     if (idx >= s->n_transforms) {
         // Stabilizer.cpp:774-780: no transform exists for this frame (last frame of a
         // flush): the queued frame is returned as is, at its own size (no border pad).
@@ -482,6 +635,147 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride) {
     return VS_OK;
 }
 
+// ---- batch mode --------------------------------------------------------------------------------------
+// Frame f (>= 1) enters: its gray image and pyramid are built at once on `pre` (ring slot f % npyr); the
+// analysis is postponed until `batch` frames wait.  All host-side decisions of generateTransform that do not
+// depend on data (detection cadence :696, keypoint buffer hand-over, warm-up :383-387) are taken here, in
+// push order, so the device work is the same as in the per-frame path.
+int batch_enqueue(vs_stab* s, const uint8_t* frame, int slot, int f, uint8_t* d_out, size_t out_stride, int* produced) {
+    const vs_params_c& p = s->p;
+    const int N = s->npyr, c = f % N, pv = (f - 1) % N;
+    if (s->bq.empty() && s->batch_id >= 2) {
+        // ring reuse: slot c was read by the analysis two batches ago (npyr = 2*batch + 2)
+        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(s->batch_id - 2) % 4], 0));
+        if (s->bdet_valid[(s->batch_id - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(s->batch_id - 2) % 4], 0));
+    }
+    {
+        StageScope t(s, VS_STAGE_GRAY, s->st_pre);
+        S_TRY(s, launch_resize_gray(frame, s->row_bytes, s->w, s->h, s->fmt, s->pyr[c].img[0], s->aw, s->aw, s->ah, s->st_pre));
+    }
+    {
+        StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
+        S_TRY(s, build_pyramid(s, c, s->st_pre));
+        if (s->prev_small) {   // :598-603 (once: 480x270 -> analysis size)
+            S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[pv].img[0], s->aw, s->aw, s->ah, s->st_pre));
+            S_TRY(s, build_pyramid(s, pv, s->st_pre));
+            s->prev_small = false;
+        }
+    }
+    vs_stab::BFrame b;
+    memset(&b, 0, sizeof b);
+    b.f = f; b.c = c; b.pv = pv;
+    b.lk_buf = s->kp_cur; b.lk_cap = s->pts_cap[s->kp_cur];
+    b.have_prev_gray = s->have_prev_gray ? 1 : 0;
+    b.detect = (++s->detect_counter % 2) == 0;
+    if (b.detect) {
+        const int q = s->kp_next;
+        s->kp_next = (s->kp_next + 1) % (int)s->d_pts.size();
+        b.det_buf = q;
+        s->pts_cap[q] = std::min(p.max_corners, 200);
+        s->kp_cur = q;
+        s->counters.detections++;
+    }
+    s->n_transforms++;
+    s->have_prev_gray = true;
+    s->last_gray_buf = c;
+    s->q_slot.push_back(slot); s->q_idx.push_back(f);                                // :376-377
+    const int R = effective_radius(s->host_radius);                                  // :383
+    if ((int)s->q_idx.size() >= R) {                                                 // :384-389
+        b.out_due = true;
+        b.out_slot = s->q_slot.front(); b.out_idx = s->q_idx.front();
+        s->q_slot.pop_front(); s->q_idx.pop_front();
+        b.d_out = d_out; b.out_stride = out_stride;
+        out_size(s, s->w, s->h, &s->last_out_w, &s->last_out_h);
+        s->counters.frames_out++;
+        *produced = 1;
+    }
+    s->bq.push_back(b);
+    if ((int)s->bq.size() >= s->batch) S_TRY(s, run_batch(s));
+    return VS_OK;
+}
+
+int run_batch(vs_stab* s) {
+    const int n = (int)s->bq.size();
+    if (n == 0) return VS_OK;
+    const vs_params_c& p = s->p;
+    const int k = s->batch_id++;
+    S_HIP(s, hipEventRecord(s->ev_bpre, s->st_pre));
+    // ---- det: every frame of the batch that re-detects, one launch per GFTT stage
+    int ndet = 0;
+    for (int i = 0; i < n; i++) {
+        const vs_stab::BFrame& b = s->bq[i];
+        if (!b.detect) continue;
+        S_TRY(s, gftt_fill_item(s->h_gf.data() + gftt_item_bytes() * ndet, s->pyr[b.c].img[0], s->aw, s->aw, s->ah,
+                                s->pts_cap[b.det_buf], 0.02, 15.0, 3, s->gws[ndet], s->d_pts[b.det_buf], s->d_npts[b.det_buf]));
+        s->dbg_det_pts = s->d_pts[b.det_buf]; s->dbg_det_n = s->d_npts[b.det_buf];
+        s->dbg_gftt_counters = s->gws[ndet].counters;
+        ndet++;
+    }
+    s->last_detected = s->bq[n - 1].detect;
+    if (ndet > 0) {
+        S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_bpre, 0));
+        // keypoint buffers and GFTT scratch are recycled: the tracking of the previous batch must have read them
+        if (k >= 1) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 1) % 4], 0));
+        S_HIP(s, hipMemcpyAsync(s->d_gf_table, s->h_gf.data(), gftt_item_bytes() * ndet, hipMemcpyHostToDevice, s->st_det));
+        {
+            StageScope t(s, VS_STAGE_GFTT, s->st_det);
+            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, s->st_det));
+        }
+        S_HIP(s, hipEventRecord(s->ev_bdet[k % 4], s->st_det));
+        s->last_det_batch = k;
+    }
+    s->bdet_valid[k % 4] = ndet > 0;
+    // ---- main: tracking and hypothesis scoring of all frames, one launch each
+    hipStream_t st = s->st;
+    S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
+    if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
+    if (s->last_det_batch >= 0 && s->last_det_batch >= k - 1) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
+    int n_max = 0;
+    for (int i = 0; i < n; i++) {
+        const vs_stab::BFrame& b = s->bq[i];
+        const vs_stab::ItemBufs& it = s->items[i];
+        LKLevel L[MAX_PYR];
+        for (int l = 0; l <= s->levels; l++) {
+            L[l].prev = s->pyr[b.pv].img[l]; L[l].next = s->pyr[b.c].img[l]; L[l].deriv = s->pyr[b.pv].der[l];
+            L[l].w = s->lw[l]; L[l].h = s->lh[l]; L[l].stride = s->lw[l];
+        }
+        const int cap = std::max(b.lk_cap, 0);
+        n_max = std::max(n_max, cap);
+        S_TRY(s, lk_fill_item(s->h_lk.data() + lk_item_bytes() * i, L, s->levels, s->d_pts[b.lk_buf], cap, s->d_npts[b.lk_buf],
+                              it.next, it.status, it.err, p.lk_win_size, p.lk_max_iters, p.lk_epsilon));   // :611-619
+        S_TRY(s, ransac_fill_item(s->h_rs.data() + ransac_item_bytes() * i, s->d_pts[b.lk_buf], it.next, it.status, cap,
+                                  s->d_npts[b.lk_buf], it.vp, it.vc, it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab,
+                                  it.counts, it.model, it.inliers, it.info, s->d_traj, &s->tp, s->d_dbg, b.have_prev_gray));
+    }
+    S_HIP(s, hipMemcpyAsync(s->d_lk_table, s->h_lk.data(), lk_item_bytes() * n, hipMemcpyHostToDevice, st));
+    S_HIP(s, hipMemcpyAsync(s->d_rs_table, s->h_rs.data(), ransac_item_bytes() * n, hipMemcpyHostToDevice, st));
+    {
+        StageScope t(s, VS_STAGE_LK, st);
+        S_TRY(s, launch_pyr_lk_batch(s->d_lk_table, n, n_max, p.lk_win_size, st));
+    }
+    {
+        StageScope t(s, VS_STAGE_RANSAC, st);
+        S_TRY(s, launch_ransac_score_batch(s->d_rs_table, n, p.ransac_max_iters, n_max, st));
+    }
+    S_HIP(s, hipEventRecord(s->ev_blk[k % 4], st));
+    // ---- ordered tail, frame by frame: selection + trajectory append (:644-693), then the output that
+    // has become due (applyNextSmoothTransform sees exactly the transforms appended so far)
+    for (int i = 0; i < n; i++) {
+        const vs_stab::BFrame b = s->bq[i];
+        {
+            StageScope t(s, VS_STAGE_RANSAC, st);
+            S_TRY(s, launch_ransac_select_item(s->h_rs.data() + ransac_item_bytes() * i, st));
+        }
+        if (b.out_due)
+            S_TRY(s, defer_output(s, b.out_idx, s->d_ring + (size_t)b.out_slot * s->frame_bytes, b.d_out, b.out_stride, b.out_slot));
+    }
+    const vs_stab::BFrame& lb = s->bq[n - 1];
+    s->dbg_prev_pts = s->d_pts[lb.lk_buf]; s->dbg_next = s->items[n - 1].next;
+    s->dbg_status = s->items[n - 1].status; s->dbg_inliers = s->items[n - 1].inliers;
+    s->bq.clear();
+    return VS_OK;
+}
+
 int check_params(const vs_params_c* p, std::string* why) {
     if (!p || p->struct_size != (int32_t)sizeof(vs_params_c)) { *why = "params: struct_size mismatch"; return VS_ERR_INVALID_ARG; }
     if (p->enable_virtual_canvas) { *why = "enableVirtualCanvas is outside the accelerated path"; return VS_ERR_UNSUPPORTED; }
@@ -496,7 +790,7 @@ int check_params(const vs_params_c* p, std::string* why) {
 }
 
 // Shared body of stabilize(): the frame is already on its way into ring slot `slot` (on `pre`).
-int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* produced) {
+int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* produced, bool may_defer) {
     const vs_params_c& p = s->p;
     const uint8_t* frame = s->d_ring + (size_t)slot * s->frame_bytes;
     *produced = 0;
@@ -513,10 +807,17 @@ int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* pr
         s->pts_pending[0] = true;
         s->pp = 0; s->pts_cap[0] = p.max_corners;
         s->last_detected = true; s->last_detect_pp = 0;
+        s->dbg_det_pts = s->d_pts[0]; s->dbg_det_n = s->d_npts[0];
         s->counters.detections++;
         s->prev_small = true; s->have_prev_gray = true;
         s->q_slot.push_back(slot); s->q_idx.push_back(0);
         s->first = false; s->next_index = 1;
+        return VS_OK;
+    }
+    if (s->batch_active) {
+        S_TRY(s, batch_enqueue(s, frame, slot, s->next_index, d_out, out_stride, produced));
+        s->next_index++;
+        if (!may_defer) { S_TRY(s, run_batch(s)); S_TRY(s, flush_warps(s)); }
         return VS_OK;
     }
     s->q_slot.push_back(slot); s->q_idx.push_back(s->next_index);                   // :376-377
@@ -531,7 +832,7 @@ int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* pr
     }
     const int R = effective_radius(s->host_radius);                                 // :383
     if ((int)s->q_idx.size() < R) { s->next_index++; return VS_OK; }                // :384-387
-    S_TRY(s, apply_next(s, d_out, out_stride));                                     // :389
+    S_TRY(s, apply_next(s, d_out, out_stride, may_defer));                          // :389
     s->next_index++;
     *produced = 1;
     return VS_OK;
@@ -565,6 +866,10 @@ void destroy_events(vs_stab* s) {
     for (auto& e : s->ev_det) kill(e);
     for (auto& e : s->ev_slot) kill(e);
     kill(s->ev_first);
+    kill(s->ev_emit); kill(s->ev_warp[0]); kill(s->ev_warp[1]);
+    kill(s->ev_bpre);
+    for (auto& e : s->ev_bdet) kill(e);
+    for (auto& e : s->ev_blk) kill(e);
 }
 
 int create_events(vs_stab* s) {
@@ -575,6 +880,10 @@ int create_events(vs_stab* s) {
     for (auto& e : s->ev_det) S_HIP(s, mk(e));
     for (auto& e : s->ev_slot) S_HIP(s, mk(e));
     S_HIP(s, mk(s->ev_first));
+    S_HIP(s, mk(s->ev_emit)); S_HIP(s, mk(s->ev_warp[0])); S_HIP(s, mk(s->ev_warp[1]));
+    S_HIP(s, mk(s->ev_bpre));
+    for (auto& e : s->ev_bdet) S_HIP(s, mk(e));
+    for (auto& e : s->ev_blk) S_HIP(s, mk(e));
     return VS_OK;
 }
 
@@ -603,6 +912,11 @@ int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_pre, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_det, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(&s->st_warp, hipStreamNonBlocking, greatest);
+    }
     if (e != hipSuccess || create_events(s) != VS_OK) {
         set_last_error(e != hipSuccess ? hipGetErrorString(e) : s->err);
         vs_stab_destroy(s);
@@ -619,6 +933,7 @@ void vs_stab_destroy(vs_stab* s) {
     if (s->st_pre) (void)hipStreamSynchronize(s->st_pre);
     if (s->st_det) (void)hipStreamSynchronize(s->st_det);
     if (s->st) (void)hipStreamSynchronize(s->st);
+    if (s->st_warp) (void)hipStreamSynchronize(s->st_warp);
     free_all(s);
     for (auto& pe : s->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
@@ -626,6 +941,7 @@ void vs_stab_destroy(vs_stab* s) {
     if (s->st) (void)hipStreamDestroy(s->st);
     if (s->st_pre) (void)hipStreamDestroy(s->st_pre);
     if (s->st_det) (void)hipStreamDestroy(s->st_det);
+    if (s->st_warp) (void)hipStreamDestroy(s->st_warp);
     delete s;
 }
 
@@ -656,17 +972,22 @@ int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride
     int slot;
     S_TRY(s, take_slot(s, &slot));
     S_TRY(s, enqueue_copy_in(s, slot, d_data, stride, hipMemcpyDeviceToDevice));
-    return push_common(s, slot, (uint8_t*)d_out, out_stride, produced);
+    return push_common(s, slot, (uint8_t*)d_out, out_stride, produced, true);
 }
 
-int vs_stab_flush_dev(vs_stab* s, void* d_out, size_t out_stride, int* produced) {   // Stabilizer.cpp:394-400
+static int flush_dev_impl(vs_stab* s, void* d_out, size_t out_stride, int* produced, bool may_defer_flush) {
     if (!s || !produced) return VS_ERR_INVALID_ARG;
     *produced = 0;
     if (!s->allocated || s->q_slot.empty()) return VS_OK;
     S_HIP(s, hipSetDevice(s->device));
-    S_TRY(s, apply_next(s, (uint8_t*)d_out, out_stride));
+    S_TRY(s, run_batch(s));
+    S_TRY(s, apply_next(s, (uint8_t*)d_out, out_stride, may_defer_flush));
     *produced = 1;
     return VS_OK;
+}
+
+int vs_stab_flush_dev(vs_stab* s, void* d_out, size_t out_stride, int* produced) {   // Stabilizer.cpp:394-400
+    return flush_dev_impl(s, d_out, out_stride, produced, true);
 }
 
 int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, int fmt, uint8_t* out,
@@ -682,11 +1003,14 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
     int ow, oh;
     out_size(s, w, h, &ow, &oh);
     const size_t orow = (size_t)ow * s->cn;
-    rc = push_common(s, slot, s->d_out, orow, produced);
+    S_TRY(s, run_batch(s));
+    S_TRY(s, flush_warps(s));
+    rc = push_common(s, slot, s->d_out, orow, produced, false);
     if (rc != VS_OK) return rc;
     if (*produced) {
         if (!out || out_stride < orow) return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
         const int orows = fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh;
+        S_HIP(s, hipStreamSynchronize(s->st_warp));   // batch mode: the warp ran on the warp stream
         S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_out, orow, orow, orows, hipMemcpyDeviceToHost, s->st));
     }
     // the caller's frame must be consumed and its result delivered before returning
@@ -703,11 +1027,34 @@ int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced) {
     out_size(s, s->w, s->h, &ow, &oh);
     const size_t orow = (size_t)ow * s->cn;
     if (!out || out_stride < orow) return fail(s, VS_ERR_INVALID_ARG, "flush: output buffer/stride too small");
-    int rc = vs_stab_flush_dev(s, s->d_out, orow, produced);
+    S_TRY(s, run_batch(s));
+    S_TRY(s, flush_warps(s));
+    int rc = flush_dev_impl(s, s->d_out, orow, produced, false);
     if (rc != VS_OK) return rc;
     const int orows = s->fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh;
+    S_HIP(s, hipStreamSynchronize(s->st_warp));
     S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_out, orow, orow, orows, hipMemcpyDeviceToHost, s->st));
     S_HIP(s, hipStreamSynchronize(s->st));
+    return VS_OK;
+}
+
+// Deferred output for the device entry points: up to `frames` consecutive results are warped by one
+// launch.  A result is complete after vs_stab_sync(); every push must then be given its own d_out.
+int vs_stab_set_warp_batch(vs_stab* s, int frames) {
+    if (!s || frames < 1 || frames > WARP_BATCH_MAX) return VS_ERR_INVALID_ARG;
+    if (s->allocated) { S_HIP(s, hipSetDevice(s->device)); S_TRY(s, flush_warps(s)); }
+    s->warp_batch = frames;
+    return VS_OK;
+}
+
+// Batch mode for the device entry points: the analysis of `frames` consecutive pushes (feature detection,
+// tracking, hypothesis scoring) runs as one launch per stage, and their warps as one launch (implies
+// vs_stab_set_warp_batch(frames)).  To be chosen before the first frame (or after vs_stab_clean).
+int vs_stab_set_batch(vs_stab* s, int frames) {
+    if (!s || frames < 1 || frames > BATCH_MAX) return VS_ERR_INVALID_ARG;
+    if (s->allocated) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_batch: call before the first frame or after vs_stab_clean");
+    s->batch = frames;
+    if (frames > 1) s->warp_batch = frames;
     return VS_OK;
 }
 
@@ -724,7 +1071,7 @@ int vs_stab_get_counters(vs_stab* s, vs_counters* out) {
         vs_debug_frame d;
         int32_t c[4] = {0, 0, 0, 0};
         S_HIP(s, hipMemcpy(&d, s->d_dbg, sizeof d, hipMemcpyDeviceToHost));
-        S_HIP(s, hipMemcpy(c, s->gw.counters, sizeof c, hipMemcpyDeviceToHost));
+        S_HIP(s, hipMemcpy(c, s->dbg_gftt_counters, sizeof c, hipMemcpyDeviceToHost));
         out->last_features = d.n_prev;
         out->last_tracked = d.n_valid;
         out->last_inliers = d.n_inliers;
@@ -745,7 +1092,7 @@ int vs_stab_get_debug(vs_stab* s, vs_debug_frame* out) {
     out->n_detected = 0;
     if (s->last_detected) {
         int32_t n = 0;
-        S_HIP(s, hipMemcpy(&n, s->d_npts[s->last_detect_pp], sizeof n, hipMemcpyDeviceToHost));
+        S_HIP(s, hipMemcpy(&n, s->dbg_det_n, sizeof n, hipMemcpyDeviceToHost));
         out->n_detected = n;
     }
     if (s->counters.frames_in <= 1) { out->n_prev = 0; out->n_valid = 0; out->out_index = -1; }
@@ -761,13 +1108,13 @@ int vs_stab_get_debug_arrays(vs_stab* s, float* prev_pts, float* curr_pts, uint8
     if (!s->allocated) return VS_OK;
     const bool first_only = s->counters.frames_in <= 1;
     if (d.n_prev > 0 && !first_only) {
-        if (prev_pts) S_HIP(s, hipMemcpy(prev_pts, s->d_pts[s->last_lk_pp], (size_t)d.n_prev * 8, hipMemcpyDeviceToHost));
-        if (curr_pts) S_HIP(s, hipMemcpy(curr_pts, s->d_next, (size_t)d.n_prev * 8, hipMemcpyDeviceToHost));
-        if (status) S_HIP(s, hipMemcpy(status, s->d_status, (size_t)d.n_prev, hipMemcpyDeviceToHost));
+        if (prev_pts) S_HIP(s, hipMemcpy(prev_pts, s->dbg_prev_pts, (size_t)d.n_prev * 8, hipMemcpyDeviceToHost));
+        if (curr_pts) S_HIP(s, hipMemcpy(curr_pts, s->dbg_next, (size_t)d.n_prev * 8, hipMemcpyDeviceToHost));
+        if (status) S_HIP(s, hipMemcpy(status, s->dbg_status, (size_t)d.n_prev, hipMemcpyDeviceToHost));
     }
-    if (d.n_valid > 0 && inliers && !first_only) S_HIP(s, hipMemcpy(inliers, s->d_inliers, (size_t)d.n_valid, hipMemcpyDeviceToHost));
+    if (d.n_valid > 0 && inliers && !first_only) S_HIP(s, hipMemcpy(inliers, s->dbg_inliers, (size_t)d.n_valid, hipMemcpyDeviceToHost));
     if (d.n_detected > 0 && detected_pts)
-        S_HIP(s, hipMemcpy(detected_pts, s->d_pts[s->last_detect_pp], (size_t)d.n_detected * 8, hipMemcpyDeviceToHost));
+        S_HIP(s, hipMemcpy(detected_pts, s->dbg_det_pts, (size_t)d.n_detected * 8, hipMemcpyDeviceToHost));
     if (first_only) {
         if (gray) S_HIP(s, hipMemcpy(gray, s->d_first_gray, (size_t)480 * 270, hipMemcpyDeviceToHost));
         if (aw) *aw = 480;

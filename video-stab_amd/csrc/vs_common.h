@@ -78,6 +78,8 @@ inline void warp_invert(const float* Mf, double* inv) {
 int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                        uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
                        const double* d_Minv, int batch, hipStream_t st);
+int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
+                            size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, hipStream_t st);
 int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
                        uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st);
 int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst,

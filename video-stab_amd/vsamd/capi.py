@@ -150,6 +150,8 @@ class VsLib:
         L.vs_stab_stream.restype = vp
         L.vs_stab_stream.argtypes = [vp]
         L.vs_stab_enable_graph.argtypes = [vp, C.c_int]
+        L.vs_stab_set_warp_batch.argtypes = [vp, C.c_int]
+        L.vs_stab_set_batch.argtypes = [vp, C.c_int]
         L.vs_stab_set_profiling.argtypes = [vp, C.c_int]
         L.vs_stab_get_stage_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.vs_dev_set_device.argtypes = [C.c_int]
@@ -570,6 +572,12 @@ class Stabilizer:
 
     def clean(self):
         self.vs.check(self.lib.vs_stab_clean(self.h), self.h)
+
+    def set_batch(self, frames):
+        self.vs.check(self.lib.vs_stab_set_batch(self.h, int(frames)), self.h)
+
+    def set_warp_batch(self, frames):
+        self.vs.check(self.lib.vs_stab_set_warp_batch(self.h, int(frames)), self.h)
 
     def enable_graph(self, on=True):
         self.vs.check(self.lib.vs_stab_enable_graph(self.h, int(on)), self.h)
