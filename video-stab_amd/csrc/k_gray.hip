@@ -21,9 +21,13 @@ __device__ __forceinline__ uint32_t bgr_to_gray(uint32_t b, uint32_t g, uint32_t
 }
 
 // ---- exact 2x, BGR -> gray: 4 output pixels per lane --------------------------
-__global__ __launch_bounds__(NT) void half_bgr_gray_kernel(const uint8_t* __restrict__ src,
-                                                           size_t sstride, uint8_t* __restrict__ dst,
-                                                           size_t dstride, int dw, int dh, int vec_ok) {
+__global__ __launch_bounds__(NT) void half_bgr_gray_kernel(const uint8_t* __restrict__ src_,
+                                                           size_t sstride, uint8_t* __restrict__ dst_,
+                                                           size_t dstride, int dw, int dh, int vec_ok,
+                                                           const ImgPair* __restrict__ table) {
+    // batched launch: blockIdx.z selects the frame's (source, destination) pair
+    const uint8_t* __restrict__ src = table ? static_cast<const uint8_t*>(table[blockIdx.z].src) : src_;
+    uint8_t* __restrict__ dst = table ? static_cast<uint8_t*>(table[blockIdx.z].dst) : dst_;
     const int gx = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 output pixels
     const int y = blockIdx.y;
     const int x = gx * 4;
@@ -66,10 +70,12 @@ __global__ __launch_bounds__(NT) void half_bgr_gray_kernel(const uint8_t* __rest
 
 // ---- general bilinear (any scale), CN = 3 (-> gray) or 1 ----------------------
 template <int CN, bool TO_GRAY>
-__global__ __launch_bounds__(NT) void resize_gray_kernel(const uint8_t* __restrict__ src, size_t sstride,
-                                                         int sw, int sh, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(NT) void resize_gray_kernel(const uint8_t* __restrict__ src_, size_t sstride,
+                                                         int sw, int sh, uint8_t* __restrict__ dst_,
                                                          size_t dstride, int dw, int dh, double scale_x,
-                                                         double scale_y, int area2) {
+                                                         double scale_y, int area2, const ImgPair* __restrict__ table) {
+    const uint8_t* __restrict__ src = table ? static_cast<const uint8_t*>(table[blockIdx.z].src) : src_;
+    uint8_t* __restrict__ dst = table ? static_cast<uint8_t*>(table[blockIdx.z].dst) : dst_;
     const int dx = blockIdx.x * blockDim.x + threadIdx.x;
     const int dy = blockIdx.y;
     if (dx >= dw || dy >= dh) return;
@@ -122,6 +128,37 @@ __global__ __launch_bounds__(NT) void resize_gray_kernel(const uint8_t* __restri
 
 }  // namespace
 
+int launch_resize_gray_batch(const ImgPair* d_pairs, int items, size_t sstride, int sw, int sh, int fmt, size_t dstride,
+                             int dw, int dh, int aligned, hipStream_t st) {
+    if (!d_pairs || items < 1 || items > 65535 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || dh > 65535 ||
+        (fmt != VS_FMT_BGR8 && fmt != VS_FMT_GRAY8)) {
+        set_last_error("resize_gray_batch: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+    const int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y);
+    const bool area2 = std::abs(scale_x - isx) < DBL_EPSILON && std::abs(scale_y - isy) < DBL_EPSILON &&
+                       isx == 2 && isy == 2;
+    const uint8_t* np = nullptr;
+    uint8_t* nd = nullptr;
+    if (fmt == VS_FMT_BGR8 && area2) {
+        const int vec_ok = aligned && (sstride % 8 == 0) && (dstride % 4 == 0);
+        dim3 grid(((dw + 3) / 4 + NT - 1) / NT, dh, items);
+        hipLaunchKernelGGL(half_bgr_gray_kernel, grid, dim3(NT), 0, st, np, sstride, nd, dstride, dw, dh, vec_ok, d_pairs);
+    } else {
+        dim3 grid((dw + NT - 1) / NT, dh, items);
+        if (fmt == VS_FMT_BGR8)
+            hipLaunchKernelGGL((resize_gray_kernel<3, true>), grid, dim3(NT), 0, st, np, sstride, sw, sh, nd, dstride, dw, dh,
+                               scale_x, scale_y, area2 ? 1 : 0, d_pairs);
+        else
+            hipLaunchKernelGGL((resize_gray_kernel<1, true>), grid, dim3(NT), 0, st, np, sstride, sw, sh, nd, dstride, dw, dh,
+                               scale_x, scale_y, area2 ? 1 : 0, d_pairs);
+    }
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
 int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
                        uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st) {
     if (!d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || dh > 65535 ||
@@ -140,15 +177,15 @@ int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int
         const int vec_ok = ((uintptr_t)d_src % 8 == 0) && (sstride % 8 == 0) && ((uintptr_t)d_dst % 4 == 0) &&
                            (dstride % 4 == 0);
         dim3 grid(((dw + 3) / 4 + NT - 1) / NT, dh);
-        hipLaunchKernelGGL(half_bgr_gray_kernel, grid, dim3(NT), 0, st, d_src, sstride, d_dst, dstride, dw, dh, vec_ok);
+        hipLaunchKernelGGL(half_bgr_gray_kernel, grid, dim3(NT), 0, st, d_src, sstride, d_dst, dstride, dw, dh, vec_ok, (const ImgPair*)nullptr);
     } else {
         dim3 grid((dw + NT - 1) / NT, dh);
         if (fmt == VS_FMT_BGR8)
             hipLaunchKernelGGL((resize_gray_kernel<3, true>), grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst,
-                               dstride, dw, dh, scale_x, scale_y, area2 ? 1 : 0);
+                               dstride, dw, dh, scale_x, scale_y, area2 ? 1 : 0, (const ImgPair*)nullptr);
         else
             hipLaunchKernelGGL((resize_gray_kernel<1, true>), grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst,
-                               dstride, dw, dh, scale_x, scale_y, area2 ? 1 : 0);
+                               dstride, dw, dh, scale_x, scale_y, area2 ? 1 : 0, (const ImgPair*)nullptr);
     }
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
@@ -168,10 +205,10 @@ int launch_resize_linear(const uint8_t* d_src, size_t sstride, int sw, int sh, i
     dim3 grid((dw + NT - 1) / NT, dh);
     if (cn == 3)
         hipLaunchKernelGGL((resize_gray_kernel<3, false>), grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst, dstride,
-                           dw, dh, scale_x, scale_y, area2);
+                           dw, dh, scale_x, scale_y, area2, (const ImgPair*)nullptr);
     else
         hipLaunchKernelGGL((resize_gray_kernel<1, false>), grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst, dstride,
-                           dw, dh, scale_x, scale_y, area2);
+                           dw, dh, scale_x, scale_y, area2, (const ImgPair*)nullptr);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

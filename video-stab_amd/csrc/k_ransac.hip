@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include "traj_device.h"
+#include "traj_emit_device.h"
 #include "vs_common.h"
 
 namespace vsd {
@@ -256,8 +257,11 @@ __device__ __forceinline__ double wave_butterfly_sum(double v) {
 // One wave: replays RANSACPointSetRegistrator::run over the vote counts, rebuilds
 // the inlier mask of the kept hypothesis, refines, and (pipeline) appends the
 // measured transform to the trajectory.
-__global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) {
-    const int lane = threadIdx.x;
+// MULTI: several waves of one workgroup each select for their own frame (batch tail); the trajectory
+// append is then left to the caller, and only the wave flagged write_dbg reports its counts.
+template <bool MULTI>
+__device__ __forceinline__ void ransac_select(const RansacArgs& a, const bool write_dbg = true) {
+    const int lane = threadIdx.x & 63;
     const float* from = a.status ? a.vp : a.from;
     const float* to = a.status ? a.vc : a.to;
     int n = a.status ? *a.d_m : device_count(a);
@@ -266,8 +270,9 @@ __global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) {
     if (lane < 6) a.model[lane] = __longlong_as_double(0x7FF8000000000000LL);
     for (int i = lane; i < a.n; i += 64) a.inliers[i] = 0;
     if (lane < 4) a.info[lane] = lane == 1 ? -1 : 0;
-    if (a.dbg && lane == 0) { a.dbg->n_prev = nprev; a.dbg->n_valid = n; }
-    __syncthreads();
+    if (a.dbg && write_dbg && lane == 0) { a.dbg->n_prev = nprev; a.dbg->n_valid = n; }
+    if (MULTI) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
     bool ok = false;
     Model best;
     if (n >= a.min_points && n >= 2 && n <= a.table_max_m) {
@@ -350,12 +355,61 @@ __global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) {
         }
     }
     (void)ok;
-    if (a.traj) {
+    if (!MULTI && a.traj) {
         // the results above were written by this same wave; make them visible to lane 0's reads
         __threadfence_block();
         __syncthreads();
         if (lane == 0) traj_append_device(a.traj, a.tp, a.model, a.info, nprev, a.dbg, a.have_prev_gray);
     }
+}
+
+__global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) { ransac_select<false>(a); }
+
+// Ordered tail of a batch, ONE launch: for every frame in push order, hypothesis selection + trajectory append,
+// then - when that push produces an output - the map of the frame leaving the queue, which must see exactly
+// the transforms appended so far (Stabilizer.cpp:380-389).
+struct TailItem {
+    int out_due, out_idx;
+    double* Minv_out;
+};
+
+__global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArgs* __restrict__ table,
+                                                                 const TailItem* __restrict__ tail, int n, float* M_out) {
+    // The ordered part below is a chain of small dependent steps executed by one lane; run from global
+    // memory every step would pay an HBM round trip.  The stream's trajectory state, the parameters and
+    // the per-frame results therefore live in LDS for the duration of the kernel.
+    __shared__ TrajState l_state;
+    __shared__ TrajParams l_tp;
+    __shared__ double l_model[16][6];
+    __shared__ int32_t l_info[16][4];
+    __shared__ int l_nprev[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    TrajState* g_state = table[0].traj;
+    for (int i = tid; i < (int)(sizeof(TrajState) / 4); i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&l_state)[i] = reinterpret_cast<const uint32_t*>(g_state)[i];
+    for (int i = tid; i < (int)(sizeof(TrajParams) / 4); i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&l_tp)[i] = reinterpret_cast<const uint32_t*>(&table[0].tp)[i];
+    // phase 1: the selections do not depend on each other: wave i serves frame i
+    if (wave < n) {
+        const RansacArgs& a = table[wave];
+        ransac_select<true>(a, wave == n - 1);
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 6) l_model[wave][lane] = a.model[lane];
+        if (lane < 4) l_info[wave][lane] = a.info[lane];
+        if (lane == 0) l_nprev[wave] = device_count(a);
+    }
+    __syncthreads();
+    // phase 2, ordered: append the measured transform of frame i, then emit the map that push i releases
+    for (int i = 0; i < n; i++) {
+        const RansacArgs& a = table[i];
+        if (tid == 0) traj_append_device(&l_state, l_tp, l_model[i], l_info[i], l_nprev[i], a.dbg, a.have_prev_gray);
+        __syncthreads();
+        if (tail[i].out_due) traj_emit_device(&l_state, l_tp, tail[i].out_idx, M_out, tail[i].Minv_out, a.dbg);
+        __syncthreads();
+    }
+    for (int i = tid; i < (int)(sizeof(TrajState) / 4); i += blockDim.x)
+        reinterpret_cast<uint32_t*>(g_state)[i] = reinterpret_cast<const uint32_t*>(&l_state)[i];
 }
 
 }  // namespace
@@ -408,6 +462,23 @@ int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_m
     }
     hipLaunchKernelGGL(ransac_score_batch_kernel, dim3(iters, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
                        static_cast<const RansacArgs*>(d_table));
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+size_t tail_item_bytes() { return sizeof(TailItem); }
+
+void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out) {
+    TailItem& t = *static_cast<TailItem*>(host_item);
+    t.out_due = out_due; t.out_idx = out_idx; t.Minv_out = d_Minv_out;
+}
+
+int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, hipStream_t st) {
+    if (!d_table || !d_tail || items < 1 || !d_M_out) { set_last_error("ransac_tail_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
+    const int threads = 64 * (items < 1 ? 1 : (items > 16 ? 16 : items));
+    if (items > 16) { set_last_error("ransac_tail_batch: at most 16 frames"); return VS_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL(ransac_tail_batch_kernel, dim3(1), dim3(threads), 0, st, static_cast<const RansacArgs*>(d_table),
+                       static_cast<const TailItem*>(d_tail), items, d_M_out);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

@@ -18,6 +18,7 @@
 #include "vs_common.h"
 #include "traj_state.h"
 #include "traj_device.h"
+#include "traj_emit_device.h"
 
 namespace vsd {
 namespace {
@@ -57,179 +58,9 @@ __global__ void traj_append_kernel(TrajState* s, TrajParams p, const double* __r
 }
 
 
-// Stabilizer.cpp:1750-1780
-__device__ float variance_of(const float* v, int n) {
-    if (n == 0) return 0.0f;
-    float mean = 0.0f;
-    for (int i = 0; i < n; i++) mean += v[i];
-    mean /= n;
-    float var = 0.0f;
-    for (int i = 0; i < n; i++) { const float d = v[i] - mean; var += d * d; }
-    var /= n;
-    return var;
-}
-__device__ float consistency_of(const float* v, int n) {
-    if (n < 2) return 0.0f;
-    const float var = variance_of(v, n);
-    float mean = 0.0f;
-    for (int i = 0; i < n; i++) mean += v[i];
-    mean /= n;
-    if (mean == 0.0f) return 0.0f;
-    const float c = 1.0f / (1.0f + (var / (mean * mean)));
-    return fmaxf(0.0f, fminf(1.0f, c));
-}
-
-__global__ void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __restrict__ M_out,
-                                 double* __restrict__ Minv_out, vs_debug_frame* dbg) {
-    // The history rings are mirrored into LDS by all lanes and the per-sample
-    // transcendental work of the intent analysis is spread over lanes; every
-    // float SUM below is still accumulated by lane 0 in the reference's order.
-    __shared__ float l_path[TRAJ_RING][3], l_tr[TRAJ_RING][3];
-    __shared__ float l_mag[16], l_dir[16];
-    const int n = s->n;
-    for (int i = threadIdx.x; i < TRAJ_RING * 3; i += blockDim.x) {
-        (&l_path[0][0])[i] = (&s->path[0][0])[i];
-        (&l_tr[0][0])[i] = (&s->transforms[0][0])[i];
-    }
-    __syncthreads();
-    const int istart = idx - 15 > 0 ? idx - 15 : 0;
-    if (threadIdx.x < 15) {
-        const int i = istart + (int)threadIdx.x;
-        if (i < idx && i < n) {
-            const float t0 = l_tr[i & (TRAJ_RING - 1)][0], t1 = l_tr[i & (TRAJ_RING - 1)][1];
-            l_mag[threadIdx.x] = sqrtf(t0 * t0 + t1 * t1);
-            l_dir[threadIdx.x] = atan2f(t1, t0);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    auto path_at = [&](int i, int c) -> float { return l_path[i & (TRAJ_RING - 1)][c]; };
-    auto tr_at = [&](int i, int c) -> float { return l_tr[i & (TRAJ_RING - 1)][c]; };
-    dbg->out_index = idx; dbg->box_radius = 0; dbg->intent = 0;
-    if (idx >= n) {   // Stabilizer.cpp:774-780: no transform for this frame -> frame returned as is
-        M_out[0] = 1.f; M_out[1] = 0.f; M_out[2] = 0.f; M_out[3] = 0.f; M_out[4] = 1.f; M_out[5] = 0.f;
-        for (int i = 0; i < 6; i++) M_out[6 + i] = M_out[i];
-        warp_invert(M_out, Minv_out);
-        warp_invert(M_out + 6, Minv_out + 6);
-        for (int c = 0; c < 3; c++) dbg->smoothed[c] = 0.f;
-        for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
-        return;
-    }
-    float sm[3];
-    if (p.method == VS_SMOOTH_GAUSSIAN) {          // :1364-1413
-        const int ks = p.gauss_ksize, center = ks / 2;
-        for (int c = 0; c < 3; c++) {
-            float acc = 0.0f;
-            for (int j = 0; j < ks; j++) {
-                // padded[idx + j]: reflect padding as the reference builds it (clamped when n <= center)
-                const int q = idx + j;
-                int src;
-                if (q < center) src = center - q;
-                else if (q < center + n) src = q - center;
-                else src = n - 1 - (q - center - n);
-                src = src < 0 ? 0 : (src > n - 1 ? n - 1 : src);
-                acc += path_at(src, c) * p.gauss_kernel[j];
-            }
-            sm[c] = acc;
-        }
-    } else if (p.method == VS_SMOOTH_KALMAN) {     // :1416-1458, advanced incrementally
-        const float q = 0.01f, r = 0.1f;
-        for (int c = 0; c < 3; c++) {
-            float* k = s->kal[c];   // x0,x1,P00,P01,P10,P11
-            int done = s->kal_n[c];
-            if (done == 0) {
-                k[0] = path_at(0, c); k[1] = 0.f; k[2] = k[3] = k[4] = k[5] = 0.f;
-                s->kal_last[c] = k[0];
-                done = 1;
-            }
-            while (done <= idx) {
-                const float xp0 = k[0] + k[1], xp1 = k[1];
-                const float t00 = k[2] + k[4], t01 = k[3] + k[5], t10 = k[4], t11 = k[5];
-                const float Q00 = (t00 + t01) + q, Q01 = t01, Q10 = t10 + t11, Q11 = t11 + q;
-                const float S = Q00 + r;
-                const float K0 = Q00 / S, K1 = Q01 / S;
-                const float innov = path_at(done, c) - xp0;
-                k[0] = xp0 + K0 * innov; k[1] = xp1 + K1 * innov;
-                k[2] = Q00 - K0 * Q00; k[3] = Q01 - K0 * Q01;
-                k[4] = Q10 - K1 * Q00; k[5] = Q11 - K1 * Q01;
-                s->kal_last[c] = k[0];
-                done++;
-            }
-            s->kal_n[c] = done;
-            sm[c] = s->kal_last[c];
-        }
-    } else {                                         // :807-823 box with adaptive radius
-        // calculateAdaptiveRadius :1637-1673
-        int ar = s->smoothing_radius;
-        if (n >= 10) {
-            const int start = n - 20 > 0 ? n - 20 : 0;
-            const int count = n - start;
-            float mean[3] = {0, 0, 0}, var[3] = {0, 0, 0};
-            for (int i = start; i < n; i++) for (int c = 0; c < 3; c++) mean[c] += path_at(i, c);
-            for (int c = 0; c < 3; c++) mean[c] /= count;
-            for (int i = start; i < n; i++)
-                for (int c = 0; c < 3; c++) { const float d = path_at(i, c) - mean[c]; var[c] += d * d; }
-            for (int c = 0; c < 3; c++) var[c] /= count;
-            const float total = sqrtf(var[0] + var[1] + var[2] * 1000);
-            ar = (int)fmaxf(5.0f, fminf(25.0f, total * 2.0f));
-        }
-        // boxFilterConvolve :1139-1172
-        const int r = p.drone ? max(10, min(ar, 50)) : max(2, min(ar, 8));
-        dbg->box_radius = r;
-        if (n <= r) {
-            for (int c = 0; c < 3; c++) sm[c] = path_at(idx, c);
-        } else {
-            const int start = idx - r > 0 ? idx - r : 0;
-            const int end = idx + r < n - 1 ? idx + r : n - 1;
-            for (int c = 0; c < 3; c++) {
-                float sum = 0.0f;
-                int count = 0;
-                for (int j = start; j <= end; j++) { sum += path_at(j, c); count++; }
-                sm[c] = sum / count;
-            }
-        }
-    }
-    float raw[3], diff[3];
-    for (int c = 0; c < 3; c++) {
-        raw[c] = tr_at(idx, c);
-        diff[c] = sm[c] - path_at(idx, c);      // :850-851
-        dbg->smoothed[c] = sm[c];
-    }
-    if (idx > 0) {                                   // :854-888, analyzeMotionIntent :1676-1719
-        int intent = 0;
-        const float magnitude = sqrtf(raw[0] * raw[0] + raw[1] * raw[1]);
-        const float angularVel = (float)((double)(fabsf(raw[2]) * 180.0f) / 3.14159265358979323846 * (double)30.0f);
-        if (n >= 15) {
-            float mags[15], dirs[15];
-            int cnt = 0;
-            for (int i = istart; i < idx; i++) {
-                if (i < n) { mags[cnt] = l_mag[i - istart]; dirs[cnt] = l_dir[i - istart]; cnt++; }
-            }
-            if (cnt > 0) {
-                const float dv = variance_of(dirs, cnt);
-                const float mc = consistency_of(mags, cnt);
-                if (dv < 0.5f && mc > 0.7f && magnitude > 5.0f) intent = 1;
-                else if (magnitude < 3.0f && mc < 0.3f && angularVel > 10.0f) intent = 2;
-                else if (magnitude > 3.0f && magnitude < 15.0f && dv > 0.5f) intent = 3;
-            }
-        }
-        dbg->intent = intent;
-        // calculateAdaptiveStabilizationStrength :1722-1747 is consumed only for NORMAL (0.7)
-        const float g = intent == 1 ? 0.5f : intent == 2 ? 1.0f : intent == 3 ? 0.8f : 0.7f;
-        for (int c = 0; c < 3; c++) diff[c] *= g;
-    }
-    const float dx = raw[0] + diff[0], dy = raw[1] + diff[1];
-    float da = raw[2] + diff[2];
-    if (p.horizon_lock) da = 0.0f;                   // :897-899
-    const float cs = cosf(da), sn = sinf(da);         // :902-908
-    M_out[0] = cs; M_out[1] = -sn; M_out[2] = dx;
-    M_out[3] = sn; M_out[4] = cs; M_out[5] = dy;
-    // chroma plane of an NV12 surface: same rotation, translation halved
-    M_out[6] = cs; M_out[7] = -sn; M_out[8] = dx * 0.5f;
-    M_out[9] = sn; M_out[10] = cs; M_out[11] = dy * 0.5f;
-    warp_invert(M_out, Minv_out);            // the warp kernels consume the inverse maps
-    warp_invert(M_out + 6, Minv_out + 6);
-    for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
+__global__ __launch_bounds__(64) void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __restrict__ M_out,
+                                                       double* __restrict__ Minv_out, vs_debug_frame* dbg) {
+    traj_emit_device(s, p, idx, M_out, Minv_out, dbg);
 }
 
 __global__ void traj_reset_kernel(TrajState* s, int smoothing_radius) {

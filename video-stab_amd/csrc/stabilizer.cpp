@@ -49,6 +49,9 @@ int ransac_fill_item(void* host_item, const float* d_from, const float* d_to, co
                      TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg, int have_prev_gray);
 int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_max, hipStream_t st);
 int launch_ransac_select_item(const void* host_item, hipStream_t st);
+size_t tail_item_bytes();
+void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out);
+int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, hipStream_t st);
 size_t gftt_item_bytes();
 int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
                    double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
@@ -167,6 +170,7 @@ struct vs_stab {
     bool batch_active = false;
     struct BFrame {
         int f, c, pv;
+        const uint8_t* frame; bool prev_small;
         bool detect; int det_buf;
         int lk_buf, lk_cap;
         bool out_due; int out_slot, out_idx; uint8_t* d_out; size_t out_stride;
@@ -178,8 +182,10 @@ struct vs_stab {
     std::vector<GfttWork> gws;                       // one GFTT scratch per detection of a batch
     struct ItemBufs { float *next, *err, *vp, *vc; uint8_t *status, *inliers; int32_t *m, *info, *counts; double* model; };
     std::vector<ItemBufs> items;
-    std::vector<uint8_t> h_lk, h_rs, h_gf;           // host images of the argument tables
-    uint8_t *d_lk_table = nullptr, *d_rs_table = nullptr, *d_gf_table = nullptr;
+    std::vector<uint8_t> h_lk, h_rs, h_gf, h_tail;   // host images of the argument tables
+    std::vector<ImgPair> h_pairs;                    // (source, destination) of the batched gray / pyramid launches
+    uint8_t *d_lk_table = nullptr, *d_rs_table = nullptr, *d_gf_table = nullptr, *d_tail_table = nullptr;
+    ImgPair* d_pairs = nullptr;
     hipEvent_t ev_bpre = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
     bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
     int last_det_batch = -1;
@@ -338,6 +344,8 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
         o_it[k].model = take(48);
     }
     const size_t o_lkt = take(lk_item_bytes() * B), o_rst = take(ransac_item_bytes() * B), o_gft = take(gftt_item_bytes() * ngw);
+    const size_t o_tail = take(tail_item_bytes() * B);
+    const size_t o_pairs = take(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
     size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
     size_t o_MinvB[2] = {take((size_t)WARP_BATCH_MAX * 96), take((size_t)WARP_BATCH_MAX * 96)};
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
@@ -362,7 +370,10 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->d_next = s->items[0].next; s->d_err = s->items[0].err; s->d_vp = s->items[0].vp; s->d_vc = s->items[0].vc;
     s->d_status = s->items[0].status; s->d_inliers = s->items[0].inliers;
     s->d_m = s->items[0].m; s->d_info = s->items[0].info; s->d_counts = s->items[0].counts; s->d_model = s->items[0].model;
-    s->d_lk_table = b + o_lkt; s->d_rs_table = b + o_rst; s->d_gf_table = b + o_gft;
+    s->d_lk_table = b + o_lkt; s->d_rs_table = b + o_rst; s->d_gf_table = b + o_gft; s->d_tail_table = b + o_tail;
+    s->h_tail.assign(tail_item_bytes() * B, 0);
+    s->d_pairs = (ImgPair*)(b + o_pairs);
+    s->h_pairs.assign((size_t)B * (2 + 2 * MAX_PYR), ImgPair{nullptr, nullptr});
     s->h_lk.assign(lk_item_bytes() * B, 0); s->h_rs.assign(ransac_item_bytes() * B, 0); s->h_gf.assign(gftt_item_bytes() * ngw, 0);
     s->d_traj = (TrajState*)(b + o_traj);
     s->d_M = (float*)(b + o_M); s->d_Minv = (double*)(b + o_Minv); s->d_dbg = (vs_debug_frame*)(b + o_dbg);
@@ -643,27 +654,11 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
 int batch_enqueue(vs_stab* s, const uint8_t* frame, int slot, int f, uint8_t* d_out, size_t out_stride, int* produced) {
     const vs_params_c& p = s->p;
     const int N = s->npyr, c = f % N, pv = (f - 1) % N;
-    if (s->bq.empty() && s->batch_id >= 2) {
-        // ring reuse: slot c was read by the analysis two batches ago (npyr = 2*batch + 2)
-        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(s->batch_id - 2) % 4], 0));
-        if (s->bdet_valid[(s->batch_id - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(s->batch_id - 2) % 4], 0));
-    }
-    {
-        StageScope t(s, VS_STAGE_GRAY, s->st_pre);
-        S_TRY(s, launch_resize_gray(frame, s->row_bytes, s->w, s->h, s->fmt, s->pyr[c].img[0], s->aw, s->aw, s->ah, s->st_pre));
-    }
-    {
-        StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
-        S_TRY(s, build_pyramid(s, c, s->st_pre));
-        if (s->prev_small) {   // :598-603 (once: 480x270 -> analysis size)
-            S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[pv].img[0], s->aw, s->aw, s->ah, s->st_pre));
-            S_TRY(s, build_pyramid(s, pv, s->st_pre));
-            s->prev_small = false;
-        }
-    }
     vs_stab::BFrame b;
     memset(&b, 0, sizeof b);
     b.f = f; b.c = c; b.pv = pv;
+    b.frame = frame; b.prev_small = s->prev_small;
+    s->prev_small = false;
     b.lk_buf = s->kp_cur; b.lk_cap = s->pts_cap[s->kp_cur];
     b.have_prev_gray = s->have_prev_gray ? 1 : 0;
     b.detect = (++s->detect_counter % 2) == 0;
@@ -699,6 +694,40 @@ int run_batch(vs_stab* s) {
     if (n == 0) return VS_OK;
     const vs_params_c& p = s->p;
     const int k = s->batch_id++;
+    // ---- pre: gray images and pyramids of all frames of the batch, one launch per stage and level
+    if (k >= 2) {
+        // ring reuse: these slots were read by the analysis two batches ago (npyr = 2*batch + 2)
+        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(k - 2) % 4], 0));
+        if (s->bdet_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(k - 2) % 4], 0));
+    }
+    if (s->bq[0].prev_small) {   // :598-603 (once: 480x270 -> analysis size)
+        StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
+        S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[s->bq[0].pv].img[0], s->aw, s->aw, s->ah, s->st_pre));
+        S_TRY(s, build_pyramid(s, s->bq[0].pv, s->st_pre));
+    }
+    {
+        // pair tables: [0] frame -> img[0]; [1..levels] img[l-1] -> img[l]; [levels+1 ..] img[l] -> der[l]
+        const int L = s->levels;
+        int aligned = 1;
+        for (int i = 0; i < n; i++) {
+            const vs_stab::BFrame& b = s->bq[i];
+            const Pyramid& P = s->pyr[b.c];
+            s->h_pairs[i] = ImgPair{b.frame, P.img[0]};
+            if ((uintptr_t)b.frame % 8) aligned = 0;
+            for (int l = 1; l <= L; l++) s->h_pairs[(size_t)l * n + i] = ImgPair{P.img[l - 1], P.img[l]};
+            for (int l = 0; l <= L; l++) s->h_pairs[(size_t)(L + 1 + l) * n + i] = ImgPair{P.img[l], P.der[l]};
+        }
+        S_HIP(s, hipMemcpyAsync(s->d_pairs, s->h_pairs.data(), sizeof(ImgPair) * n * (2 * L + 2), hipMemcpyHostToDevice, s->st_pre));
+        {
+            StageScope t(s, VS_STAGE_GRAY, s->st_pre);
+            S_TRY(s, launch_resize_gray_batch(s->d_pairs, n, s->row_bytes, s->w, s->h, s->fmt, s->aw, s->aw, s->ah, aligned, s->st_pre));  // :448-450
+        }
+        StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
+        for (int l = 1; l <= L; l++)
+            S_TRY(s, launch_pyr_down_batch(s->d_pairs + (size_t)l * n, n, s->lw[l - 1], s->lw[l - 1], s->lh[l - 1], s->lw[l], s->st_pre));
+        for (int l = 0; l <= L; l++)
+            S_TRY(s, launch_scharr_batch(s->d_pairs + (size_t)(L + 1 + l) * n, n, s->lw[l], s->lw[l], s->lh[l], s->st_pre));
+    }
     S_HIP(s, hipEventRecord(s->ev_bpre, s->st_pre));
     // ---- det: every frame of the batch that re-detects, one launch per GFTT stage
     int ndet = 0;
@@ -758,16 +787,35 @@ int run_batch(vs_stab* s) {
         S_TRY(s, launch_ransac_score_batch(s->d_rs_table, n, p.ransac_max_iters, n_max, st));
     }
     S_HIP(s, hipEventRecord(s->ev_blk[k % 4], st));
-    // ---- ordered tail, frame by frame: selection + trajectory append (:644-693), then the output that
-    // has become due (applyNextSmoothTransform sees exactly the transforms appended so far)
-    for (int i = 0; i < n; i++) {
-        const vs_stab::BFrame b = s->bq[i];
-        {
-            StageScope t(s, VS_STAGE_RANSAC, st);
-            S_TRY(s, launch_ransac_select_item(s->h_rs.data() + ransac_item_bytes() * i, st));
+    // ---- ordered tail, ONE launch: per frame in push order, selection + trajectory append (:644-693), then the
+    // map of the output that has become due (applyNextSmoothTransform sees exactly the transforms appended so
+    // far); all due warps of the batch then leave as one launch.
+    S_TRY(s, flush_warps(s));                      // the list of pending warps starts empty
+    {
+        const int set = s->pend_set;
+        bool any = false;
+        for (int i = 0; i < n; i++) any |= s->bq[i].out_due;
+        if (any && s->warp_valid[set]) {           // the previous user of this set of maps must have read them
+            S_HIP(s, hipStreamWaitEvent(st, s->ev_warp[set], 0));
+            s->warp_valid[set] = false;
         }
-        if (b.out_due)
-            S_TRY(s, defer_output(s, b.out_idx, s->d_ring + (size_t)b.out_slot * s->frame_bytes, b.d_out, b.out_stride, b.out_slot));
+        for (int i = 0; i < n; i++) {
+            const vs_stab::BFrame& b = s->bq[i];
+            double* minv = nullptr;
+            if (b.out_due) {
+                if (!s->pend.empty() && s->pend_stride != b.out_stride) return fail(s, VS_ERR_INVALID_ARG, "batch mode: the output stride must not change within a batch");
+                minv = s->d_MinvB[set] + 12 * s->pend.size();
+                s->pend.push_back({s->d_ring + (size_t)b.out_slot * s->frame_bytes, b.d_out, b.out_slot});
+                s->pend_stride = b.out_stride;
+            }
+            tail_fill_item(s->h_tail.data() + tail_item_bytes() * i, b.out_due ? 1 : 0, b.out_idx, minv);
+        }
+        S_HIP(s, hipMemcpyAsync(s->d_tail_table, s->h_tail.data(), tail_item_bytes() * n, hipMemcpyHostToDevice, st));
+        {
+            StageScope t(s, VS_STAGE_TRAJ, st);
+            S_TRY(s, launch_ransac_tail_batch(s->d_rs_table, s->d_tail_table, n, s->d_M, st));
+        }
+        S_TRY(s, flush_warps(s));
     }
     const vs_stab::BFrame& lb = s->bq[n - 1];
     s->dbg_prev_pts = s->d_pts[lb.lk_buf]; s->dbg_next = s->items[n - 1].next;

@@ -82,6 +82,13 @@ int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, in
                             size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, hipStream_t st);
 int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
                        uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st);
+// Batched forms (batch mode): the images of `items` frames in one launch; d_pairs = device table of
+// (source, destination) pointers, all of one geometry.
+struct ImgPair { const void* src; void* dst; };
+int launch_resize_gray_batch(const ImgPair* d_pairs, int items, size_t sstride, int sw, int sh, int fmt, size_t dstride,
+                             int dw, int dh, int aligned, hipStream_t st);
+int launch_pyr_down_batch(const ImgPair* d_pairs, int items, size_t sstride, int sw, int sh, size_t dstride, hipStream_t st);
+int launch_scharr_batch(const ImgPair* d_pairs, int items, size_t sstride, int w, int h, hipStream_t st);
 int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst,
                     size_t dstride, hipStream_t st);
 int launch_scharr(const uint8_t* d_src, size_t sstride, int w, int h, int16_t* d_dst,
