@@ -376,19 +376,25 @@ struct TailItem {
 __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArgs* __restrict__ table,
                                                                  const TailItem* __restrict__ tail, int n, float* M_out) {
     // The ordered part below is a chain of small dependent steps executed by one lane; run from global
-    // memory every step would pay an HBM round trip.  The stream's trajectory state, the parameters and
-    // the per-frame results therefore live in LDS for the duration of the kernel.
+    // memory every step would pay an HBM round trip (and every barrier would wait for the stores of the
+    // step before).  The stream's trajectory state, the parameters, the per-frame inputs and all results
+    // therefore live in LDS for the duration of the kernel and are written out once at the end.
     __shared__ TrajState l_state;
     __shared__ TrajParams l_tp;
+    __shared__ vs_debug_frame l_dbg;
     __shared__ double l_model[16][6];
+    __shared__ double l_minv[16][12];
+    __shared__ float l_M[12];
     __shared__ int32_t l_info[16][4];
-    __shared__ int l_nprev[16];
+    __shared__ int l_nprev[16], l_hpg[16], l_due[16], l_oidx[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     TrajState* g_state = table[0].traj;
+    vs_debug_frame* g_dbg = table[0].dbg;
     for (int i = tid; i < (int)(sizeof(TrajState) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(&l_state)[i] = reinterpret_cast<const uint32_t*>(g_state)[i];
     for (int i = tid; i < (int)(sizeof(TrajParams) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(&l_tp)[i] = reinterpret_cast<const uint32_t*>(&table[0].tp)[i];
+    if (tid < 12) l_M[tid] = M_out[tid];
     // phase 1: the selections do not depend on each other: wave i serves frame i
     if (wave < n) {
         const RansacArgs& a = table[wave];
@@ -397,19 +403,30 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
         __builtin_amdgcn_wave_barrier();
         if (lane < 6) l_model[wave][lane] = a.model[lane];
         if (lane < 4) l_info[wave][lane] = a.info[lane];
-        if (lane == 0) l_nprev[wave] = device_count(a);
+        if (lane == 0) {
+            l_nprev[wave] = device_count(a); l_hpg[wave] = a.have_prev_gray;
+            l_due[wave] = tail[wave].out_due; l_oidx[wave] = tail[wave].out_idx;
+        }
     }
+    __threadfence();
+    __syncthreads();
+    // (after the selections: the last one has reported n_prev / n_valid into the global record)
+    for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&l_dbg)[i] = reinterpret_cast<const uint32_t*>(g_dbg)[i];
     __syncthreads();
     // phase 2, ordered: append the measured transform of frame i, then emit the map that push i releases
     for (int i = 0; i < n; i++) {
-        const RansacArgs& a = table[i];
-        if (tid == 0) traj_append_device(&l_state, l_tp, l_model[i], l_info[i], l_nprev[i], a.dbg, a.have_prev_gray);
+        if (tid == 0) traj_append_device(&l_state, l_tp, l_model[i], l_info[i], l_nprev[i], &l_dbg, l_hpg[i]);
         __syncthreads();
-        if (tail[i].out_due) traj_emit_device(&l_state, l_tp, tail[i].out_idx, M_out, tail[i].Minv_out, a.dbg);
+        if (l_due[i]) traj_emit_device(&l_state, l_tp, l_oidx[i], l_M, l_minv[i], &l_dbg);
         __syncthreads();
     }
     for (int i = tid; i < (int)(sizeof(TrajState) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(g_state)[i] = reinterpret_cast<const uint32_t*>(&l_state)[i];
+    for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)
+        reinterpret_cast<uint32_t*>(g_dbg)[i] = reinterpret_cast<const uint32_t*>(&l_dbg)[i];
+    if (tid < 12) M_out[tid] = l_M[tid];
+    if (wave < n && lane < 12 && l_due[wave]) tail[wave].Minv_out[lane] = l_minv[wave][lane];
 }
 
 }  // namespace

@@ -311,7 +311,8 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->batch_active = s->batch > 1 && fmt != VS_FMT_NV12 && s->p.border_size <= 0 && !s->p.adaptive_smoothing;
     const int B = s->batch_active ? s->batch : 1;
     s->npyr = s->batch_active ? 2 * B + 2 : NPYR;
-    const int nkp = s->batch_active ? B / 2 + 4 : 2, ngw = s->batch_active ? B / 2 + 1 : 1;
+    // keypoint buffers: one per detection, recycled after two batches' worth of detections
+    const int nkp = s->batch_active ? B + 4 : 2, ngw = s->batch_active ? B / 2 + 1 : 1;
     s->pyr.assign(s->npyr, Pyramid());
     s->d_pts.assign(nkp, nullptr); s->d_npts.assign(nkp, nullptr); s->pts_cap.assign(nkp, 0);
     s->items.assign(B, vs_stab::ItemBufs());
@@ -743,8 +744,9 @@ int run_batch(vs_stab* s) {
     s->last_detected = s->bq[n - 1].detect;
     if (ndet > 0) {
         S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_bpre, 0));
-        // keypoint buffers and GFTT scratch are recycled: the tracking of the previous batch must have read them
-        if (k >= 1) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 1) % 4], 0));
+        // keypoint buffers are recycled after B + 4 detections (two batches): the tracking of the batch before
+        // the previous one must have read them (the GFTT scratch is only touched on this stream)
+        if (k >= 2) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 2) % 4], 0));
         S_HIP(s, hipMemcpyAsync(s->d_gf_table, s->h_gf.data(), gftt_item_bytes() * ndet, hipMemcpyHostToDevice, s->st_det));
         {
             StageScope t(s, VS_STAGE_GFTT, s->st_det);

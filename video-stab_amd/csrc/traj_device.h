@@ -15,7 +15,7 @@ __device__ __forceinline__ float hf_mag(const float t[3]) {
 }
 
 // One lane.  `info` = {ok, best_iter, iters_run, n_inliers}, `model` = refined 2x3 (double).
-__device__ inline void traj_append_device(TrajState* s, const TrajParams& p, const double* model,
+__device__ __forceinline__ void traj_append_device(TrajState* s, const TrajParams& p, const double* model,
                                           const int32_t* info, int nprev, vs_debug_frame* dbg,
                                           int have_prev_gray) {
     float tr[3] = {0.f, 0.f, 0.f};

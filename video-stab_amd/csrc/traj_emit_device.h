@@ -1,7 +1,16 @@
 // The part of applyNextSmoothTransform() that produces the 2x3 matrix of one output frame
 // (/root/reference/src/Stabilizer.cpp:783-908) as a device function, so that it can run as its own
-// kernel (k_traj.hip) or inside the ordered tail of a batch (k_ransac.hip).  Called by all 64 lanes of
-// ONE wave-sized workgroup; lane 0 does the reference's sequential arithmetic.
+// kernel (k_traj.hip) or inside the ordered tail of a batch (k_ransac.hip).
+//
+// Every float SUM of the reference is a sequential accumulation, and its order is part of the result.
+// A single lane walking an LDS array pays ~100 cycles per element (dependent load + add), so the sums
+// are evaluated wave-cooperatively instead: lane j loads element j (all loads in flight together), and
+// the accumulation then runs over v_readlane(j) in the reference's order - the same additions, in
+// the same order, on values that are already in registers.  The loops are unrolled to their maximum
+// length with constant lane numbers; lanes past the end hold +0 (or the mean, for a variance), and
+// adding +0 to a running float sum that started at +0 never changes it.
+//
+// traj_emit_device is called by ALL threads of a workgroup (any multiple of 64); wave 0 does the work.
 #ifndef VS_TRAJ_EMIT_DEVICE_H
 #define VS_TRAJ_EMIT_DEVICE_H
 
@@ -10,148 +19,195 @@
 
 namespace vsd {
 
-// Stabilizer.cpp:1750-1780
-__device__ inline float variance_of(const float* v, int n) {
+__device__ __forceinline__ float lane_value(float v, int j) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+// sum of lanes 0..MAXN-1 in lane order (lanes >= n must hold +0)
+template <int MAXN>
+__device__ __forceinline__ float seq_sum(float v) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXN; i++) acc += lane_value(v, i);
+    return acc;
+}
+// sum of (v[i] - mean)^2 in lane order (lanes >= n must hold `mean`)
+template <int MAXN>
+__device__ __forceinline__ float seq_sqdev(float v, float mean) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXN; i++) { const float d = lane_value(v, i) - mean; acc += d * d; }
+    return acc;
+}
+
+// Stabilizer.cpp:1750-1780 on values held one per lane (lanes 0..n-1 of v, +0 beyond), n <= MAXN
+template <int MAXN>
+__device__ __forceinline__ float wave_variance_of(float v, int n) {
     if (n == 0) return 0.0f;
-    float mean = 0.0f;
-    for (int i = 0; i < n; i++) mean += v[i];
+    float mean = seq_sum<MAXN>(v);
     mean /= n;
-    float var = 0.0f;
-    for (int i = 0; i < n; i++) { const float d = v[i] - mean; var += d * d; }
+    float var = seq_sqdev<MAXN>((int)(threadIdx.x & 63) < n ? v : mean, mean);
     var /= n;
     return var;
 }
-__device__ inline float consistency_of(const float* v, int n) {
+template <int MAXN>
+__device__ __forceinline__ float wave_consistency_of(float v, int n) {
     if (n < 2) return 0.0f;
-    const float var = variance_of(v, n);
-    float mean = 0.0f;
-    for (int i = 0; i < n; i++) mean += v[i];
+    const float var = wave_variance_of<MAXN>(v, n);
+    float mean = seq_sum<MAXN>(v);
     mean /= n;
     if (mean == 0.0f) return 0.0f;
     const float c = 1.0f / (1.0f + (var / (mean * mean)));
     return fmaxf(0.0f, fminf(1.0f, c));
 }
 
-// lane 0: smoothing around frame idx, motion-intent gain, T = [cos -sin dx; sin cos dy]
-__device__ inline void traj_emit_lane0(TrajState* s, const TrajParams& p, int idx, float* __restrict__ M_out,
-                                       double* __restrict__ Minv_out, vs_debug_frame* dbg,
-                                       const float (*l_path)[3], const float (*l_tr)[3], const float* l_mag,
-                                       const float* l_dir, const int n, const int istart) {
+// Wave 0 (64 lanes, all active): smoothing around frame idx, motion-intent gain,
+// T = [cos -sin dx; sin cos dy].  Uniform values are computed by every lane; lane 0 stores.
+__device__ __forceinline__ void traj_emit_wave0(TrajState* s, const TrajParams& p, int idx, float* __restrict__ M_out,
+                                                double* __restrict__ Minv_out, vs_debug_frame* dbg,
+                                                const float (*l_path)[3], const float (*l_tr)[3], const float* l_mag,
+                                                const float* l_dir, const int n, const int istart) {
+    const int lane = threadIdx.x & 63;
     auto path_at = [&](int i, int c) -> float { return l_path[i & (TRAJ_RING - 1)][c]; };
     auto tr_at = [&](int i, int c) -> float { return l_tr[i & (TRAJ_RING - 1)][c]; };
-    dbg->out_index = idx; dbg->box_radius = 0; dbg->intent = 0;
     if (idx >= n) {   // Stabilizer.cpp:774-780: no transform for this frame -> frame returned as is
-        M_out[0] = 1.f; M_out[1] = 0.f; M_out[2] = 0.f; M_out[3] = 0.f; M_out[4] = 1.f; M_out[5] = 0.f;
-        for (int i = 0; i < 6; i++) M_out[6 + i] = M_out[i];
-        warp_invert(M_out, Minv_out);
-        warp_invert(M_out + 6, Minv_out + 6);
-        for (int c = 0; c < 3; c++) dbg->smoothed[c] = 0.f;
-        for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
+        if (lane == 0) {
+            dbg->out_index = idx; dbg->box_radius = 0; dbg->intent = 0;
+            M_out[0] = 1.f; M_out[1] = 0.f; M_out[2] = 0.f; M_out[3] = 0.f; M_out[4] = 1.f; M_out[5] = 0.f;
+            for (int i = 0; i < 6; i++) M_out[6 + i] = M_out[i];
+            warp_invert(M_out, Minv_out);
+            warp_invert(M_out + 6, Minv_out + 6);
+            for (int c = 0; c < 3; c++) dbg->smoothed[c] = 0.f;
+            for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
+        }
         return;
     }
+    int box_radius = 0;
     float sm[3];
-    if (p.method == VS_SMOOTH_GAUSSIAN) {          // :1364-1413
+    if (p.method == VS_SMOOTH_GAUSSIAN) {          // :1364-1413, ksize <= GAUSS_MAX (63): one tap per lane
         const int ks = p.gauss_ksize, center = ks / 2;
+        float tap[3] = {0.f, 0.f, 0.f}, kw = 0.f;
+        if (lane < ks) {
+            // padded[idx + lane]: reflect padding as the reference builds it (clamped when n <= center)
+            const int q = idx + lane;
+            int src;
+            if (q < center) src = center - q;
+            else if (q < center + n) src = q - center;
+            else src = n - 1 - (q - center - n);
+            src = src < 0 ? 0 : (src > n - 1 ? n - 1 : src);
+            for (int c = 0; c < 3; c++) tap[c] = path_at(src, c);
+            kw = p.gauss_kernel[lane];
+        }
         for (int c = 0; c < 3; c++) {
             float acc = 0.0f;
-            for (int j = 0; j < ks; j++) {
-                // padded[idx + j]: reflect padding as the reference builds it (clamped when n <= center)
-                const int q = idx + j;
-                int src;
-                if (q < center) src = center - q;
-                else if (q < center + n) src = q - center;
-                else src = n - 1 - (q - center - n);
-                src = src < 0 ? 0 : (src > n - 1 ? n - 1 : src);
-                acc += path_at(src, c) * p.gauss_kernel[j];
-            }
+#pragma unroll
+            for (int j = 0; j < GAUSS_MAX; j++) acc += lane_value(tap[c], j) * lane_value(kw, j);   // taps >= ks: 0 * 0
             sm[c] = acc;
         }
-    } else if (p.method == VS_SMOOTH_KALMAN) {     // :1416-1458, advanced incrementally
-        const float q = 0.01f, r = 0.1f;
-        for (int c = 0; c < 3; c++) {
-            float* k = s->kal[c];   // x0,x1,P00,P01,P10,P11
-            int done = s->kal_n[c];
-            if (done == 0) {
-                k[0] = path_at(0, c); k[1] = 0.f; k[2] = k[3] = k[4] = k[5] = 0.f;
-                s->kal_last[c] = k[0];
-                done = 1;
+    } else if (p.method == VS_SMOOTH_KALMAN) {     // :1416-1458, advanced incrementally (a recursion: lane 0)
+        float r3[3] = {0.f, 0.f, 0.f};
+        if (lane == 0) {
+            const float q = 0.01f, r = 0.1f;
+            for (int c = 0; c < 3; c++) {
+                float* k = s->kal[c];   // x0,x1,P00,P01,P10,P11
+                int done = s->kal_n[c];
+                if (done == 0) {
+                    k[0] = path_at(0, c); k[1] = 0.f; k[2] = k[3] = k[4] = k[5] = 0.f;
+                    s->kal_last[c] = k[0];
+                    done = 1;
+                }
+                while (done <= idx) {
+                    const float xp0 = k[0] + k[1], xp1 = k[1];
+                    const float t00 = k[2] + k[4], t01 = k[3] + k[5], t10 = k[4], t11 = k[5];
+                    const float Q00 = (t00 + t01) + q, Q01 = t01, Q10 = t10 + t11, Q11 = t11 + q;
+                    const float S = Q00 + r;
+                    const float K0 = Q00 / S, K1 = Q01 / S;
+                    const float innov = path_at(done, c) - xp0;
+                    k[0] = xp0 + K0 * innov; k[1] = xp1 + K1 * innov;
+                    k[2] = Q00 - K0 * Q00; k[3] = Q01 - K0 * Q01;
+                    k[4] = Q10 - K1 * Q00; k[5] = Q11 - K1 * Q01;
+                    s->kal_last[c] = k[0];
+                    done++;
+                }
+                s->kal_n[c] = done;
+                r3[c] = s->kal_last[c];
             }
-            while (done <= idx) {
-                const float xp0 = k[0] + k[1], xp1 = k[1];
-                const float t00 = k[2] + k[4], t01 = k[3] + k[5], t10 = k[4], t11 = k[5];
-                const float Q00 = (t00 + t01) + q, Q01 = t01, Q10 = t10 + t11, Q11 = t11 + q;
-                const float S = Q00 + r;
-                const float K0 = Q00 / S, K1 = Q01 / S;
-                const float innov = path_at(done, c) - xp0;
-                k[0] = xp0 + K0 * innov; k[1] = xp1 + K1 * innov;
-                k[2] = Q00 - K0 * Q00; k[3] = Q01 - K0 * Q01;
-                k[4] = Q10 - K1 * Q00; k[5] = Q11 - K1 * Q01;
-                s->kal_last[c] = k[0];
-                done++;
-            }
-            s->kal_n[c] = done;
-            sm[c] = s->kal_last[c];
         }
+        for (int c = 0; c < 3; c++) sm[c] = lane_value(r3[c], 0);
     } else {                                         // :807-823 box with adaptive radius
-        // calculateAdaptiveRadius :1637-1673
+        // calculateAdaptiveRadius :1637-1673: statistics of the last <= 20 path samples, one per lane
         int ar = s->smoothing_radius;
         if (n >= 10) {
             const int start = n - 20 > 0 ? n - 20 : 0;
             const int count = n - start;
-            float mean[3] = {0, 0, 0}, var[3] = {0, 0, 0};
-            for (int i = start; i < n; i++) for (int c = 0; c < 3; c++) mean[c] += path_at(i, c);
+            float v[3] = {0.f, 0.f, 0.f};
+            if (lane < count)
+                for (int c = 0; c < 3; c++) v[c] = path_at(start + lane, c);
+            float mean[3], var[3];
+            for (int c = 0; c < 3; c++) mean[c] = seq_sum<20>(v[c]);
             for (int c = 0; c < 3; c++) mean[c] /= count;
-            for (int i = start; i < n; i++)
-                for (int c = 0; c < 3; c++) { const float d = path_at(i, c) - mean[c]; var[c] += d * d; }
+            for (int c = 0; c < 3; c++) var[c] = seq_sqdev<20>(lane < count ? v[c] : mean[c], mean[c]);
             for (int c = 0; c < 3; c++) var[c] /= count;
             const float total = sqrtf(var[0] + var[1] + var[2] * 1000);
             ar = (int)fmaxf(5.0f, fminf(25.0f, total * 2.0f));
         }
-        // boxFilterConvolve :1139-1172
+        // boxFilterConvolve :1139-1172: window of at most 2*50+1 samples, 64 per pass
         const int r = p.drone ? max(10, min(ar, 50)) : max(2, min(ar, 8));
-        dbg->box_radius = r;
+        box_radius = r;
         if (n <= r) {
             for (int c = 0; c < 3; c++) sm[c] = path_at(idx, c);
         } else {
             const int start = idx - r > 0 ? idx - r : 0;
             const int end = idx + r < n - 1 ? idx + r : n - 1;
-            for (int c = 0; c < 3; c++) {
-                float sum = 0.0f;
-                int count = 0;
-                for (int j = start; j <= end; j++) { sum += path_at(j, c); count++; }
-                sm[c] = sum / count;
+            const int count = end - start + 1;
+            float sum[3] = {0.f, 0.f, 0.f};
+            if (count <= 17) {            // radius <= 8: the usual case
+                float v[3] = {0.f, 0.f, 0.f};
+                if (lane < count)
+                    for (int c = 0; c < 3; c++) v[c] = path_at(start + lane, c);
+                for (int c = 0; c < 3; c++) sum[c] = seq_sum<17>(v[c]);
+            } else {                      // drone mode: up to 101 samples, 64 per pass
+                for (int base = start; base <= end; base += 64) {
+                    const int m = end - base + 1 < 64 ? end - base + 1 : 64;
+                    float v[3] = {0.f, 0.f, 0.f};
+                    if (lane < m)
+                        for (int c = 0; c < 3; c++) v[c] = path_at(base + lane, c);
+                    for (int c = 0; c < 3; c++)
+                        for (int j = 0; j < m; j++) sum[c] += lane_value(v[c], j);
+                }
             }
+            for (int c = 0; c < 3; c++) sm[c] = sum[c] / count;
         }
     }
     float raw[3], diff[3];
     for (int c = 0; c < 3; c++) {
         raw[c] = tr_at(idx, c);
         diff[c] = sm[c] - path_at(idx, c);      // :850-851
-        dbg->smoothed[c] = sm[c];
     }
+    int intent = 0;
     if (idx > 0) {                                   // :854-888, analyzeMotionIntent :1676-1719
-        int intent = 0;
         const float magnitude = sqrtf(raw[0] * raw[0] + raw[1] * raw[1]);
         const float angularVel = (float)((double)(fabsf(raw[2]) * 180.0f) / 3.14159265358979323846 * (double)30.0f);
         if (n >= 15) {
-            float mags[15], dirs[15];
-            int cnt = 0;
-            for (int i = istart; i < idx; i++) {
-                if (i < n) { mags[cnt] = l_mag[i - istart]; dirs[cnt] = l_dir[i - istart]; cnt++; }
-            }
+            // samples istart .. min(idx, n) - 1, one per lane (l_mag / l_dir were filled by lanes 0..14)
+            const int last = idx < n ? idx : n;
+            const int cnt = last - istart > 0 ? last - istart : 0;
+            const float mg = lane < cnt ? l_mag[lane] : 0.f, dr = lane < cnt ? l_dir[lane] : 0.f;
             if (cnt > 0) {
-                const float dv = variance_of(dirs, cnt);
-                const float mc = consistency_of(mags, cnt);
+                const float dv = wave_variance_of<15>(dr, cnt);
+                const float mc = wave_consistency_of<15>(mg, cnt);
                 if (dv < 0.5f && mc > 0.7f && magnitude > 5.0f) intent = 1;
                 else if (magnitude < 3.0f && mc < 0.3f && angularVel > 10.0f) intent = 2;
                 else if (magnitude > 3.0f && magnitude < 15.0f && dv > 0.5f) intent = 3;
             }
         }
-        dbg->intent = intent;
         // calculateAdaptiveStabilizationStrength :1722-1747 is consumed only for NORMAL (0.7)
         const float g = intent == 1 ? 0.5f : intent == 2 ? 1.0f : intent == 3 ? 0.8f : 0.7f;
         for (int c = 0; c < 3; c++) diff[c] *= g;
     }
+    if (lane != 0) return;
+    dbg->out_index = idx; dbg->box_radius = box_radius; dbg->intent = intent;
+    for (int c = 0; c < 3; c++) dbg->smoothed[c] = sm[c];
     const float dx = raw[0] + diff[0], dy = raw[1] + diff[1];
     float da = raw[2] + diff[2];
     if (p.horizon_lock) da = 0.0f;                   // :897-899
@@ -166,11 +222,10 @@ __device__ inline void traj_emit_lane0(TrajState* s, const TrajParams& p, int id
     for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
 }
 
-__device__ inline void traj_emit_device(TrajState* s, const TrajParams& p, int idx, float* __restrict__ M_out,
-                                        double* __restrict__ Minv_out, vs_debug_frame* dbg) {
-    // The history rings are mirrored into LDS by all lanes and the per-sample
-    // transcendental work of the intent analysis is spread over lanes; every
-    // float SUM is still accumulated by lane 0 in the reference's order.
+__device__ __forceinline__ void traj_emit_device(TrajState* s, const TrajParams& p, int idx, float* __restrict__ M_out,
+                                                 double* __restrict__ Minv_out, vs_debug_frame* dbg) {
+    // The history rings are mirrored into LDS by all lanes and the per-sample transcendental work of
+    // the intent analysis is spread over lanes.
     __shared__ float l_path[TRAJ_RING][3], l_tr[TRAJ_RING][3];
     __shared__ float l_mag[16], l_dir[16];
     const int n = s->n;
@@ -189,7 +244,7 @@ __device__ inline void traj_emit_device(TrajState* s, const TrajParams& p, int i
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) traj_emit_lane0(s, p, idx, M_out, Minv_out, dbg, l_path, l_tr, l_mag, l_dir, n, istart);
+    if (threadIdx.x < 64) traj_emit_wave0(s, p, idx, M_out, Minv_out, dbg, l_path, l_tr, l_mag, l_dir, n, istart);
 }
 
 }  // namespace vsd
