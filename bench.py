@@ -96,7 +96,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-stages", action="store_true", help="time every stage (adds event records)")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph when available")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--zero-copy", type=int, default=1,
+                    help="frames are read where they lie in HBM instead of being copied into the instance's queue")
+    ap.add_argument("--batch", type=int, default=16,
                     help="batch mode: analysis stages of this many consecutive pushes run as one launch each (1 = per-frame pipeline)")
     ap.add_argument("--warp-batch", type=int, default=8,
                     help="deferred output: results of this many consecutive pushes are warped by one launch (1 = one launch per push)")
@@ -134,6 +136,7 @@ def main():
     stabs = [vs.stabilizer(make_params(vs), device=local_rank) for _ in range(S)]
     for s in stabs:
         s.set_batch(BT)
+        s.set_zero_copy(bool(args.zero_copy))
         s.set_warp_batch(WB)
 
     preroll = 64   # past the 29-frame warm-up of smoothingRadius 30: every timed step produces a frame
@@ -218,7 +221,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d stream(s)/GPU %dx%d BGR8, 200 corners, 3-level LK 21x21, "
                                    "RANSAC partial affine, warpAffine; frames resident in HBM" % (S, W, H),
-                       "streams_per_gpu": S, "graph": bool(args.graph), "batch": BT, "warp_batch": WB,
+                       "streams_per_gpu": S, "graph": bool(args.graph), "batch": BT, "warp_batch": WB, "zero_copy": bool(args.zero_copy),
                        "timed_frames_per_rank": [int(r[1]) for r in per_rank]},
             "roofline": {"bound": "hbm", "kernel": "warp_affine_kernel<3>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

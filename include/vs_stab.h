@@ -224,6 +224,14 @@ int vs_stab_set_warp_batch(vs_stab* s, int frames);
  * be given its own d_out until then.  Must be chosen before the first frame (or after
  * vs_stab_clean).  NV12, border/crop modes and adaptive smoothing keep the per-frame path. */
 int vs_stab_set_batch(vs_stab* s, int frames);
+/* Zero-copy input for vs_stab_push_dev: the frame is read where the caller put it (decoder
+ * surface pool, resident clip) instead of being copied into the instance's queue - the
+ * reference aliases the caller's cv::Mat the same way (Stabilizer.cpp:376).  The buffer
+ * must stay valid and unchanged until the result of the same push count has been produced
+ * (clamp(smoothingRadius,5,35) further pushes plus the batch depth) or the queue has been
+ * drained with vs_stab_flush_dev.  Frames must be tightly packed.  The frame queue must be
+ * empty when the mode is switched. */
+int vs_stab_set_zero_copy(vs_stab* s, int enable);
 
 /* Per-stage device timing with HIP events recorded on the instance stream
  * (SURVEY.md section 5 "Tracing").  mode 0 = off, 1 = warp stage only,

@@ -263,6 +263,39 @@ def test_batch_mode_matches_per_frame_pipeline(gpu, batch, radius, n):
         s.close()
 
 
+@pytest.mark.parametrize("batch", [1, 8])
+def test_zero_copy_input_matches_queued_copy(gpu, batch):
+    """vs_stab_set_zero_copy: frames are read where the caller holds them (here: a resident clip that stays
+    untouched); same results as with the copy into the instance's queue, per-frame and batch mode alike."""
+    n = 40
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 31, 320, 240, n)
+    p = gpu.params(smoothing_radius=6)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(batch)
+    s2.set_zero_copy(True)
+    fb = clip[0].nbytes
+    d_in = capi.DevBuf(gpu, fb * n)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, fb * n), capi.DevBuf(gpu, fb * n)
+    k1 = k2 = 0
+    for i in range(n):
+        k1 += s1.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_ref.ptr + k1 * fb, 320 * 3)
+        k2 += s2.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr + k2 * fb, 320 * 3)
+    while s1.flush_dev(d_ref.ptr + k1 * fb, 320 * 3):
+        k1 += 1
+    while s2.flush_dev(d_got.ptr + k2 * fb, 320 * 3):
+        k2 += 1
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n
+    assert np.array_equal(d_ref.download((n, 240, 320, 3), np.uint8), d_got.download((n, 240, 320, 3), np.uint8))
+    with pytest.raises(capi.VsError):      # a padded stride cannot be read in place
+        s3 = gpu.stabilizer(p)
+        s3.set_zero_copy(True)
+        s3.push_dev(d_in.ptr, 316, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr, 316 * 3)
+    s1.close(); s2.close()
+
+
 def test_errors_are_loud(gpu):
     with pytest.raises(capi.VsError):
         gpu.stabilizer(gpu.params(enable_virtual_canvas=1))

@@ -99,7 +99,9 @@ struct vs_stab {
     int lw[MAX_PYR], lh[MAX_PYR];
     // frame queue (Stabilizer.h:311-312)
     uint8_t* d_ring = nullptr;
-    std::deque<int> q_slot, q_idx;
+    std::deque<int> q_slot, q_idx;      // ring slot (-1: the caller's own buffer, zero-copy mode) and frame index
+    std::deque<const uint8_t*> q_ptr;   // where the queued frame lives
+    bool zero_copy = false;             // vs_stab_set_zero_copy
     std::deque<int> free_slots;     // FIFO: the slot released longest ago is reused first
     bool first = true;
     int next_index = 0;             // index of the frame being pushed (nextFrameIndex_)
@@ -173,7 +175,7 @@ struct vs_stab {
         const uint8_t* frame; bool prev_small;
         bool detect; int det_buf;
         int lk_buf, lk_cap;
-        bool out_due; int out_slot, out_idx; uint8_t* d_out; size_t out_stride;
+        bool out_due; int out_slot, out_idx; const uint8_t* out_frame; uint8_t* d_out; size_t out_stride;
         int have_prev_gray;
     };
     std::vector<BFrame> bq;
@@ -254,7 +256,7 @@ void out_size(const vs_stab* s, int w, int h, int* ow, int* oh) {
     *ow = w; *oh = h;   // crop+zoom resizes back to origSize_ == frame size
 }
 
-int flush_warps(vs_stab* s);
+int flush_warps(vs_stab* s, bool on_main = false);
 int run_batch(vs_stab* s);
 
 int sync_all(vs_stab* s) {
@@ -539,25 +541,32 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame, int f) {
     return VS_OK;
 }
 
-// One launch for all pending warps, on the warp stream; releases their ring slots.
-int flush_warps(vs_stab* s) {
+// One launch for all pending warps; releases their ring slots.  Per-frame pipeline: on the high-priority warp
+// stream, so that the analysis of the next frames is not held up.  Batch mode (on_main): in line on `main`,
+// between the tail of this batch and the tracking of the next - the tracking kernel keeps ~90 KB of LDS per
+// CU busy for its whole (latency-bound) run, which would leave room for 3 warp workgroups per CU instead of 8.
+int flush_warps(vs_stab* s, bool on_main) {
     if (s->pend.empty()) return VS_OK;
+    hipStream_t ws = on_main ? s->st : s->st_warp;
     const int n = (int)s->pend.size(), set = s->pend_set;
     const uint8_t* srcs[WARP_BATCH_MAX];
     uint8_t* dsts[WARP_BATCH_MAX];
     for (int i = 0; i < n; i++) { srcs[i] = s->pend[i].src; dsts[i] = s->pend[i].dst; }
-    S_HIP(s, hipEventRecord(s->ev_emit, s->st));                 // the maps of this batch are written on `main`
-    S_HIP(s, hipStreamWaitEvent(s->st_warp, s->ev_emit, 0));
+    if (!on_main) {
+        S_HIP(s, hipEventRecord(s->ev_emit, s->st));             // the maps of this batch are written on `main`
+        S_HIP(s, hipStreamWaitEvent(ws, s->ev_emit, 0));
+    }
     int rc;
     {
-        StageScope t(s, VS_STAGE_WARP, s->st_warp);
+        StageScope t(s, VS_STAGE_WARP, ws);
         rc = launch_warp_affine_list(srcs, dsts, n, s->row_bytes, s->w, s->h, s->pend_stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[set], 12, s->st_warp);
+                                     s->d_MinvB[set], 12, ws);
     }
-    if (hipEventRecord(s->ev_warp[set], s->st_warp) == hipSuccess) s->warp_valid[set] = true;
+    if (hipEventRecord(s->ev_warp[set], ws) == hipSuccess) s->warp_valid[set] = true;
     for (int i = 0; i < n; i++) {
         const int slot = s->pend[i].slot;
-        if (hipEventRecord(s->ev_slot[slot], s->st_warp) == hipSuccess) s->slot_valid[slot] = true;
+        if (slot < 0) continue;          // zero-copy: the frame is the caller's
+        if (hipEventRecord(s->ev_slot[slot], ws) == hipSuccess) s->slot_valid[slot] = true;
         s->free_slots.push_back(slot);
     }
     s->pend.clear();
@@ -590,8 +599,8 @@ int defer_output(vs_stab* s, int idx, const uint8_t* frame, uint8_t* d_out, size
 int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
     const vs_params_c& p = s->p;
     const int slot = s->q_slot.front(), idx = s->q_idx.front();
-    s->q_slot.pop_front(); s->q_idx.pop_front();
-    const uint8_t* frame = s->d_ring + (size_t)slot * s->frame_bytes;
+    const uint8_t* frame = s->q_ptr.front();
+    s->q_slot.pop_front(); s->q_idx.pop_front(); s->q_ptr.pop_front();
     hipStream_t st = s->st;
     int ow, oh;
     out_size(s, s->w, s->h, &ow, &oh);
@@ -640,8 +649,10 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
         rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
     }
     // the slot may be overwritten once this warp has read it
-    if (hipEventRecord(s->ev_slot[slot], st) == hipSuccess) s->slot_valid[slot] = true;
-    s->free_slots.push_back(slot);
+    if (slot >= 0) {
+        if (hipEventRecord(s->ev_slot[slot], st) == hipSuccess) s->slot_valid[slot] = true;
+        s->free_slots.push_back(slot);
+    }
     if (rc != VS_OK) { s->err = get_last_error(); return rc; }
     s->counters.frames_out++;
     return VS_OK;
@@ -674,12 +685,12 @@ int batch_enqueue(vs_stab* s, const uint8_t* frame, int slot, int f, uint8_t* d_
     s->n_transforms++;
     s->have_prev_gray = true;
     s->last_gray_buf = c;
-    s->q_slot.push_back(slot); s->q_idx.push_back(f);                                // :376-377
+    s->q_slot.push_back(slot); s->q_idx.push_back(f); s->q_ptr.push_back(frame);     // :376-377
     const int R = effective_radius(s->host_radius);                                  // :383
     if ((int)s->q_idx.size() >= R) {                                                 // :384-389
         b.out_due = true;
-        b.out_slot = s->q_slot.front(); b.out_idx = s->q_idx.front();
-        s->q_slot.pop_front(); s->q_idx.pop_front();
+        b.out_slot = s->q_slot.front(); b.out_idx = s->q_idx.front(); b.out_frame = s->q_ptr.front();
+        s->q_slot.pop_front(); s->q_idx.pop_front(); s->q_ptr.pop_front();
         b.d_out = d_out; b.out_stride = out_stride;
         out_size(s, s->w, s->h, &s->last_out_w, &s->last_out_h);
         s->counters.frames_out++;
@@ -807,7 +818,7 @@ int run_batch(vs_stab* s) {
             if (b.out_due) {
                 if (!s->pend.empty() && s->pend_stride != b.out_stride) return fail(s, VS_ERR_INVALID_ARG, "batch mode: the output stride must not change within a batch");
                 minv = s->d_MinvB[set] + 12 * s->pend.size();
-                s->pend.push_back({s->d_ring + (size_t)b.out_slot * s->frame_bytes, b.d_out, b.out_slot});
+                s->pend.push_back({b.out_frame, b.d_out, b.out_slot});
                 s->pend_stride = b.out_stride;
             }
             tail_fill_item(s->h_tail.data() + tail_item_bytes() * i, b.out_due ? 1 : 0, b.out_idx, minv);
@@ -817,7 +828,7 @@ int run_batch(vs_stab* s) {
             StageScope t(s, VS_STAGE_TRAJ, st);
             S_TRY(s, launch_ransac_tail_batch(s->d_rs_table, s->d_tail_table, n, s->d_M, st));
         }
-        S_TRY(s, flush_warps(s));
+        S_TRY(s, flush_warps(s, true));
     }
     const vs_stab::BFrame& lb = s->bq[n - 1];
     s->dbg_prev_pts = s->d_pts[lb.lk_buf]; s->dbg_next = s->items[n - 1].next;
@@ -840,9 +851,9 @@ int check_params(const vs_params_c* p, std::string* why) {
 }
 
 // Shared body of stabilize(): the frame is already on its way into ring slot `slot` (on `pre`).
-int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* produced, bool may_defer) {
+int push_common(vs_stab* s, int slot, const uint8_t* zc_frame, uint8_t* d_out, size_t out_stride, int* produced, bool may_defer) {
     const vs_params_c& p = s->p;
-    const uint8_t* frame = s->d_ring + (size_t)slot * s->frame_bytes;
+    const uint8_t* frame = slot >= 0 ? s->d_ring + (size_t)slot * s->frame_bytes : zc_frame;
     *produced = 0;
     s->counters.frames_in++;
     if (p.crop_n_zoom && s->orig_w == 0) { s->orig_w = s->w; s->orig_h = s->h; }   // :267-269
@@ -860,7 +871,7 @@ int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* pr
         s->dbg_det_pts = s->d_pts[0]; s->dbg_det_n = s->d_npts[0];
         s->counters.detections++;
         s->prev_small = true; s->have_prev_gray = true;
-        s->q_slot.push_back(slot); s->q_idx.push_back(0);
+        s->q_slot.push_back(slot); s->q_idx.push_back(0); s->q_ptr.push_back(frame);
         s->first = false; s->next_index = 1;
         return VS_OK;
     }
@@ -870,7 +881,7 @@ int push_common(vs_stab* s, int slot, uint8_t* d_out, size_t out_stride, int* pr
         if (!may_defer) { S_TRY(s, run_batch(s)); S_TRY(s, flush_warps(s)); }
         return VS_OK;
     }
-    s->q_slot.push_back(slot); s->q_idx.push_back(s->next_index);                   // :376-377
+    s->q_slot.push_back(slot); s->q_idx.push_back(s->next_index); s->q_ptr.push_back(frame);   // :376-377
     S_TRY(s, generate_transform(s, frame, s->next_index));                          // :380
     if (p.adaptive_smoothing) {
         // params_.smoothingRadius is data dependent in this mode (:1482-1486) and
@@ -999,7 +1010,7 @@ int vs_stab_clean(vs_stab* s) {   // Stabilizer.cpp:221-256
     if (!s) return VS_ERR_INVALID_ARG;
     S_TRY(s, sync_all(s));
     free_all(s);
-    s->q_slot.clear(); s->q_idx.clear();
+    s->q_slot.clear(); s->q_idx.clear(); s->q_ptr.clear();
     s->first = true; s->next_index = 0; s->w = s->h = 0; s->orig_w = s->orig_h = 0; s->n_transforms = 0;
     s->have_prev_gray = false; s->prev_small = false; s->pp = 0;
     s->host_radius = s->p.smoothing_radius;
@@ -1019,10 +1030,15 @@ int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride
     if (!d_data) return VS_OK;   // empty frame -> empty result (Stabilizer.cpp:263-265)
     int rc = prepare(s, w, h, fmt, stride);
     if (rc != VS_OK) return rc;
+    if (s->zero_copy) {
+        // the frame is read where it is: it must stay valid and unchanged until its own result has been produced
+        if (stride != s->row_bytes) return fail(s, VS_ERR_INVALID_ARG, "zero-copy mode: frames must be tightly packed (stride == width*channels)");
+        return push_common(s, -1, (const uint8_t*)d_data, (uint8_t*)d_out, out_stride, produced, true);
+    }
     int slot;
     S_TRY(s, take_slot(s, &slot));
     S_TRY(s, enqueue_copy_in(s, slot, d_data, stride, hipMemcpyDeviceToDevice));
-    return push_common(s, slot, (uint8_t*)d_out, out_stride, produced, true);
+    return push_common(s, slot, nullptr, (uint8_t*)d_out, out_stride, produced, true);
 }
 
 static int flush_dev_impl(vs_stab* s, void* d_out, size_t out_stride, int* produced, bool may_defer_flush) {
@@ -1055,7 +1071,7 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
     const size_t orow = (size_t)ow * s->cn;
     S_TRY(s, run_batch(s));
     S_TRY(s, flush_warps(s));
-    rc = push_common(s, slot, s->d_out, orow, produced, false);
+    rc = push_common(s, slot, nullptr, s->d_out, orow, produced, false);
     if (rc != VS_OK) return rc;
     if (*produced) {
         if (!out || out_stride < orow) return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
@@ -1105,6 +1121,17 @@ int vs_stab_set_batch(vs_stab* s, int frames) {
     if (s->allocated) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_batch: call before the first frame or after vs_stab_clean");
     s->batch = frames;
     if (frames > 1) s->warp_batch = frames;
+    return VS_OK;
+}
+
+// Zero-copy input for vs_stab_push_dev: the frame is not copied into the instance's queue but read where the
+// caller put it (a decoder surface pool, a resident clip).  It must stay valid and unchanged until the result
+// of the SAME push count has been produced, i.e. for clamp(smoothingRadius,5,35) further pushes plus the
+// batch depth, or until vs_stab_flush_dev has drained the queue.  Frames must be tightly packed.
+int vs_stab_set_zero_copy(vs_stab* s, int enable) {
+    if (!s) return VS_ERR_INVALID_ARG;
+    if (!s->q_slot.empty()) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_zero_copy: the frame queue must be empty");
+    s->zero_copy = enable != 0;
     return VS_OK;
 }
 
