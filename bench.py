@@ -202,7 +202,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "warp_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                t = json.load(open(pmc))
+                # measured on full launches of t["frames_per_launch"] frames of 1920x1080 BGR8; scale to this run's launch
+                traffic = round(t["hbm_bytes_per_launch"] / t["frames_per_launch"] * frames_per_launch * (fb / (1920 * 1080 * 3.0)))
             except Exception:
                 traffic = None
         total_frames = args.steps * S * n_gpus

@@ -139,23 +139,35 @@ __device__ __forceinline__ void nms_row(const float* __restrict__ eig, int w, in
                                         int32_t* __restrict__ counters) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
-    const float maxv = key_to_float(*max_key);
-    const float thr = (float)((double)maxv * quality);
-    const float* r = eig + (size_t)y * w + x;
-    const float v = r[0] > thr ? r[0] : 0.f;   // THRESH_TOZERO
-    if (v == 0.f) return;
-    float m = v;
+    bool is_cand = false;
+    float v = 0.f;
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+        const float maxv = key_to_float(*max_key);
+        const float thr = (float)((double)maxv * quality);
+        const float* r = eig + (size_t)y * w + x;
+        v = r[0] > thr ? r[0] : 0.f;   // THRESH_TOZERO
+        if (v != 0.f) {
+            float m = v;
 #pragma unroll
-    for (int j = -1; j <= 1; j++)
+            for (int j = -1; j <= 1; j++)
 #pragma unroll
-        for (int i = -1; i <= 1; i++) {
-            const float n = r[j * w + i];
-            const float tn = n > thr ? n : 0.f;
-            m = tn > m ? tn : m;
+                for (int i = -1; i <= 1; i++) {
+                    const float n = r[j * w + i];
+                    const float tn = n > thr ? n : 0.f;
+                    m = tn > m ? tn : m;
+                }
+            is_cand = v == m;
         }
-    if (v != m) return;
-    const int pos = atomicAdd(&counters[0], 1);
+    }
+    // one atomic per wave: the list is sorted by (value, index) afterwards, so its order is free
+    const unsigned long long mask = __ballot(is_cand);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&counters[0], __popcll(mask));
+    base = __builtin_amdgcn_readlane(base, __ffsll((long long)mask) - 1);
+    if (!is_cand) return;
+    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
     if (pos < cap) cand[pos] = ((unsigned long long)order_key(v) << 32) | (uint32_t)(y * w + x);
     else counters[2] = 1;
 }
