@@ -95,7 +95,6 @@ def main():
     ap.add_argument("--clip-frames", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-stages", action="store_true", help="time every stage (adds event records)")
-    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph when available")
     ap.add_argument("--zero-copy", type=int, default=1,
                     help="frames are read where they lie in HBM instead of being copied into the instance's queue")
     ap.add_argument("--batch", type=int, default=16,
@@ -157,9 +156,6 @@ def main():
     for i in range(preroll):
         step(i)
     sync_all()
-    if args.graph:
-        for s in stabs:
-            s.enable_graph(True)
     for i in range(preroll, preroll + args.warmup):
         step(i)
     for s in stabs:
@@ -223,7 +219,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d stream(s)/GPU %dx%d BGR8, 200 corners, 3-level LK 21x21, "
                                    "RANSAC partial affine, warpAffine; frames resident in HBM" % (S, W, H),
-                       "streams_per_gpu": S, "graph": bool(args.graph), "batch": BT, "warp_batch": WB, "zero_copy": bool(args.zero_copy),
+                       "streams_per_gpu": S, "batch": BT, "warp_batch": WB, "zero_copy": bool(args.zero_copy),
                        "timed_frames_per_rank": [int(r[1]) for r in per_rank]},
             "roofline": {"bound": "hbm", "kernel": "warp_affine_kernel<3>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

@@ -205,8 +205,9 @@ int vs_stab_get_debug_arrays(vs_stab* s, float* prev_pts, float* curr_pts,
                              float* detected_pts, uint8_t* gray, int* aw, int* ah);
 const char* vs_stab_last_error(const vs_stab* s);
 void*       vs_stab_stream(vs_stab* s);    /* hipStream_t of the instance     */
-/* capture one steady-state push_dev into a hipGraph and replay it from then
- * on (two variants: with / without re-detection).  0 disables. */
+/* Reserved: accepted and ignored.  Graph replay of the per-frame step was superseded by
+ * the batch mode below (the step is bound by latency chains, not by launch overhead -
+ * DESIGN.md section 5); kept so that callers written against ABI 1 keep linking. */
 int vs_stab_enable_graph(vs_stab* s, int enable);
 /* Deferred output for vs_stab_push_dev / vs_stab_flush_dev (batch / file-to-file use): the
  * warps of up to `frames` (1..16) consecutive results are issued as ONE kernel launch, each

@@ -1239,7 +1239,7 @@ int vs_stab_get_stage_times(vs_stab* s, double* total_ms, int64_t* launches) {
 
 int vs_stab_enable_graph(vs_stab* s, int enable) {
     if (!s) return VS_ERR_INVALID_ARG;
-    (void)enable;   // capture is added in a later step; eager launches are always correct
+    (void)enable;   // reserved (see vs_stab.h): the batch mode replaced graph replay
     return VS_OK;
 }
 
