@@ -97,8 +97,9 @@ struct CropScratch {
     std::vector<int8_t> img;          // labelled copy of the mask inside a zero frame
     std::vector<P2> best, cur;        // SIMPLE points of the largest / current contour
     std::vector<int> chain_best, chain_cur;   // every border pixel (frame coordinates) of the same
-    std::vector<int> row_cnt, col_cnt;        // prefix counts of filled pixels
-    std::vector<int> sx, sy, cross;
+    struct Span { int a, b; };                // filled pixels a..b (inclusive) of one row
+    std::vector<std::vector<Span>> spans;     // the filled contour, row by row (merged, ascending)
+    std::vector<int> sx, sy;
     std::vector<std::vector<int>> rows;       // crossings per row
 };
 
@@ -174,41 +175,43 @@ int trace_largest(const uint8_t* mask, int w, int h, size_t stride, CropScratch&
     return n_contours;
 }
 
-// Prefix counts of the filled contour (cv::drawContours FILLED): interior by the even-odd rule on the
-// border chain (each chain step that changes row is one crossing of the upper of its two rows) plus
-// the border pixels themselves.  row_cnt[y*(w+1)+x] = filled pixels in row y left of x; col_cnt likewise.
-void fill_counts(int w, int h, CropScratch& S, std::vector<uint8_t>* dump) {
+// The filled contour (cv::drawContours FILLED) as row spans: interior by the even-odd rule on the border chain
+// (each chain step that changes row is one crossing of the upper of its two rows) plus the border pixels
+// themselves.  Nothing of the size of the image is written: the shrink loop below only asks how many pixels
+// of a row / column segment are NOT filled.
+void fill_spans(int w, int h, CropScratch& S, std::vector<uint8_t>* dump) {
     const int W = w + 2;
-    std::vector<uint8_t> filled((size_t)w * h, 0);
-    S.rows.resize(h);
-    for (auto& r : S.rows) r.clear();
+    typedef CropScratch::Span Span;
+    S.rows.resize(h); S.spans.resize(h);
+    for (int y = 0; y < h; y++) { S.rows[y].clear(); S.spans[y].clear(); }
     const size_t n = S.chain_best.size();
     for (size_t i = 0; i < n; i++) {
         const int a = S.chain_best[i], b = S.chain_best[(i + 1) % n];
         const int ay = a / W - 1, ax = a % W - 1, by = b / W - 1, bx = b % W - 1;
-        filled[(size_t)ay * w + ax] = 255;
+        S.spans[ay].push_back(Span{ax, ax});
         if (ay == by) continue;
         if (ay < by) S.rows[ay].push_back(ax); else S.rows[by].push_back(bx);
     }
     for (int y = 0; y < h; y++) {
         std::vector<int>& r = S.rows[y];
-        if (r.empty()) continue;
+        std::vector<Span>& sp = S.spans[y];
+        if (sp.empty()) continue;
         std::sort(r.begin(), r.end());
         for (size_t k = 0; k + 1 < r.size(); k += 2)
-            if (r[k + 1] > r[k]) memset(&filled[(size_t)y * w + r[k]], 255, (size_t)(r[k + 1] - r[k] + 1));
+            if (r[k + 1] > r[k]) sp.push_back(Span{r[k], r[k + 1]});
+        std::sort(sp.begin(), sp.end(), [](const Span& p, const Span& q) { return p.a < q.a; });
+        size_t m = 0;
+        for (size_t k = 1; k < sp.size(); k++) {
+            if (sp[k].a <= sp[m].b + 1) sp[m].b = std::max(sp[m].b, sp[k].b);
+            else sp[++m] = sp[k];
+        }
+        sp.resize(m + 1);
     }
-    S.row_cnt.assign((size_t)h * (w + 1), 0);
-    S.col_cnt.assign((size_t)w * (h + 1), 0);
-    for (int y = 0; y < h; y++) {
-        int* rc = &S.row_cnt[(size_t)y * (w + 1)];
-        const uint8_t* f = &filled[(size_t)y * w];
-        for (int x = 0; x < w; x++) rc[x + 1] = rc[x] + (f[x] != 0);
+    if (dump) {
+        dump->assign((size_t)w * h, 0);
+        for (int y = 0; y < h; y++)
+            for (const Span& q : S.spans[y]) memset(&(*dump)[(size_t)y * w + q.a], 255, (size_t)(q.b - q.a + 1));
     }
-    for (int y = 0; y < h; y++) {
-        const uint8_t* f = &filled[(size_t)y * w];
-        for (int x = 0; x < w; x++) S.col_cnt[(size_t)x * (h + 1) + y + 1] = S.col_cnt[(size_t)x * (h + 1) + y] + (f[x] != 0);
-    }
-    if (dump) dump->swap(filled);
 }
 
 // info = {n_contours, contour_points, x, y, w, h, iterations, valid}
@@ -218,18 +221,27 @@ void crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, CropScratc
     info[0] = trace_largest(mask, w, h, stride, S);
     if (info[0] == 0) return;
     info[1] = (int)S.best.size();
-    fill_counts(w, h, S, filled_dump);
+    fill_spans(w, h, S, filled_dump);
     S.sx.clear(); S.sy.clear();
     for (const P2& p : S.best) { S.sx.push_back(p.x); S.sy.push_back(p.y); }
     std::sort(S.sx.begin(), S.sx.end());
     std::sort(S.sy.begin(), S.sy.end());
     auto row_zeros = [&](int y, int xa, int xb) {   // zeros in row y, columns [xa, xb)
-        const int* rc = &S.row_cnt[(size_t)y * (w + 1)];
-        return (xb - xa) - (rc[xb] - rc[xa]);
+        int filled = 0;
+        for (const CropScratch::Span& q : S.spans[y]) {
+            const int lo = std::max(q.a, xa), hi = std::min(q.b, xb - 1);
+            if (hi >= lo) filled += hi - lo + 1;
+        }
+        return (xb - xa) - filled;
     };
-    auto col_zeros = [&](int x, int ya, int yb) {
-        const int* cc = &S.col_cnt[(size_t)x * (h + 1)];
-        return (yb - ya) - (cc[yb] - cc[ya]);
+    auto col_zeros = [&](int x, int ya, int yb) {   // zeros in column x, rows [ya, yb)
+        int zeros = 0;
+        for (int y = ya; y < yb; y++) {
+            bool in = false;
+            for (const CropScratch::Span& q : S.spans[y]) if (q.a <= x && x <= q.b) { in = true; break; }
+            zeros += !in;
+        }
+        return zeros;
     };
     size_t lo_x = 0, hi_x = S.sx.size() - 1, lo_y = 0, hi_y = S.sy.size() - 1;
     int bx = 0, by = 0, bw = 0, bh = 0, iters = 0;

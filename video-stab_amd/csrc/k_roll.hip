@@ -7,9 +7,11 @@
 //   resize x0.25 + BGR2GRAY (fused, k_gray.hip)
 //   sobel_kernel      3x3 Sobel, BORDER_REPLICATE -> dx,dy (int16) and L1 magnitude
 //   canny_nms_kernel  non-maximum suppression with the tan(22.5) fixed-point sectors,
-//                     double threshold -> map {0 maybe, 1 no, 2 edge}; strong edges queued
-//   canny_hyst_kernel ONE workgroup, breadth-first growth of the edge set through the
-//                     "maybe" pixels (atomicCAS on the map, frontier in a global queue)
+//                     double threshold -> map {0 maybe, 1 no, 2 edge}
+//   canny_hyst_tile_kernel  growth of the edge set through the "maybe" pixels: every 64x32 tile is iterated
+//                     to its own fixed point in LDS; passes over the image repeat until a pass changes
+//                     nothing (chains that cross tile borders; the host reads one flag word per group
+//                     of passes)
 //   hough_accum_kernel  votes of every (edge pixel, angle) pair, float rho as cv::HoughLines
 //   hough_peaks_kernel  local maxima above the threshold -> (votes, index) keys
 //   hough_select_kernel ONE workgroup: bitonic sort (votes desc, index asc) and the
@@ -51,8 +53,7 @@ __global__ __launch_bounds__(NT) void sobel_kernel(const uint8_t* __restrict__ g
 
 // map/mag are framed with one pixel (map frame = 1, mag frame = 0), row pitch mw = w + 2
 __global__ __launch_bounds__(NT) void canny_nms_kernel(const short2* __restrict__ dxy, const int* __restrict__ mag,
-                                                       int w, int h, int mw, int low, int high, int* __restrict__ map,
-                                                       int* __restrict__ queue, int* __restrict__ counters) {
+                                                       int w, int h, int mw, int low, int high, int* __restrict__ map) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w || y >= h) return;
     const int p = (y + 1) * mw + x + 1;
@@ -76,36 +77,52 @@ __global__ __launch_bounds__(NT) void canny_nms_kernel(const short2* __restrict_
             }
         }
         if (is_max) {
-            if (m > high) { out = 2; queue[atomicAdd(&counters[0], 1)] = p; }
-            else out = 0;
+            out = m > high ? 2 : 0;
         }
     }
     map[p] = out;
 }
 
-__global__ __launch_bounds__(1024) void canny_hyst_kernel(int* __restrict__ map, int mw, int* __restrict__ queue,
-                                                          int* __restrict__ counters) {
-    __shared__ int s_head, s_tail;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_head = 0; s_tail = counters[0]; }
-    __syncthreads();
-    while (true) {
-        const int head = s_head, tail = s_tail;
-        if (head >= tail) break;
+constexpr int HT_W = 64, HT_H = 32;      // hysteresis tile
+
+// One pass: each tile grows its edges (2) through its candidates (0) until nothing changes inside the tile; the
+// halo is read as the neighbours left it.  Growth is monotone, so concurrent tiles can only help each other.
+__global__ __launch_bounds__(NT) void canny_hyst_tile_kernel(int* __restrict__ map, int mw, int w, int h,
+                                                             int* __restrict__ changed) {
+    __shared__ int8_t t[HT_H + 2][HT_W + 2 + 2];
+    __shared__ int s_flag;
+    const int x0 = blockIdx.x * HT_W, y0 = blockIdx.y * HT_H, tid = threadIdx.x;
+    for (int i = tid; i < (HT_H + 2) * (HT_W + 2); i += NT) {
+        const int ly = i / (HT_W + 2), lx = i - ly * (HT_W + 2);
+        const int x = x0 + lx - 1, y = y0 + ly - 1;           // image coordinates; the map has a frame of 1s
+        int8_t v = 1;
+        if (x >= -1 && x <= w && y >= -1 && y <= h) v = (int8_t)map[(y + 1) * mw + x + 1];
+        t[ly][lx] = v;
+    }
+    bool mine = false;
+    for (;;) {
         __syncthreads();
-        for (int i = head + tid; i < tail; i += 1024) {
-            const int p = __hip_atomic_load(&queue[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int nb[8] = {-mw - 1, -mw, -mw + 1, -1, 1, mw - 1, mw, mw + 1};
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int q = p + nb[k];
-                if (atomicCAS(&map[q], 0, 2) == 0) queue[atomicAdd(&counters[0], 1)] = q;
-            }
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        bool grew = false;
+        for (int i = tid; i < HT_H * HT_W; i += NT) {
+            const int ly = i / HT_W + 1, lx = i % HT_W + 1;
+            if (t[ly][lx] != 0) continue;
+            const bool near = t[ly - 1][lx - 1] == 2 || t[ly - 1][lx] == 2 || t[ly - 1][lx + 1] == 2 || t[ly][lx - 1] == 2 ||
+                              t[ly][lx + 1] == 2 || t[ly + 1][lx - 1] == 2 || t[ly + 1][lx] == 2 || t[ly + 1][lx + 1] == 2;
+            if (near) { t[ly][lx] = 2; grew = true; }
         }
-        __threadfence();
+        if (grew) { s_flag = 1; mine = true; }
         __syncthreads();
-        if (tid == 0) { s_head = tail; s_tail = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        __syncthreads();
+        if (!s_flag) break;
+    }
+    if (__syncthreads_or(mine)) {
+        for (int i = tid; i < HT_H * HT_W; i += NT) {
+            const int ly = i / HT_W + 1, lx = i % HT_W + 1;
+            const int x = x0 + lx - 1, y = y0 + ly - 1;
+            if (x < w && y < h && t[ly][lx] == 2) map[(y + 1) * mw + x + 1] = 2;
+        }
+        if (tid == 0) *changed = 1;
     }
 }
 
@@ -302,10 +319,24 @@ static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double l
     const int low = (int)std::floor(low_t), high = (int)std::floor(high_t);
     const int w = k.w, h = k.h;
     dim3 grid((w + NT - 1) / NT, h);
-    VS_HIP_TRY(hipMemsetAsync(k.counters, 0, 64, st));
     hipLaunchKernelGGL(sobel_kernel, grid, dim3(NT), 0, st, d_gray, stride, w, h, k.dxy, k.mag, k.mw);
-    hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.map, k.queue, k.counters);
-    hipLaunchKernelGGL(canny_hyst_kernel, dim3(1), dim3(1024), 0, st, k.map, k.mw, k.queue, k.counters);
+    hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.map);
+    VS_HIP_TRY(hipGetLastError());
+    // hysteresis: passes in groups of 2, 4, 8, 16, 16, ...; one flag word per pass, read back per group.  A pass
+    // that changed nothing ends the growth (later passes of its group were no-ops).
+    {
+        dim3 hg((w + HT_W - 1) / HT_W, (h + HT_H - 1) / HT_H);
+        int32_t flags[16];
+        for (int group = 2;; group = group < 16 ? group * 2 : 16) {
+            VS_HIP_TRY(hipMemsetAsync(k.counters, 0, 64, st));
+            for (int p = 0; p < group; p++)
+                hipLaunchKernelGGL(canny_hyst_tile_kernel, hg, dim3(NT), 0, st, k.map, k.mw, w, h, k.counters + p);
+            VS_HIP_TRY(hipGetLastError());
+            VS_HIP_TRY(hipMemcpyAsync(flags, k.counters, 64, hipMemcpyDeviceToHost, st));
+            VS_HIP_TRY(hipStreamSynchronize(st));
+            if (!flags[group - 1]) break;
+        }
+    }
     hipLaunchKernelGGL(canny_out_kernel, grid, dim3(NT), 0, st, k.map, w, h, k.mw, d_edges, estride);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
