@@ -21,7 +21,10 @@
 #include <algorithm>
 #include <array>
 #include <cstring>
+#include <cstdlib>
 #include <deque>
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -88,6 +91,7 @@ struct vs_stab {
     hipStream_t st_pre = nullptr;
     hipStream_t st_det = nullptr;
     hipStream_t st_warp = nullptr;  // deferred (batched) warps, high priority
+    bool shared_streams = false;    // the four streams belong to the per-device pool
     std::string err;
     // geometry, fixed by the first frame
     bool allocated = false;
@@ -950,6 +954,61 @@ int create_events(vs_stab* s) {
 
 }  // namespace
 
+// All instances of a process on one device share ONE set of four HIP streams (unless VS_STAB_PRIVATE_STREAMS
+// is set).  Every instance's launches are already wide in batch mode, and the runtime maps HIP streams onto a
+// handful of hardware queues: with four private streams per instance, 2 instances ran at 0.9x and 8 instances
+// at 0.15x of ONE instance's total throughput; on shared streams the instances simply take turns.
+namespace {
+struct StreamPool {
+    hipStream_t st = nullptr, pre = nullptr, det = nullptr, warp = nullptr;
+    int refs = 0;
+};
+std::mutex g_pool_mutex;
+std::map<int, StreamPool> g_pools;
+
+hipError_t make_streams(hipStream_t* st, hipStream_t* pre, hipStream_t* det, hipStream_t* warp) {
+    hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(pre, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(det, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(warp, hipStreamNonBlocking, greatest);
+    }
+    return e;
+}
+
+hipError_t acquire_streams(vs_stab* s) {
+    if (std::getenv("VS_STAB_PRIVATE_STREAMS")) return make_streams(&s->st, &s->st_pre, &s->st_det, &s->st_warp);
+    std::lock_guard<std::mutex> g(g_pool_mutex);
+    StreamPool& p = g_pools[s->device];
+    if (p.refs == 0) {
+        hipError_t e = make_streams(&p.st, &p.pre, &p.det, &p.warp);
+        if (e != hipSuccess) return e;
+    }
+    p.refs++;
+    s->st = p.st; s->st_pre = p.pre; s->st_det = p.det; s->st_warp = p.warp;
+    s->shared_streams = true;
+    return hipSuccess;
+}
+
+void release_streams(vs_stab* s) {
+    if (!s->shared_streams) {
+        if (s->st) (void)hipStreamDestroy(s->st);
+        if (s->st_pre) (void)hipStreamDestroy(s->st_pre);
+        if (s->st_det) (void)hipStreamDestroy(s->st_det);
+        if (s->st_warp) (void)hipStreamDestroy(s->st_warp);
+        return;
+    }
+    std::lock_guard<std::mutex> g(g_pool_mutex);
+    StreamPool& p = g_pools[s->device];
+    if (--p.refs == 0) {
+        (void)hipStreamDestroy(p.st); (void)hipStreamDestroy(p.pre); (void)hipStreamDestroy(p.det); (void)hipStreamDestroy(p.warp);
+        p = StreamPool();
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
@@ -970,14 +1029,7 @@ int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
     s->host_radius = params->smoothing_radius;
     memset(&s->counters, 0, sizeof s->counters);
     fill_traj_params(s);
-    hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_pre, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_det, hipStreamNonBlocking);
-    if (e == hipSuccess) {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        e = hipStreamCreateWithPriority(&s->st_warp, hipStreamNonBlocking, greatest);
-    }
+    hipError_t e = acquire_streams(s);
     if (e != hipSuccess || create_events(s) != VS_OK) {
         set_last_error(e != hipSuccess ? hipGetErrorString(e) : s->err);
         vs_stab_destroy(s);
@@ -999,10 +1051,7 @@ void vs_stab_destroy(vs_stab* s) {
     for (auto& pe : s->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     destroy_events(s);
-    if (s->st) (void)hipStreamDestroy(s->st);
-    if (s->st_pre) (void)hipStreamDestroy(s->st_pre);
-    if (s->st_det) (void)hipStreamDestroy(s->st_det);
-    if (s->st_warp) (void)hipStreamDestroy(s->st_warp);
+    if (s->st) release_streams(s);
     delete s;
 }
 
