@@ -25,6 +25,14 @@ def test_rng_stream_kat(oracle):
     assert [int(x) % 200 for x in got[:4]] == [5, 4, 140, 173]
 
 
+def test_rng_stream_golden_file(oracle):
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cv_rng_mwc_stream.json")))
+    got = oracle.rng_stream(int(g["seed"], 16), len(g["next_u32"]))
+    assert [int(x) for x in got] == g["next_u32"]
+    assert [int(x) % 200 for x in got] == g["uniform_0_200"]
+
+
 def test_bgr2gray_known_colors(oracle):
     img = np.zeros((1, 5, 3), np.uint8)
     img[0, 0] = (255, 255, 255)
