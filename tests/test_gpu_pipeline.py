@@ -263,6 +263,39 @@ def test_batch_mode_matches_per_frame_pipeline(gpu, batch, radius, n):
         s.close()
 
 
+@pytest.mark.parametrize("extra", [dict(smoothing_method=capi.SMOOTH_GAUSSIAN, gaussian_sigma=3.0),
+                                   dict(smoothing_method=capi.SMOOTH_KALMAN),
+                                   dict(drone_high_freq_mode=1, horizon_lock=1),
+                                   dict(max_corners=60, lk_win_size=15, lk_max_level=3)])
+def test_batch_mode_with_other_smoothers_and_drone_state(gpu, extra):
+    """The ordered tail of a batch keeps the whole trajectory state (Kalman, drone filters) in LDS: same
+    frames as the per-frame pipeline for every smoothing method, with intent segments in the clip."""
+    segs = [(0, 512, 0, 384, 200), (14, 2200, 0, 60, 20), (30, 200, 0, 40, 900), (44, 1000, 900, 700, 100)]
+    n = 56
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 41, 320, 240, n, segments=segs)
+    p = gpu.params(smoothing_radius=6, **extra)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(7)
+    s2.set_zero_copy(True)
+    fb = clip[0].nbytes
+    d_in = capi.DevBuf(gpu, fb * n)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, fb * n), capi.DevBuf(gpu, fb * n)
+    k1 = k2 = 0
+    for i in range(n):
+        k1 += s1.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_ref.ptr + k1 * fb, 320 * 3)
+        k2 += s2.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr + k2 * fb, 320 * 3)
+    while s1.flush_dev(d_ref.ptr + k1 * fb, 320 * 3):
+        k1 += 1
+    while s2.flush_dev(d_got.ptr + k2 * fb, 320 * 3):
+        k2 += 1
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n
+    assert np.array_equal(d_ref.download((n, 240, 320, 3), np.uint8), d_got.download((n, 240, 320, 3), np.uint8))
+    s1.close(); s2.close()
+
+
 @pytest.mark.parametrize("batch", [1, 8])
 def test_zero_copy_input_matches_queued_copy(gpu, batch):
     """vs_stab_set_zero_copy: frames are read where the caller holds them (here: a resident clip that stays
