@@ -87,8 +87,8 @@ def cpu_baseline(width, height, frames, order_fn):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=640)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU (batch mode)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

@@ -229,7 +229,8 @@ int vs_stab_set_batch(vs_stab* s, int frames);
  * surface pool, resident clip) instead of being copied into the instance's queue - the
  * reference aliases the caller's cv::Mat the same way (Stabilizer.cpp:376).  The buffer
  * must stay valid and unchanged until the result of the same push count has been produced
- * (clamp(smoothingRadius,5,35) further pushes plus the batch depth) or the queue has been
+ * (clamp(smoothingRadius,5,35) further pushes plus twice the batch depth: the warps of a
+ * batch are issued with the next one) and vs_stab_sync has returned, or the queue has been
  * drained with vs_stab_flush_dev.  Frames must be tightly packed.  The frame queue must be
  * empty when the mode is switched. */
 int vs_stab_set_zero_copy(vs_stab* s, int enable);

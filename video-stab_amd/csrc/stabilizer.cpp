@@ -200,6 +200,16 @@ struct vs_stab {
     const uint8_t *dbg_status = nullptr, *dbg_inliers = nullptr;
     const float* dbg_det_pts = nullptr; const int32_t* dbg_det_n = nullptr;
     const int32_t* dbg_gftt_counters = nullptr;
+    // batch mode: the warps of batch k are issued during run_batch(k+1), behind the detection of batch k+1, so
+    // that the (HBM-bound) warp has the GPU to itself: pre/det of k+1 overlap the tracking and tail of k instead
+    struct ReadyWarps {
+        bool valid = false;
+        int n = 0, set = 0;
+        size_t stride = 0;
+        const uint8_t* srcs[BATCH_MAX];
+        uint8_t* dsts[BATCH_MAX];
+        int slots[BATCH_MAX];
+    } ready;
     // stage profiling (HIP events on the stream the stage runs on)
     int prof_mode = 0;
     struct Pending { hipEvent_t a, b; int stage; };
@@ -262,10 +272,18 @@ void out_size(const vs_stab* s, int w, int h, int* ow, int* oh) {
 
 int flush_warps(vs_stab* s, bool on_main = false);
 int run_batch(vs_stab* s);
+int launch_ready(vs_stab* s);
+
+// Batch mode: everything queued so far is analysed and its warps are issued (nothing stays deferred).
+int drain_batch(vs_stab* s) {
+    S_TRY(s, run_batch(s));
+    S_TRY(s, launch_ready(s));
+    return VS_OK;
+}
 
 int sync_all(vs_stab* s) {
     S_HIP(s, hipSetDevice(s->device));
-    S_TRY(s, run_batch(s));
+    S_TRY(s, drain_batch(s));
     S_TRY(s, flush_warps(s));
     if (s->st_warp) S_HIP(s, hipStreamSynchronize(s->st_warp));
     if (s->st_pre) S_HIP(s, hipStreamSynchronize(s->st_pre));
@@ -322,7 +340,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->pyr.assign(s->npyr, Pyramid());
     s->d_pts.assign(nkp, nullptr); s->d_npts.assign(nkp, nullptr); s->pts_cap.assign(nkp, 0);
     s->items.assign(B, vs_stab::ItemBufs());
-    s->bq.clear(); s->batch_id = 0; s->kp_cur = 0; s->kp_next = 1; s->last_det_batch = -1;
+    s->bq.clear(); s->batch_id = 0; s->kp_cur = 0; s->kp_next = 1; s->last_det_batch = -1; s->ready.valid = false;
     for (auto& v : s->bdet_valid) v = false;
     S_HIP(s, hipMalloc((void**)&s->d_ring, s->frame_bytes * FRAME_RING));
     s->free_slots.clear();
@@ -599,6 +617,29 @@ int defer_output(vs_stab* s, int idx, const uint8_t* frame, uint8_t* d_out, size
     return VS_OK;
 }
 
+// Batch mode: the warps of the batch whose tail was queued last, as one launch on `main`.
+int launch_ready(vs_stab* s) {
+    vs_stab::ReadyWarps& R = s->ready;
+    if (!R.valid) return VS_OK;
+    hipStream_t st = s->st;
+    int rc;
+    {
+        StageScope t(s, VS_STAGE_WARP, st);
+        rc = launch_warp_affine_list(R.srcs, R.dsts, R.n, s->row_bytes, s->w, s->h, R.stride, s->w, s->h, s->cn,
+                                     s->d_MinvB[R.set], 12, st);
+    }
+    if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) s->warp_valid[R.set] = true;
+    for (int i = 0; i < R.n; i++) {
+        const int slot = R.slots[i];
+        if (slot < 0) continue;          // zero-copy: the frame is the caller's
+        if (hipEventRecord(s->ev_slot[slot], st) == hipSuccess) s->slot_valid[slot] = true;
+        s->free_slots.push_back(slot);
+    }
+    R.valid = false;
+    if (rc != VS_OK) { s->err = get_last_error(); return rc; }
+    return VS_OK;
+}
+
 // applyNextSmoothTransform (Stabilizer.cpp:763-1137) into d_out (device), on `main`
 int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
     const vs_params_c& p = s->p;
@@ -776,6 +817,9 @@ int run_batch(vs_stab* s) {
     S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
     if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
     if (s->last_det_batch >= 0 && s->last_det_batch >= k - 1) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
+    // `main` has now waited for this batch's gray/pyramid/detection work: the warps of the PREVIOUS batch go out
+    // here, alone on the GPU, before this batch's tracking
+    S_TRY(s, launch_ready(s));
     int n_max = 0;
     for (int i = 0; i < n; i++) {
         const vs_stab::BFrame& b = s->bq[i];
@@ -832,7 +876,12 @@ int run_batch(vs_stab* s) {
             StageScope t(s, VS_STAGE_TRAJ, st);
             S_TRY(s, launch_ransac_tail_batch(s->d_rs_table, s->d_tail_table, n, s->d_M, st));
         }
-        S_TRY(s, flush_warps(s, true));
+        // the warps of this batch wait for the next run_batch (or a drain)
+        vs_stab::ReadyWarps& R = s->ready;
+        R.n = (int)s->pend.size(); R.set = set; R.stride = s->pend_stride; R.valid = R.n > 0;
+        for (int i = 0; i < R.n; i++) { R.srcs[i] = s->pend[i].src; R.dsts[i] = s->pend[i].dst; R.slots[i] = s->pend[i].slot; }
+        s->pend.clear();
+        if (R.valid) s->pend_set = set ^ 1;
     }
     const vs_stab::BFrame& lb = s->bq[n - 1];
     s->dbg_prev_pts = s->d_pts[lb.lk_buf]; s->dbg_next = s->items[n - 1].next;
@@ -882,7 +931,7 @@ int push_common(vs_stab* s, int slot, const uint8_t* zc_frame, uint8_t* d_out, s
     if (s->batch_active) {
         S_TRY(s, batch_enqueue(s, frame, slot, s->next_index, d_out, out_stride, produced));
         s->next_index++;
-        if (!may_defer) { S_TRY(s, run_batch(s)); S_TRY(s, flush_warps(s)); }
+        if (!may_defer) { S_TRY(s, drain_batch(s)); S_TRY(s, flush_warps(s)); }
         return VS_OK;
     }
     s->q_slot.push_back(slot); s->q_idx.push_back(s->next_index); s->q_ptr.push_back(frame);   // :376-377
@@ -967,6 +1016,16 @@ std::mutex g_pool_mutex;
 std::map<int, StreamPool> g_pools;
 
 hipError_t make_streams(hipStream_t* st, hipStream_t* pre, hipStream_t* det, hipStream_t* warp) {
+    if (const char* m = std::getenv("VS_STAB_STREAM_LAYOUT")) {
+        // experiment switch: "1" = everything on one stream, "2" = pre+det share one stream, main has its own
+        hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        if (m[0] == '1') { *pre = *st; *det = *st; *warp = *st; return hipSuccess; }
+        e = hipStreamCreateWithFlags(pre, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        *det = *pre; *warp = *st;
+        return hipSuccess;
+    }
     hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(pre, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(det, hipStreamNonBlocking);
@@ -1095,7 +1154,7 @@ static int flush_dev_impl(vs_stab* s, void* d_out, size_t out_stride, int* produ
     *produced = 0;
     if (!s->allocated || s->q_slot.empty()) return VS_OK;
     S_HIP(s, hipSetDevice(s->device));
-    S_TRY(s, run_batch(s));
+    S_TRY(s, drain_batch(s));
     S_TRY(s, apply_next(s, (uint8_t*)d_out, out_stride, may_defer_flush));
     *produced = 1;
     return VS_OK;
@@ -1118,7 +1177,7 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
     int ow, oh;
     out_size(s, w, h, &ow, &oh);
     const size_t orow = (size_t)ow * s->cn;
-    S_TRY(s, run_batch(s));
+    S_TRY(s, drain_batch(s));
     S_TRY(s, flush_warps(s));
     rc = push_common(s, slot, nullptr, s->d_out, orow, produced, false);
     if (rc != VS_OK) return rc;
@@ -1142,7 +1201,7 @@ int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced) {
     out_size(s, s->w, s->h, &ow, &oh);
     const size_t orow = (size_t)ow * s->cn;
     if (!out || out_stride < orow) return fail(s, VS_ERR_INVALID_ARG, "flush: output buffer/stride too small");
-    S_TRY(s, run_batch(s));
+    S_TRY(s, drain_batch(s));
     S_TRY(s, flush_warps(s));
     int rc = flush_dev_impl(s, s->d_out, orow, produced, false);
     if (rc != VS_OK) return rc;
@@ -1175,8 +1234,8 @@ int vs_stab_set_batch(vs_stab* s, int frames) {
 
 // Zero-copy input for vs_stab_push_dev: the frame is not copied into the instance's queue but read where the
 // caller put it (a decoder surface pool, a resident clip).  It must stay valid and unchanged until the result
-// of the SAME push count has been produced, i.e. for clamp(smoothingRadius,5,35) further pushes plus the
-// batch depth, or until vs_stab_flush_dev has drained the queue.  Frames must be tightly packed.
+// of the SAME push count has been produced, i.e. for clamp(smoothingRadius,5,35) further pushes plus twice
+// the batch depth and a vs_stab_sync, or until vs_stab_flush_dev has drained the queue.  Tightly packed frames.
 int vs_stab_set_zero_copy(vs_stab* s, int enable) {
     if (!s) return VS_ERR_INVALID_ARG;
     if (!s->q_slot.empty()) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_zero_copy: the frame queue must be empty");
