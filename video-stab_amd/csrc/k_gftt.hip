@@ -40,6 +40,7 @@ constexpr int CELLS_MAX = 2560;
 constexpr int SLOTS = 4;
 constexpr int ACC_MAX = 4096;
 constexpr int SEL_NT = 256;
+constexpr int NMS_ROWS = 8;
 
 __device__ __forceinline__ uint32_t order_key(float v) {
     uint32_t b = __float_as_uint(v);
@@ -137,13 +138,16 @@ __device__ __forceinline__ void nms_row(const float* __restrict__ eig, int w, in
                                         const uint32_t* __restrict__ max_key,
                                         unsigned long long* __restrict__ cand, int cap,
                                         int32_t* __restrict__ counters) {
+    // NMS_ROWS rows per workgroup: with one row each the launch is bound by the workgroup dispatch rate
+    // (2000 workgroups of a few dozen instructions per image)
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
+    const float maxv = key_to_float(*max_key);
+    const float thr = (float)((double)maxv * quality);
+    const int lane = threadIdx.x & 63;
+    for (int y = blockIdx.y * NMS_ROWS; y < min((int)(blockIdx.y + 1) * NMS_ROWS, h); y++) {
     bool is_cand = false;
     float v = 0.f;
     if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-        const float maxv = key_to_float(*max_key);
-        const float thr = (float)((double)maxv * quality);
         const float* r = eig + (size_t)y * w + x;
         v = r[0] > thr ? r[0] : 0.f;   // THRESH_TOZERO
         if (v != 0.f) {
@@ -161,15 +165,15 @@ __device__ __forceinline__ void nms_row(const float* __restrict__ eig, int w, in
     }
     // one atomic per wave: the list is sorted by (value, index) afterwards, so its order is free
     const unsigned long long mask = __ballot(is_cand);
-    if (!mask) return;
-    const int lane = threadIdx.x & 63;
+    if (!mask) continue;
     int base = 0;
     if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&counters[0], __popcll(mask));
     base = __builtin_amdgcn_readlane(base, __ffsll((long long)mask) - 1);
-    if (!is_cand) return;
+    if (!is_cand) continue;
     const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
     if (pos < cap) cand[pos] = ((unsigned long long)order_key(v) << 32) | (uint32_t)(y * w + x);
     else counters[2] = 1;
+    }
 }
 
 __global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ eig, int w, int h, double quality,
@@ -464,7 +468,7 @@ int launch_gftt_batch(const void* d_table, int items, int w, int h, hipStream_t 
     const GfttItem* t = static_cast<const GfttItem*>(d_table);
     hipLaunchKernelGGL(gftt_zero_batch_kernel, dim3(items), dim3(64), 0, st, t);
     hipLaunchKernelGGL(min_eigen_batch_kernel, dim3((w + TW - 1) / TW, (h + TH - 1) / TH, items), dim3(NT), 0, st, t);
-    hipLaunchKernelGGL(nms_batch_kernel, dim3((w + NT - 1) / NT, h, items), dim3(NT), 0, st, t);
+    hipLaunchKernelGGL(nms_batch_kernel, dim3((w + NT - 1) / NT, (h + NMS_ROWS - 1) / NMS_ROWS, items), dim3(NT), 0, st, t);
     hipLaunchKernelGGL(select_batch_kernel, dim3(items), dim3(SEL_NT), 0, st, t);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
@@ -498,7 +502,7 @@ int launch_gftt(const uint8_t* d_gray, size_t stride, int w, int h, int max_corn
     dim3 g1((w + TW - 1) / TW, (h + TH - 1) / TH);
     hipLaunchKernelGGL(min_eigen_kernel, g1, dim3(NT), 0, st, d_gray, stride, w, h, block_size, f1, wk.eig,
                        (uint32_t*)&wk.counters[1]);
-    dim3 g2((w + NT - 1) / NT, h);
+    dim3 g2((w + NT - 1) / NT, (h + NMS_ROWS - 1) / NMS_ROWS);
     hipLaunchKernelGGL(nms_kernel, g2, dim3(NT), 0, st, wk.eig, w, h, quality, (const uint32_t*)&wk.counters[1],
                        (unsigned long long*)wk.cand, wk.cap, wk.counters);
     SelArgs a;

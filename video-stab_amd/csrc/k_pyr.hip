@@ -11,6 +11,7 @@ namespace vsd {
 namespace {
 
 constexpr int NT = 256;
+constexpr int RPB = 4;      // image rows per workgroup: one row each made the launches dispatch-rate bound
 
 __global__ __launch_bounds__(NT) void pyr_down_kernel(const uint8_t* __restrict__ src_, size_t sstride,
                                                       int sw, int sh, uint8_t* __restrict__ dst_,
@@ -19,18 +20,19 @@ __global__ __launch_bounds__(NT) void pyr_down_kernel(const uint8_t* __restrict_
     const uint8_t* __restrict__ src = table ? static_cast<const uint8_t*>(table[blockIdx.z].src) : src_;
     uint8_t* __restrict__ dst = table ? static_cast<uint8_t*>(table[blockIdx.z].dst) : dst_;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= dw || y >= dh) return;
+    if (x >= dw) return;
     int xi[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) xi[k] = reflect101(2 * x + k - 2, sw);
-    int col[5];
+    for (int y = blockIdx.y * RPB; y < min((int)(blockIdx.y + 1) * RPB, dh); y++) {
+        int col[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const uint8_t* s = src + (size_t)reflect101(2 * y + j - 2, sh) * sstride;
-        col[j] = s[xi[2]] * 6 + (s[xi[1]] + s[xi[3]]) * 4 + s[xi[0]] + s[xi[4]];
+        for (int j = 0; j < 5; j++) {
+            const uint8_t* s = src + (size_t)reflect101(2 * y + j - 2, sh) * sstride;
+            col[j] = s[xi[2]] * 6 + (s[xi[1]] + s[xi[3]]) * 4 + s[xi[0]] + s[xi[4]];
+        }
+        dst[(size_t)y * dstride + x] = (uint8_t)((col[2] * 6 + (col[1] + col[3]) * 4 + col[0] + col[4] + 128) >> 8);
     }
-    dst[(size_t)y * dstride + x] = (uint8_t)((col[2] * 6 + (col[1] + col[3]) * 4 + col[0] + col[4] + 128) >> 8);
 }
 
 __global__ __launch_bounds__(NT) void scharr_kernel(const uint8_t* __restrict__ src_, size_t sstride, int w,
@@ -38,8 +40,8 @@ __global__ __launch_bounds__(NT) void scharr_kernel(const uint8_t* __restrict__ 
     const uint8_t* __restrict__ src = table ? static_cast<const uint8_t*>(table[blockIdx.z].src) : src_;
     int16_t* __restrict__ dst = table ? static_cast<int16_t*>(table[blockIdx.z].dst) : dst_;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= w || y >= h) return;
+    if (x >= w) return;
+    for (int y = blockIdx.y * RPB; y < min((int)(blockIdx.y + 1) * RPB, h); y++) {
     const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * sstride;
     const uint8_t* r1 = src + (size_t)y * sstride;
     const uint8_t* r2 = src + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * sstride;
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(NT) void scharr_kernel(const uint8_t* __restrict__ 
     o.x = (short)(a_p - a_m);
     o.y = (short)((b_p + b_m) * 3 + b_c * 10);
     *reinterpret_cast<short2*>(dst + ((size_t)y * w + x) * 2) = o;
+    }
 }
 
 }  // namespace
@@ -67,7 +70,7 @@ int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_
         return VS_ERR_INVALID_ARG;
     }
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    dim3 grid((dw + NT - 1) / NT, dh);
+    dim3 grid((dw + NT - 1) / NT, (dh + RPB - 1) / RPB);
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst, dstride, dw, dh, (const ImgPair*)nullptr);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
@@ -78,7 +81,7 @@ int launch_scharr(const uint8_t* d_src, size_t sstride, int w, int h, int16_t* d
         set_last_error("scharr: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
-    dim3 grid((w + NT - 1) / NT, h);
+    dim3 grid((w + NT - 1) / NT, (h + RPB - 1) / RPB);
     hipLaunchKernelGGL(scharr_kernel, grid, dim3(NT), 0, st, d_src, sstride, w, h, d_dst, (const ImgPair*)nullptr);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
@@ -90,7 +93,7 @@ int launch_pyr_down_batch(const ImgPair* d_pairs, int items, size_t sstride, int
         return VS_ERR_INVALID_ARG;
     }
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    dim3 grid((dw + NT - 1) / NT, dh, items);
+    dim3 grid((dw + NT - 1) / NT, (dh + RPB - 1) / RPB, items);
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(NT), 0, st, (const uint8_t*)nullptr, sstride, sw, sh, (uint8_t*)nullptr, dstride,
                        dw, dh, d_pairs);
     VS_HIP_TRY(hipGetLastError());
@@ -102,7 +105,7 @@ int launch_scharr_batch(const ImgPair* d_pairs, int items, size_t sstride, int w
         set_last_error("scharr_batch: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
-    dim3 grid((w + NT - 1) / NT, h, items);
+    dim3 grid((w + NT - 1) / NT, (h + RPB - 1) / RPB, items);
     hipLaunchKernelGGL(scharr_kernel, grid, dim3(NT), 0, st, (const uint8_t*)nullptr, sstride, w, h, (int16_t*)nullptr, d_pairs);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
