@@ -387,6 +387,7 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     __shared__ float l_M[12];
     __shared__ int32_t l_info[16][4];
     __shared__ int l_nprev[16], l_hpg[16], l_due[16], l_oidx[16];
+    __shared__ float l_t3[16][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     TrajState* g_state = table[0].traj;
     vs_debug_frame* g_dbg = table[0].dbg;
@@ -414,13 +415,34 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(&l_dbg)[i] = reinterpret_cast<const uint32_t*>(g_dbg)[i];
     __syncthreads();
-    // phase 2, ordered: append the measured transform of frame i, then emit the map that push i releases
-    for (int i = 0; i < n; i++) {
-        if (tid == 0) traj_append_device(&l_state, l_tp, l_model[i], l_info[i], l_nprev[i], &l_dbg, l_hpg[i]);
-        __syncthreads();
-        if (l_due[i]) traj_emit_device(&l_state, l_tp, l_oidx[i], l_M, l_minv[i], &l_dbg);
-        __syncthreads();
+    // phase 2, ordered, wave 0 alone (no workgroup barriers): append the measured transform of frame i, then
+    // smooth around the frame that push i releases -> its transform (dx, dy, da)
+    if (wave == 0) {
+        for (int i = 0; i < n; i++) {
+            if (lane == 0) traj_append_device(&l_state, l_tp, l_model[i], l_info[i], l_nprev[i], &l_dbg, l_hpg[i]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (l_due[i]) traj_emit_lds_wave0(&l_state, l_tp, l_oidx[i], &l_dbg, l_t3[i]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
+    __syncthreads();
+    // phase 3: the matrices and inverse maps of all due outputs, one lane each (cosf / sinf / the double
+    // inversions leave the ordered chain); the last due output also leaves its matrix in the debug record
+    {
+        int last_due = -1;
+        for (int i = 0; i < n; i++) if (l_due[i]) last_due = i;
+        if (tid < n && l_due[tid]) {
+            float Mt[12];
+            traj_matrix_lane(l_t3[tid], Mt, l_minv[tid], nullptr);
+            if (tid == last_due) {
+                for (int i = 0; i < 12; i++) l_M[i] = Mt[i];
+                for (int i = 0; i < 6; i++) l_dbg.warp_matrix[i] = Mt[i];
+            }
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < (int)(sizeof(TrajState) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(g_state)[i] = reinterpret_cast<const uint32_t*>(&l_state)[i];
     for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)

@@ -61,24 +61,46 @@ __device__ __forceinline__ float wave_consistency_of(float v, int n) {
     return fmaxf(0.0f, fminf(1.0f, c));
 }
 
-// Wave 0 (64 lanes, all active): smoothing around frame idx, motion-intent gain,
-// T = [cos -sin dx; sin cos dy].  Uniform values are computed by every lane; lane 0 stores.
+// One lane: T = [cos -sin dx; sin cos dy] (:902-908) from the smoothed transform t3 = {dx, dy, da, valid},
+// the chroma variant, and the inverse maps the warp kernels consume.  valid == 0: identity (:774-780).
+__device__ __forceinline__ void traj_matrix_lane(const float* t3, float* __restrict__ M_out, double* __restrict__ Minv_out,
+                                                 vs_debug_frame* dbg) {
+    if (t3[3] == 0.f) {
+        M_out[0] = 1.f; M_out[1] = 0.f; M_out[2] = 0.f; M_out[3] = 0.f; M_out[4] = 1.f; M_out[5] = 0.f;
+        for (int i = 0; i < 6; i++) M_out[6 + i] = M_out[i];
+    } else {
+        const float dx = t3[0], dy = t3[1], da = t3[2];
+        const float cs = cosf(da), sn = sinf(da);
+        M_out[0] = cs; M_out[1] = -sn; M_out[2] = dx;
+        M_out[3] = sn; M_out[4] = cs; M_out[5] = dy;
+        // chroma plane of an NV12 surface: same rotation, translation halved
+        M_out[6] = cs; M_out[7] = -sn; M_out[8] = dx * 0.5f;
+        M_out[9] = sn; M_out[10] = cs; M_out[11] = dy * 0.5f;
+    }
+    warp_invert(M_out, Minv_out);
+    warp_invert(M_out + 6, Minv_out + 6);
+    if (dbg) for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
+}
+
+// Wave 0 (64 lanes, all active): smoothing around frame idx and motion-intent gain -> the smoothed transform.
+// mg / dr: magnitude and direction of transform istart + lane (lanes 0..14).  Uniform values are computed by
+// every lane; lane 0 stores.  DEFER: only t3 = {dx, dy, da, valid} is produced (the caller builds the matrices,
+// for all outputs of a batch in parallel); otherwise lane 0 also builds them.
+template <bool DEFER>
 __device__ __forceinline__ void traj_emit_wave0(TrajState* s, const TrajParams& p, int idx, float* __restrict__ M_out,
                                                 double* __restrict__ Minv_out, vs_debug_frame* dbg,
-                                                const float (*l_path)[3], const float (*l_tr)[3], const float* l_mag,
-                                                const float* l_dir, const int n, const int istart) {
+                                                const float (*l_path)[3], const float (*l_tr)[3], const float mg_lane,
+                                                const float dr_lane, const int n, const int istart, float* t3) {
     const int lane = threadIdx.x & 63;
     auto path_at = [&](int i, int c) -> float { return l_path[i & (TRAJ_RING - 1)][c]; };
     auto tr_at = [&](int i, int c) -> float { return l_tr[i & (TRAJ_RING - 1)][c]; };
     if (idx >= n) {   // Stabilizer.cpp:774-780: no transform for this frame -> frame returned as is
         if (lane == 0) {
             dbg->out_index = idx; dbg->box_radius = 0; dbg->intent = 0;
-            M_out[0] = 1.f; M_out[1] = 0.f; M_out[2] = 0.f; M_out[3] = 0.f; M_out[4] = 1.f; M_out[5] = 0.f;
-            for (int i = 0; i < 6; i++) M_out[6 + i] = M_out[i];
-            warp_invert(M_out, Minv_out);
-            warp_invert(M_out + 6, Minv_out + 6);
             for (int c = 0; c < 3; c++) dbg->smoothed[c] = 0.f;
-            for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
+            float id[4] = {0.f, 0.f, 0.f, 0.f};
+            if (DEFER) { for (int c = 0; c < 4; c++) t3[c] = id[c]; }
+            else traj_matrix_lane(id, M_out, Minv_out, dbg);
         }
         return;
     }
@@ -192,7 +214,7 @@ __device__ __forceinline__ void traj_emit_wave0(TrajState* s, const TrajParams& 
             // samples istart .. min(idx, n) - 1, one per lane (l_mag / l_dir were filled by lanes 0..14)
             const int last = idx < n ? idx : n;
             const int cnt = last - istart > 0 ? last - istart : 0;
-            const float mg = lane < cnt ? l_mag[lane] : 0.f, dr = lane < cnt ? l_dir[lane] : 0.f;
+            const float mg = lane < cnt ? mg_lane : 0.f, dr = lane < cnt ? dr_lane : 0.f;
             if (cnt > 0) {
                 const float dv = wave_variance_of<15>(dr, cnt);
                 const float mc = wave_consistency_of<15>(mg, cnt);
@@ -211,15 +233,30 @@ __device__ __forceinline__ void traj_emit_wave0(TrajState* s, const TrajParams& 
     const float dx = raw[0] + diff[0], dy = raw[1] + diff[1];
     float da = raw[2] + diff[2];
     if (p.horizon_lock) da = 0.0f;                   // :897-899
-    const float cs = cosf(da), sn = sinf(da);         // :902-908
-    M_out[0] = cs; M_out[1] = -sn; M_out[2] = dx;
-    M_out[3] = sn; M_out[4] = cs; M_out[5] = dy;
-    // chroma plane of an NV12 surface: same rotation, translation halved
-    M_out[6] = cs; M_out[7] = -sn; M_out[8] = dx * 0.5f;
-    M_out[9] = sn; M_out[10] = cs; M_out[11] = dy * 0.5f;
-    warp_invert(M_out, Minv_out);            // the warp kernels consume the inverse maps
-    warp_invert(M_out + 6, Minv_out + 6);
-    for (int i = 0; i < 6; i++) dbg->warp_matrix[i] = M_out[i];
+    const float r4[4] = {dx, dy, da, 1.f};
+    if (DEFER) { for (int c = 0; c < 4; c++) t3[c] = r4[c]; }
+    else traj_matrix_lane(r4, M_out, Minv_out, dbg);
+}
+
+// magnitude / direction of transform istart + lane, for the intent analysis (lanes 0..14 of wave 0)
+__device__ __forceinline__ void traj_intent_samples(const float (*l_tr)[3], int idx, int n, int istart, float& mg, float& dr) {
+    mg = 0.f; dr = 0.f;
+    const int lane = threadIdx.x & 63;
+    const int i = istart + lane;
+    if (lane < 15 && i < idx && i < n) {
+        const float t0 = l_tr[i & (TRAJ_RING - 1)][0], t1 = l_tr[i & (TRAJ_RING - 1)][1];
+        mg = sqrtf(t0 * t0 + t1 * t1);
+        dr = atan2f(t1, t0);
+    }
+}
+
+// The same for a trajectory state that already lives in LDS (batch tail): wave 0 only, no workgroup barrier.
+__device__ __forceinline__ void traj_emit_lds_wave0(TrajState* s, const TrajParams& p, int idx, vs_debug_frame* dbg, float* t3) {
+    const int n = s->n;
+    const int istart = idx - 15 > 0 ? idx - 15 : 0;
+    float mg, dr;
+    traj_intent_samples(s->transforms, idx, n, istart, mg, dr);
+    traj_emit_wave0<true>(s, p, idx, nullptr, nullptr, dbg, s->path, s->transforms, mg, dr, n, istart, t3);
 }
 
 __device__ __forceinline__ void traj_emit_device(TrajState* s, const TrajParams& p, int idx, float* __restrict__ M_out,
@@ -227,7 +264,6 @@ __device__ __forceinline__ void traj_emit_device(TrajState* s, const TrajParams&
     // The history rings are mirrored into LDS by all lanes and the per-sample transcendental work of
     // the intent analysis is spread over lanes.
     __shared__ float l_path[TRAJ_RING][3], l_tr[TRAJ_RING][3];
-    __shared__ float l_mag[16], l_dir[16];
     const int n = s->n;
     for (int i = threadIdx.x; i < TRAJ_RING * 3; i += blockDim.x) {
         (&l_path[0][0])[i] = (&s->path[0][0])[i];
@@ -235,16 +271,11 @@ __device__ __forceinline__ void traj_emit_device(TrajState* s, const TrajParams&
     }
     __syncthreads();
     const int istart = idx - 15 > 0 ? idx - 15 : 0;
-    if (threadIdx.x < 15) {
-        const int i = istart + (int)threadIdx.x;
-        if (i < idx && i < n) {
-            const float t0 = l_tr[i & (TRAJ_RING - 1)][0], t1 = l_tr[i & (TRAJ_RING - 1)][1];
-            l_mag[threadIdx.x] = sqrtf(t0 * t0 + t1 * t1);
-            l_dir[threadIdx.x] = atan2f(t1, t0);
-        }
+    if (threadIdx.x < 64) {
+        float mg, dr;
+        traj_intent_samples(l_tr, idx, n, istart, mg, dr);
+        traj_emit_wave0<false>(s, p, idx, M_out, Minv_out, dbg, l_path, l_tr, mg, dr, n, istart, nullptr);
     }
-    __syncthreads();
-    if (threadIdx.x < 64) traj_emit_wave0(s, p, idx, M_out, Minv_out, dbg, l_path, l_tr, l_mag, l_dir, n, istart);
 }
 
 }  // namespace vsd
