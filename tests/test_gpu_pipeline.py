@@ -296,6 +296,41 @@ def test_batch_mode_with_other_smoothers_and_drone_state(gpu, extra):
     s1.close(); s2.close()
 
 
+def test_pipeline_full_hd_config2_against_oracle(gpu, oracle):
+    """BASELINE configs[1] at its full size: 1920x1080 BGR8, 200 corners, LK 21x21 / 3 levels, frame by frame
+    against the oracle (every intermediate, as in run_both), then the same clip through the batch pipeline."""
+    clip = synth.make_clip(synth.SEED_CONFIG2, 1920, 1080, 14)
+    kw = dict(smoothing_radius=5, max_corners=200, lk_win_size=21, lk_max_level=2)
+    oracle.lib.vso_set_threads(8)
+    try:
+        n_out, worst = run_both(gpu, oracle, clip, **kw)
+    finally:
+        oracle.lib.vso_set_threads(1)
+    assert n_out == 14
+    p = gpu.params(**kw)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(16)
+    s2.set_zero_copy(True)
+    fb = clip[0].nbytes
+    d_in = capi.DevBuf(gpu, fb * 14)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_got = capi.DevBuf(gpu, fb * 14)
+    k = 0
+    ref = []
+    for i, f in enumerate(clip):
+        r = s1.push(f)
+        if r is not None:
+            ref.append(r)
+        k += s2.push_dev(d_in.ptr + i * fb, 1920, 1080, 1920 * 3, capi.FMT_BGR8, d_got.ptr + k * fb, 1920 * 3)
+    s2.sync()
+    assert k == len(ref) == 10
+    got = d_got.download((k, 1080, 1920, 3), np.uint8)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    s1.close(); s2.close()
+
+
 @pytest.mark.parametrize("batch", [1, 8])
 def test_zero_copy_input_matches_queued_copy(gpu, batch):
     """vs_stab_set_zero_copy: frames are read where the caller holds them (here: a resident clip that stays
