@@ -20,7 +20,7 @@ TOL_ANGLE = 1e-6
 TOL_MAT = 1e-6
 
 
-def run_both(gpu, oracle, clip, fmt=0, **params):
+def run_both(gpu, oracle, clip, fmt=0, max_lsb=1, **params):
     ps = gpu.params(**params)
     po = oracle.params(**params)
     sg = gpu.stabilizer(ps)
@@ -58,7 +58,7 @@ def run_both(gpu, oracle, clip, fmt=0, **params):
             assert np.allclose(np.array(dg.smoothed), np.array(do.smoothed), rtol=0, atol=1e-5), k
             assert np.allclose(np.array(dg.warp_matrix), np.array(do.warp_matrix), rtol=0, atol=TOL_MAT), k
             diff = np.abs(og.astype(np.int16) - oo.astype(np.int16))
-            assert diff.max() <= 1, k
+            assert diff.max() <= max_lsb, k
             frac = np.count_nonzero(diff) / diff.size
             worst = max(worst, frac)
             assert frac <= 1e-4, (k, frac)
@@ -70,7 +70,7 @@ def run_both(gpu, oracle, clip, fmt=0, **params):
             break
         n_out += 1
         diff = np.abs(og.astype(np.int16) - oo.astype(np.int16))
-        assert diff.max() <= 1 and np.count_nonzero(diff) / diff.size <= 1e-4
+        assert diff.max() <= max_lsb and np.count_nonzero(diff) / diff.size <= 1e-4
     sg.close()
     so.close()
     return n_out, worst
@@ -329,6 +329,29 @@ def test_pipeline_full_hd_config2_against_oracle(gpu, oracle):
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
     s1.close(); s2.close()
+
+
+def test_pipeline_4k_nv12_config3_against_oracle(gpu, oracle):
+    """BASELINE configs[2] at its full size: 3840x2160 NV12, 400 corners (per-frame pipeline), followed by
+    roll correction + auto zoom/crop on a 4K BGR frame."""
+    import roll_scene
+    clip = [synth.bgr_to_nv12(f) for f in synth.make_clip(synth.SEED_CONFIG3, 3840, 2160, 8)]
+    oracle.lib.vso_set_threads(8)
+    try:
+        # at 3840 columns a last-ulp difference of cosf/sinf (device libm vs glibc) moves the 1/1024-px coordinate
+        # of a few columns across a rounding boundary: a 1/32-px shift, i.e. up to 255/32 = 8 levels at a hard edge
+        n_out, worst = run_both(gpu, oracle, clip, fmt=capi.FMT_NV12, max_lsb=8, smoothing_radius=5, max_corners=400)
+        assert n_out == 8 and worst <= 2e-5
+        f = roll_scene.horizon_frame(3840, 2160, 45, seed=7)
+        ro, rg = oracle.roll_correction(), gpu.roll_correction()
+        for _ in range(2):
+            a, b = ro.correct(f), rg.correct(f)
+            assert np.array_equal(a, b) and ro.state() == rg.state()
+        z, info = oracle.auto_zoom_crop(a)
+        az = gpu.auto_zoom_crop()
+        assert np.array_equal(az.apply(b), z) and az.info().tolist() == info.tolist()
+    finally:
+        oracle.lib.vso_set_threads(1)
 
 
 @pytest.mark.parametrize("batch", [1, 8])
