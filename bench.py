@@ -129,9 +129,10 @@ def main():
         for i, f in enumerate(frames):
             buf.upload(f, i * fb)
         d_in.append(buf)
-    BT = max(1, min(16, args.batch))
+    BT = max(1, min(32, args.batch))
     WB = max(1, min(16, args.warp_batch if BT == 1 else BT))
-    d_out = [[capi.DevBuf(vs, fb) for _ in range(2 * WB)] for _ in range(S)]   # a result stays untouched for >= WB pushes
+    NOUT = max(2 * WB, 3 * BT)        # a result stays untouched until its batch and the next one have been issued
+    d_out = [[capi.DevBuf(vs, fb) for _ in range(NOUT)] for _ in range(S)]
     stabs = [vs.stabilizer(make_params(vs), device=local_rank) for _ in range(S)]
     for s in stabs:
         s.set_batch(BT)
@@ -144,7 +145,7 @@ def main():
 
     def step(i):
         for j in range(S):
-            stabs[j].push_dev(d_in[j].ptr + order[i] * fb, W, H, W * 3, capi.FMT_BGR8, d_out[j][i % (2 * WB)].ptr, W * 3)
+            stabs[j].push_dev(d_in[j].ptr + order[i] * fb, W, H, W * 3, capi.FMT_BGR8, d_out[j][i % NOUT].ptr, W * 3)
 
     def sync_all():
         for s in stabs:

@@ -216,7 +216,7 @@ int vs_stab_enable_graph(vs_stab* s, int enable);
  * every push issues its own warp.  The host entry points (vs_stab_push / vs_stab_flush)
  * always deliver their result before returning. */
 int vs_stab_set_warp_batch(vs_stab* s, int frames);
-/* Batch mode for vs_stab_push_dev / vs_stab_flush_dev: the analysis of `frames` (1..16)
+/* Batch mode for vs_stab_push_dev / vs_stab_flush_dev: the analysis of `frames` (1..32)
  * consecutive pushes - goodFeaturesToTrack, calcOpticalFlowPyrLK and the RANSAC
  * hypothesis scoring, all latency-bound on one frame - runs as ONE launch per stage over
  * the whole group; the ordered part (hypothesis selection + trajectory append, smoothing)

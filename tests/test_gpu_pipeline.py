@@ -217,7 +217,7 @@ def test_deferred_warp_batches_match_immediate_output(gpu, batch):
         s.close()
 
 
-@pytest.mark.parametrize("batch,radius,n", [(2, 7, 30), (8, 7, 45), (16, 12, 61), (5, 30, 80)])
+@pytest.mark.parametrize("batch,radius,n", [(2, 7, 30), (8, 7, 45), (16, 12, 61), (5, 30, 80), (32, 9, 100), (27, 5, 70)])
 def test_batch_mode_matches_per_frame_pipeline(gpu, batch, radius, n):
     """vs_stab_set_batch: GFTT / LK / RANSAC scoring of `batch` frames per launch; outputs (flush included),
     the last frame's debug record and the counters equal the per-frame pipeline's."""

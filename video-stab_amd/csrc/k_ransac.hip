@@ -382,12 +382,13 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     __shared__ TrajState l_state;
     __shared__ TrajParams l_tp;
     __shared__ vs_debug_frame l_dbg;
-    __shared__ double l_model[16][6];
-    __shared__ double l_minv[16][12];
+    constexpr int TB = 32;           // frames per tail (= BATCH_MAX of stabilizer.cpp)
+    __shared__ double l_model[TB][6];
+    __shared__ double l_minv[TB][12];
     __shared__ float l_M[12];
-    __shared__ int32_t l_info[16][4];
-    __shared__ int l_nprev[16], l_hpg[16], l_due[16], l_oidx[16];
-    __shared__ float l_t3[16][4];
+    __shared__ int32_t l_info[TB][4];
+    __shared__ int l_nprev[TB], l_hpg[TB], l_due[TB], l_oidx[TB];
+    __shared__ float l_t3[TB][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     TrajState* g_state = table[0].traj;
     vs_debug_frame* g_dbg = table[0].dbg;
@@ -397,16 +398,17 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
         reinterpret_cast<uint32_t*>(&l_tp)[i] = reinterpret_cast<const uint32_t*>(&table[0].tp)[i];
     if (tid < 12) l_M[tid] = M_out[tid];
     // phase 1: the selections do not depend on each other: wave i serves frame i
-    if (wave < n) {
-        const RansacArgs& a = table[wave];
-        ransac_select<true>(a, wave == n - 1);
+    const int nwaves = blockDim.x >> 6;
+    for (int f = wave; f < n; f += nwaves) {
+        const RansacArgs& a = table[f];
+        ransac_select<true>(a, f == n - 1);
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();
-        if (lane < 6) l_model[wave][lane] = a.model[lane];
-        if (lane < 4) l_info[wave][lane] = a.info[lane];
+        if (lane < 6) l_model[f][lane] = a.model[lane];
+        if (lane < 4) l_info[f][lane] = a.info[lane];
         if (lane == 0) {
-            l_nprev[wave] = device_count(a); l_hpg[wave] = a.have_prev_gray;
-            l_due[wave] = tail[wave].out_due; l_oidx[wave] = tail[wave].out_idx;
+            l_nprev[f] = device_count(a); l_hpg[f] = a.have_prev_gray;
+            l_due[f] = tail[f].out_due; l_oidx[f] = tail[f].out_idx;
         }
     }
     __threadfence();
@@ -448,7 +450,8 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(g_dbg)[i] = reinterpret_cast<const uint32_t*>(&l_dbg)[i];
     if (tid < 12) M_out[tid] = l_M[tid];
-    if (wave < n && lane < 12 && l_due[wave]) tail[wave].Minv_out[lane] = l_minv[wave][lane];
+    for (int f = wave; f < n; f += nwaves)
+        if (lane < 12 && l_due[f]) tail[f].Minv_out[lane] = l_minv[f][lane];
 }
 
 }  // namespace
@@ -515,7 +518,7 @@ void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_ou
 int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, hipStream_t st) {
     if (!d_table || !d_tail || items < 1 || !d_M_out) { set_last_error("ransac_tail_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
     const int threads = 64 * (items < 1 ? 1 : (items > 16 ? 16 : items));
-    if (items > 16) { set_last_error("ransac_tail_batch: at most 16 frames"); return VS_ERR_INVALID_ARG; }
+    if (items > 32) { set_last_error("ransac_tail_batch: at most 32 frames"); return VS_ERR_INVALID_ARG; }
     hipLaunchKernelGGL(ransac_tail_batch_kernel, dim3(1), dim3(threads), 0, st, static_cast<const RansacArgs*>(d_table),
                        static_cast<const TailItem*>(d_tail), items, d_M_out);
     VS_HIP_TRY(hipGetLastError());

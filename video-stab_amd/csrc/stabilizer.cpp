@@ -67,12 +67,12 @@ int launch_make_border(const uint8_t* src, size_t sstride, int w, int h, int cn,
 int launch_resize_linear(const uint8_t* d_src, size_t sstride, int sw, int sh, int cn, uint8_t* d_dst,
                          size_t dstride, int dw, int dh, hipStream_t st);
 
-constexpr int FRAME_RING = 96;      // <= 35 queued frames (clamp(smoothingRadius,5,35)) + slack so that a
+constexpr int FRAME_RING = 128;     // <= 35 queued frames (clamp(smoothingRadius,5,35)) + slack so that a
                                     // slot is reused several frames after the warp that released it
 constexpr int MAX_PYR = 8;
 constexpr int NPYR = 3;             // pyramid buffers: frame k writes k%3 while LK(k-1) still reads (k-1)%3,(k-2)%3
 constexpr int WARP_BATCH_MAX = 16;   // = the warp kernel's frames per launch (k_warp.hip MAXB)
-constexpr int BATCH_MAX = 16;        // frames analysed per launch in batch mode (vs_stab_set_batch)
+constexpr int BATCH_MAX = 32;        // frames analysed per launch in batch mode (vs_stab_set_batch)
 constexpr int EVR = 4;              // per-frame event ring
 
 struct Pyramid {
@@ -372,7 +372,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     const size_t o_tail = take(tail_item_bytes() * B);
     const size_t o_pairs = take(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
     size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
-    size_t o_MinvB[2] = {take((size_t)WARP_BATCH_MAX * 96), take((size_t)WARP_BATCH_MAX * 96)};
+    size_t o_MinvB[2] = {take((size_t)BATCH_MAX * 96), take((size_t)BATCH_MAX * 96)};
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
     S_HIP(s, hipMemsetAsync(s->d_all, 0, off, s->st));
     uint8_t* b = s->d_all;
@@ -622,11 +622,12 @@ int launch_ready(vs_stab* s) {
     vs_stab::ReadyWarps& R = s->ready;
     if (!R.valid) return VS_OK;
     hipStream_t st = s->st;
-    int rc;
-    {
+    int rc = VS_OK;
+    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes 16 frames per launch
+        const int m = std::min(WARP_BATCH_MAX, R.n - i0);
         StageScope t(s, VS_STAGE_WARP, st);
-        rc = launch_warp_affine_list(R.srcs, R.dsts, R.n, s->row_bytes, s->w, s->h, R.stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[R.set], 12, st);
+        rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->row_bytes, s->w, s->h, R.stride, s->w, s->h, s->cn,
+                                     s->d_MinvB[R.set] + 12 * i0, 12, st);
     }
     if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) s->warp_valid[R.set] = true;
     for (int i = 0; i < R.n; i++) {
@@ -1228,7 +1229,7 @@ int vs_stab_set_batch(vs_stab* s, int frames) {
     if (!s || frames < 1 || frames > BATCH_MAX) return VS_ERR_INVALID_ARG;
     if (s->allocated) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_batch: call before the first frame or after vs_stab_clean");
     s->batch = frames;
-    if (frames > 1) s->warp_batch = frames;
+    if (frames > 1) s->warp_batch = std::min(frames, WARP_BATCH_MAX);
     return VS_OK;
 }
 
