@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--profile-stages", action="store_true", help="time every stage (adds event records)")
     ap.add_argument("--zero-copy", type=int, default=1,
                     help="frames are read where they lie in HBM instead of being copied into the instance's queue")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=32,
                     help="batch mode: analysis stages of this many consecutive pushes run as one launch each (1 = per-frame pipeline)")
     ap.add_argument("--warp-batch", type=int, default=8,
                     help="deferred output: results of this many consecutive pushes are warped by one launch (1 = one launch per push)")

@@ -210,6 +210,7 @@ struct vs_stab {
         uint8_t* dsts[BATCH_MAX];
         int slots[BATCH_MAX];
     } ready;
+    int last_warp_set = -1;
     // stage profiling (HIP events on the stream the stage runs on)
     int prof_mode = 0;
     struct Pending { hipEvent_t a, b; int stage; };
@@ -340,7 +341,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->pyr.assign(s->npyr, Pyramid());
     s->d_pts.assign(nkp, nullptr); s->d_npts.assign(nkp, nullptr); s->pts_cap.assign(nkp, 0);
     s->items.assign(B, vs_stab::ItemBufs());
-    s->bq.clear(); s->batch_id = 0; s->kp_cur = 0; s->kp_next = 1; s->last_det_batch = -1; s->ready.valid = false;
+    s->bq.clear(); s->batch_id = 0; s->kp_cur = 0; s->kp_next = 1; s->last_det_batch = -1; s->ready.valid = false; s->last_warp_set = -1;
     for (auto& v : s->bdet_valid) v = false;
     S_HIP(s, hipMalloc((void**)&s->d_ring, s->frame_bytes * FRAME_RING));
     s->free_slots.clear();
@@ -629,7 +630,7 @@ int launch_ready(vs_stab* s) {
         rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->row_bytes, s->w, s->h, R.stride, s->w, s->h, s->cn,
                                      s->d_MinvB[R.set] + 12 * i0, 12, st);
     }
-    if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) s->warp_valid[R.set] = true;
+    if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
     for (int i = 0; i < R.n; i++) {
         const int slot = R.slots[i];
         if (slot < 0) continue;          // zero-copy: the frame is the caller's
@@ -757,6 +758,11 @@ int run_batch(vs_stab* s) {
         // ring reuse: these slots were read by the analysis two batches ago (npyr = 2*batch + 2)
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(k - 2) % 4], 0));
         if (s->bdet_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(k - 2) % 4], 0));
+    }
+    if (s->last_warp_set >= 0 && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr) {
+        // keep the HBM-bound warp alone on the GPU even when the host runs batches ahead: this batch's gray /
+        // pyramid / detection kernels start after the warps issued during the previous run_batch (batch k-2's)
+        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_warp[s->last_warp_set], 0));
     }
     if (s->bq[0].prev_small) {   // :598-603 (once: 480x270 -> analysis size)
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
