@@ -354,6 +354,39 @@ def test_pipeline_4k_nv12_config3_against_oracle(gpu, oracle):
         oracle.lib.vso_set_threads(1)
 
 
+def test_batch_mode_output_pitch_may_change(gpu):
+    """A different output pitch closes the batch being collected (one pitch per batched warp launch)."""
+    n = 30
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 51, 320, 240, n)
+    p = gpu.params(smoothing_radius=5)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(8)
+    fb = clip[0].nbytes
+    pitch2 = 336 * 3
+    d_in = capi.DevBuf(gpu, fb * n)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, fb * n), capi.DevBuf(gpu, pitch2 * 240 * n)
+    d_got.zero()
+    k1 = k2 = 0
+    pitches = []
+    for i in range(n):
+        k1 += s1.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_ref.ptr + k1 * fb, 320 * 3)
+        pitch = pitch2 if (i // 5) % 2 else 320 * 3          # changes every 5 pushes, i.e. inside batches
+        got = s2.push_dev(d_in.ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr + k2 * pitch2 * 240, pitch)
+        if got:
+            pitches.append(pitch)
+        k2 += got
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n - 4
+    ref = d_ref.download((k1, 240, 320, 3), np.uint8)
+    raw = d_got.download((n, pitch2 * 240), np.uint8)
+    for j, pitch in enumerate(pitches):
+        got = raw[j, :pitch * 240].reshape(240, pitch)[:, :960].reshape(240, 320, 3)
+        assert np.array_equal(got, ref[j]), j
+    s1.close(); s2.close()
+
+
 @pytest.mark.parametrize("batch", [1, 8])
 def test_zero_copy_input_matches_queued_copy(gpu, batch):
     """vs_stab_set_zero_copy: frames are read where the caller holds them (here: a resident clip that stays

@@ -713,6 +713,9 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
 int batch_enqueue(vs_stab* s, const uint8_t* frame, int slot, int f, uint8_t* d_out, size_t out_stride, int* produced) {
     const vs_params_c& p = s->p;
     const int N = s->npyr, c = f % N, pv = (f - 1) % N;
+    // one output pitch per batched warp launch: a change of pitch closes the batch that is being collected
+    for (const vs_stab::BFrame& q : s->bq)
+        if (q.out_due && q.out_stride != out_stride) { S_TRY(s, drain_batch(s)); break; }
     vs_stab::BFrame b;
     memset(&b, 0, sizeof b);
     b.f = f; b.c = c; b.pv = pv;
