@@ -223,7 +223,8 @@ int vs_stab_set_warp_batch(vs_stab* s, int frames);
  * stays per frame, and the warps go out together as with vs_stab_set_warp_batch(frames).
  * Results are bit-identical to frames = 1 and complete after vs_stab_sync(); every push must
  * be given its own d_out until then.  Must be chosen before the first frame (or after
- * vs_stab_clean).  NV12, border/crop modes and adaptive smoothing keep the per-frame path. */
+ * vs_stab_clean).  BGR8, GRAY8 and NV12 frames; border/crop modes and adaptive smoothing
+ * keep the per-frame path. */
 int vs_stab_set_batch(vs_stab* s, int frames);
 /* Zero-copy input for vs_stab_push_dev: the frame is read where the caller put it (decoder
  * surface pool, resident clip) instead of being copied into the instance's queue - the

@@ -13,18 +13,25 @@ d_in = capi.DevBuf(vs, fb * 6)
 for i, f in enumerate(clip): d_in.upload(f, i * fb)
 outs = [capi.DevBuf(vs, fb) for _ in range(4)]
 p = vs.params(smoothing_radius=30, max_corners=400, lk_win_size=21, lk_max_level=2)
-s = vs.stabilizer(p)
-order = [i % 6 if (i // 6) % 2 == 0 else 5 - i % 6 for i in range(1000)]
-for i in range(80):
-    s.push_dev(d_in.ptr + order[i] * fb, W, H, W, capi.FMT_NV12, outs[i % 4].ptr, W)
-s.sync()
-n = 300
-t0 = time.perf_counter()
-for i in range(80, 80 + n):
-    s.push_dev(d_in.ptr + order[i] * fb, W, H, W, capi.FMT_NV12, outs[i % 4].ptr, W)
-s.sync()
-dt = time.perf_counter() - t0
-print("4K NV12 stabilize (per-frame pipeline): %.0f frames/s" % (n / dt))
+order = [i % 6 if (i // 6) % 2 == 0 else 5 - i % 6 for i in range(2000)]
+for batch in (1, 16):
+    s = vs.stabilizer(p)
+    if batch > 1:
+        s.set_batch(batch); s.set_zero_copy(True)
+    nb = max(4, 3 * batch)
+    while len(outs) < nb:
+        outs.append(capi.DevBuf(vs, fb))
+    for i in range(96):
+        s.push_dev(d_in.ptr + order[i] * fb, W, H, W, capi.FMT_NV12, outs[i % nb].ptr, W)
+    s.sync()
+    n = 320
+    t0 = time.perf_counter()
+    for i in range(96, 96 + n):
+        s.push_dev(d_in.ptr + order[i] * fb, W, H, W, capi.FMT_NV12, outs[i % nb].ptr, W)
+    s.sync()
+    dt = time.perf_counter() - t0
+    print("4K NV12 stabilize, batch %d: %.0f frames/s" % (batch, n / dt))
+    s.close()
 f = roll_scene.horizon_frame(W, H, 60, seed=1)
 d_f, d_r, d_z = capi.DevBuf.from_array(vs, f), capi.DevBuf(vs, f.nbytes), capi.DevBuf(vs, f.nbytes)
 rc, az = vs.roll_correction(), vs.auto_zoom_crop()

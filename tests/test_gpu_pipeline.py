@@ -354,6 +354,36 @@ def test_pipeline_4k_nv12_config3_against_oracle(gpu, oracle):
         oracle.lib.vso_set_threads(1)
 
 
+@pytest.mark.parametrize("size,batch", [((320, 240), 8), ((640, 360), 16)])
+def test_batch_mode_nv12(gpu, size, batch):
+    """NV12 surfaces in batch mode (Y plane analysed and warped, interleaved chroma warped with the halved
+    translation): same surfaces as the per-frame pipeline, flush included."""
+    w, h = size
+    n = 44
+    clip = [synth.bgr_to_nv12(f) for f in synth.make_clip(synth.SEED_CONFIG3 + 5, w, h, n)]
+    p = gpu.params(smoothing_radius=6, max_corners=400)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(batch)
+    s2.set_zero_copy(True)
+    fb = clip[0].nbytes
+    d_in = capi.DevBuf(gpu, fb * n)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, fb * n), capi.DevBuf(gpu, fb * n)
+    k1 = k2 = 0
+    for i in range(n):
+        k1 += s1.push_dev(d_in.ptr + i * fb, w, h, w, capi.FMT_NV12, d_ref.ptr + k1 * fb, w)
+        k2 += s2.push_dev(d_in.ptr + i * fb, w, h, w, capi.FMT_NV12, d_got.ptr + k2 * fb, w)
+    while s1.flush_dev(d_ref.ptr + k1 * fb, w):
+        k1 += 1
+    while s2.flush_dev(d_got.ptr + k2 * fb, w):
+        k2 += 1
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n
+    assert np.array_equal(d_ref.download((n, h * 3 // 2, w), np.uint8), d_got.download((n, h * 3 // 2, w), np.uint8))
+    s1.close(); s2.close()
+
+
 def test_batch_mode_output_pitch_may_change(gpu):
     """A different output pitch closes the batch being collected (one pitch per batched warp launch)."""
     n = 30

@@ -333,7 +333,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
             if (sw <= s->p.lk_win_size || sh <= s->p.lk_win_size) break;
         }
     }
-    s->batch_active = s->batch > 1 && fmt != VS_FMT_NV12 && s->p.border_size <= 0 && !s->p.adaptive_smoothing;
+    s->batch_active = s->batch > 1 && s->p.border_size <= 0 && !s->p.adaptive_smoothing;
     const int B = s->batch_active ? s->batch : 1;
     s->npyr = s->batch_active ? 2 * B + 2 : NPYR;
     // keypoint buffers: one per detection, recycled after two batches' worth of detections
@@ -629,6 +629,17 @@ int launch_ready(vs_stab* s) {
         StageScope t(s, VS_STAGE_WARP, st);
         rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->row_bytes, s->w, s->h, R.stride, s->w, s->h, s->cn,
                                      s->d_MinvB[R.set] + 12 * i0, 12, st);
+        if (rc == VS_OK && s->fmt == VS_FMT_NV12) {
+            // interleaved chroma plane: half size, two channels, the map with the halved translation
+            const uint8_t* us[WARP_BATCH_MAX];
+            uint8_t* ud[WARP_BATCH_MAX];
+            for (int i = 0; i < m; i++) {
+                us[i] = R.srcs[i0 + i] + (size_t)s->h * s->row_bytes;
+                ud[i] = R.dsts[i0 + i] + (size_t)s->h * R.stride;
+            }
+            rc = launch_warp_affine_list(us, ud, m, s->row_bytes, s->w / 2, s->h / 2, R.stride, s->w / 2, s->h / 2, 2,
+                                         s->d_MinvB[R.set] + 12 * i0 + 6, 12, st);
+        }
     }
     if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
     for (int i = 0; i < R.n; i++) {
@@ -787,7 +798,9 @@ int run_batch(vs_stab* s) {
         S_HIP(s, hipMemcpyAsync(s->d_pairs, s->h_pairs.data(), sizeof(ImgPair) * n * (2 * L + 2), hipMemcpyHostToDevice, s->st_pre));
         {
             StageScope t(s, VS_STAGE_GRAY, s->st_pre);
-            S_TRY(s, launch_resize_gray_batch(s->d_pairs, n, s->row_bytes, s->w, s->h, s->fmt, s->aw, s->aw, s->ah, aligned, s->st_pre));  // :448-450
+            // NV12: the Y plane is the gray image (no reference path; same policy as the per-frame pipeline)
+            S_TRY(s, launch_resize_gray_batch(s->d_pairs, n, s->row_bytes, s->w, s->h, s->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s->fmt,
+                                              s->aw, s->aw, s->ah, aligned, s->st_pre));  // :448-450
         }
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
         for (int l = 1; l <= L; l++)
