@@ -1,11 +1,8 @@
-// Small per-frame device kernels that keep stabilize() free of host round
-// trips (so one step is a fixed kernel sequence, capturable in a hipGraph):
+// Small per-frame device kernels that keep stabilize() free of host round trips.
+// (The status compaction, /root/reference/src/Stabilizer.cpp:629-641, is fused into the RANSAC scoring
+// kernel and the transform append, :644-693 + drone filters :2468-2682, into the RANSAC selection:
+// k_ransac.hip, traj_device.h.)
 //
-//  compact_kernel - status compaction of the LK result, order preserving
-//      (/root/reference/src/Stabilizer.cpp:629-641), one wave, ballot + prefix.
-//  traj_append_kernel - model -> (dx,dy,da) (:644-662), drone filters
-//      (:2468-2520,:2605-2682), transforms_/path_ append (:673-688),
-//      adaptSmoothingRadius (:1461-1492).
 //  traj_emit_kernel - the part of applyNextSmoothTransform() that produces the
 //      2x3 matrix (:783-908): box / gaussian / kalman smoothing evaluated only
 //      around the frame that leaves the queue (the reference re-smooths the
@@ -22,41 +19,6 @@
 
 namespace vsd {
 namespace {
-
-__global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ prev, const float* __restrict__ cur,
-                                                     const uint8_t* __restrict__ status, int n_cap,
-                                                     const int32_t* __restrict__ d_n, float* __restrict__ vp,
-                                                     float* __restrict__ vc, int32_t* __restrict__ d_m,
-                                                     vs_debug_frame* dbg) {
-    const int lane = threadIdx.x;
-    int n = *d_n;
-    n = n < n_cap ? n : n_cap;
-    int m = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const bool keep = i < n && status[i] != 0;
-        const unsigned long long mask = __ballot(keep);
-        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-        if (keep) {
-            vp[2 * pos] = prev[2 * i]; vp[2 * pos + 1] = prev[2 * i + 1];
-            vc[2 * pos] = cur[2 * i]; vc[2 * pos + 1] = cur[2 * i + 1];
-        }
-        m += __popcll(mask);
-    }
-    if (lane == 0) {
-        *d_m = m;
-        dbg->n_prev = n;
-        dbg->n_valid = m;
-    }
-}
-
-__global__ void traj_append_kernel(TrajState* s, TrajParams p, const double* __restrict__ model,
-                                   const int32_t* __restrict__ info, const int32_t* __restrict__ d_nprev,
-                                   vs_debug_frame* dbg, int have_prev_gray) {
-    if (threadIdx.x != 0) return;
-    traj_append_device(s, p, model, info, *d_nprev, dbg, have_prev_gray);
-}
-
 
 __global__ __launch_bounds__(64) void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __restrict__ M_out,
                                                        double* __restrict__ Minv_out, vs_debug_frame* dbg) {
@@ -109,18 +71,6 @@ __global__ __launch_bounds__(256) void make_border_kernel(const uint8_t* __restr
 
 }  // namespace
 
-int launch_compact(const float* prev, const float* cur, const uint8_t* status, int n_cap, const int32_t* d_n,
-                   float* vp, float* vc, int32_t* d_m, vs_debug_frame* dbg, hipStream_t st) {
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(64), 0, st, prev, cur, status, n_cap, d_n, vp, vc, d_m, dbg);
-    VS_HIP_TRY(hipGetLastError());
-    return VS_OK;
-}
-int launch_traj_append(TrajState* s, const TrajParams& p, const double* model, const int32_t* info,
-                       const int32_t* d_nprev, vs_debug_frame* dbg, int have_prev_gray, hipStream_t st) {
-    hipLaunchKernelGGL(traj_append_kernel, dim3(1), dim3(64), 0, st, s, p, model, info, d_nprev, dbg, have_prev_gray);
-    VS_HIP_TRY(hipGetLastError());
-    return VS_OK;
-}
 int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
                      hipStream_t st) {
     hipLaunchKernelGGL(traj_emit_kernel, dim3(1), dim3(64), 0, st, s, p, idx, M_out, Minv_out, dbg);
