@@ -18,6 +18,12 @@
 // (pyramid ready, keypoints ready, buffer no longer read).  Pyramids are
 // triple-buffered and the frame ring has spare slots so that `pre` of the next
 // frame never waits for `main` of the current one.
+//
+// Batch mode (vs_stab_set_batch, device entry points): the same decisions are taken per
+// push, but the device work of `batch` consecutive frames is issued together - one
+// launch per stage over all frames (argument tables in device memory), one ordered
+// tail kernel (selection + trajectory append + smoothing, state in LDS), one warp
+// launch per 16 frames - see run_batch().  DESIGN.md section 5 has the schedule.
 #include <algorithm>
 #include <array>
 #include <cstring>
