@@ -154,8 +154,31 @@ typedef struct vs_roll_params_c {
     double  max_angle_change_deg;    /* 0.5                                    */
 } vs_roll_params_c;
 
+/* Flat mirror of vs::Enhancer::Parameters (include/video/Enhancer.h:12-43). */
+typedef struct vs_enh_params_c {
+    int32_t struct_size;
+    float   brightness;              /* 0   added to every sample (convertTo beta)  */
+    float   contrast;                /* 1   multiplies every sample (convertTo alpha) */
+    int32_t enable_white_balance;    /* 0                                      */
+    float   wb_strength;             /* 1                                      */
+    int32_t enable_vibrance;         /* 0                                      */
+    float   vibrance_strength;       /* 0.3                                    */
+    int32_t enable_unsharp;          /* 0                                      */
+    float   sharpness;               /* 0                                      */
+    float   blur_sigma;              /* 1   (kernel 2*round(3*sigma)+1 taps, at most 33) */
+    int32_t enable_clahe;            /* 0                                      */
+    float   clahe_clip_limit;        /* 2                                      */
+    int32_t clahe_tile_grid_size;    /* 8   (1..16)                            */
+    int32_t enable_denoise;          /* 0   (VS_ERR_UNSUPPORTED if set with strength > 0) */
+    float   denoise_strength;        /* 10                                     */
+    float   gamma;                   /* 1                                      */
+    int32_t use_cuda;                /* 0: stage order of the reference's CPU branch, 1: of its CUDA branch */
+    int32_t reserved0;
+} vs_enh_params_c;
+
 typedef struct vs_stab vs_stab;   /* opaque instance (one video stream)        */
 typedef struct vs_roll vs_roll;   /* opaque roll-correction state              */
+typedef struct vs_enh vs_enh;     /* opaque enhancer scratch (tables, stream)  */
 
 /* ---- library ------------------------------------------------------------- */
 int          vs_abi_version(void);
@@ -377,6 +400,41 @@ int vs_op_content_mask(const void* d_src, size_t stride, int w, int h, int cn, v
  * drawContours(FILLED) mask.  Needs no device. */
 int vs_azc_crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, int32_t* info8,
                           uint8_t* filled_out);
+
+/* ---- image enhancer: vs::Enhancer (Enhancer.h:10-60, Enhancer.cpp:138-239) ------------ */
+/* Enhancer::Parameters defaults, Enhancer.h:12-43 */
+void vs_enh_params_default(vs_enh_params_c* p);
+/* enhanceImage is a static function without state (Enhancer.cpp:138); the object only owns
+ * the device tables, scratch frames and the stream the work is queued on. */
+int vs_enh_create(int device, vs_enh** out);
+void vs_enh_destroy(vs_enh* e);
+const char* vs_enh_last_error(const vs_enh* e);
+/* cv::Mat Enhancer::enhanceImage(const cv::Mat& input, const Parameters&), Enhancer.cpp:138-239.
+ * BGR8 in, BGR8 out of the same size; synchronous.  Stage order: params->use_cuda = 0 the CPU
+ * branch (:142-181: white balance, brightness/contrast, CLAHE, vibrance, unsharp, gamma),
+ * 1 the CUDA branch (:183-233: brightness/contrast, unsharp, white balance, vibrance, CLAHE,
+ * gamma); each stage computes what the CPU OpenCV primitive computes.  enable_denoise with
+ * denoise_strength > 0 (:165-169) returns VS_ERR_UNSUPPORTED. */
+int vs_enh_apply(vs_enh* e, const vs_enh_params_c* params, const uint8_t* data, int w, int h,
+                 size_t stride, uint8_t* out, size_t out_stride);
+/* Same with frames in HBM (d_out must not alias d_data); left in flight on the object's
+ * stream (vs_enh_sync to wait). */
+int vs_enh_apply_dev(vs_enh* e, const vs_enh_params_c* params, const void* d_data, int w, int h,
+                     size_t stride, void* d_out, size_t out_stride);
+/* n frames of one geometry; one launch per pass over all frames when the stage list has no
+ * per-frame statistic (no white balance / CLAHE), frame by frame otherwise. */
+int vs_enh_apply_batch_dev(vs_enh* e, const vs_enh_params_c* params, const void* const* d_frames,
+                           void* const* d_outs, int n, int w, int h, size_t stride,
+                           size_t out_stride);
+int vs_enh_sync(vs_enh* e);
+/* passes over the frame (kernel launches that read it) the last apply needed */
+int vs_enh_last_passes(const vs_enh* e);
+/* cv::cvtColor on packed 8-bit 3-channel pixels (Enhancer.cpp:43,56,61,68), on the object's stream */
+enum vs_cvt_code { VS_CVT_BGR2HSV = 0, VS_CVT_HSV2BGR = 1, VS_CVT_BGR2LAB = 2, VS_CVT_LAB2BGR = 3 };
+int vs_enh_cvt_color(vs_enh* e, int code, const void* d_src, void* d_dst, size_t npix);
+/* cv::GaussianBlur(src, dst, Size(0,0), sigma) on BGR8 (Enhancer.cpp:160-161), on the object's stream */
+int vs_enh_gaussian_blur(vs_enh* e, const void* d_src, size_t stride, int w, int h, double sigma,
+                         void* d_dst, size_t dstride);
 
 #ifdef __cplusplus
 }

@@ -129,6 +129,33 @@ void vso_azc_crop_rect(const uint8_t* content_mask, int w, int h, int32_t* info)
 int  vso_azc_apply(const uint8_t* src, int w, int h, size_t stride, int cn, uint8_t* out, int32_t* out_w,
                    int32_t* out_h, int32_t* info);
 
+/* ---- vs::Enhancer restated (src/Enhancer.cpp:19-69,138-239), vso_enhance.cpp ---- */
+void vso_enh_params_default(vs_enh_params_c* p);
+/* convertTo(-1, alpha, beta) on CV_8U as a table (:37-39,:150) */
+void vso_convert_scale_lut(double alpha, double beta, uint8_t* lut256);
+/* whiteBalanceCPU factors from the channel sums (:22-36) */
+void vso_wb_scales(const uint64_t* sums, uint64_t npix, float alpha, double* scales);
+void vso_gamma_lut(float gamma, uint8_t* lut256);                       /* :171-178 */
+/* cvtColor 8U, packed 3-channel pixels: BGR2HSV / HSV2BGR (:43,:56), BGR2Lab / Lab2BGR (:61,:68) */
+void vso_bgr2hsv(const uint8_t* src, size_t n, uint8_t* dst);
+void vso_hsv2bgr(const uint8_t* src, size_t n, uint8_t* dst);
+void vso_bgr2lab(const uint8_t* src, size_t n, uint8_t* dst);
+void vso_lab2bgr(const uint8_t* src, size_t n, uint8_t* dst);
+void vso_vibrance(uint8_t* bgr, size_t n, float alpha);                 /* :41-57 */
+/* tap count of GaussianBlur(Size(0,0), sigma) on CV_8U and its 8.8 fixed-point kernel */
+int  vso_gaussian_kernel_q8(double sigma, uint16_t* k, int cap);
+int  vso_gaussian_blur_u8(const uint8_t* src, int w, int h, size_t stride, int cn, double sigma, uint8_t* dst,
+                          size_t dstride);                              /* :160-161 */
+void vso_add_weighted_u8(const uint8_t* a, double alpha, const uint8_t* b, double beta, double gamma, uint8_t* dst,
+                         size_t n);                                     /* :162 */
+/* cv::CLAHE on one 8-bit plane (:64-65); lut_out (optional) tiles*tiles*256 bytes */
+int  vso_clahe_u8(const uint8_t* src, int w, int h, size_t stride, double clip_limit, int tiles, uint8_t* dst,
+                  size_t dstride, uint8_t* lut_out);
+int  vso_clahe_bgr(uint8_t* bgr, int w, int h, float clip_limit, int tiles);   /* :59-69 */
+/* enhanceImage (:138-239), BGR8; 0 ok, -1 bad argument, -2 stage not restated (denoise) */
+int  vso_enhance(const uint8_t* src, int w, int h, size_t stride, const vs_enh_params_c* p, uint8_t* out,
+                 size_t out_stride);
+
 
 /* threads used by row/point-parallel stages of vso_stab_push (default 1) */
 void vso_set_threads(int n);

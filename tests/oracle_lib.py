@@ -307,6 +307,99 @@ class Oracle:
         shape = (oh.value, ow.value) if cn == 1 else (oh.value, ow.value, 3)
         return buf[:oh.value * ow.value * cn].reshape(shape).copy(), info
 
+    # ---- enhancer (vso_enhance.cpp) ---------------------------------------
+    def enh_params(self, **kw):
+        from vsamd.capi import VsEnhParams
+        p = VsEnhParams()
+        self.lib.vso_enh_params_default.restype = None
+        self.lib.vso_enh_params_default(C.byref(p))
+        for k, v in kw.items():
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+        return p
+
+    def convert_scale_lut(self, alpha, beta):
+        lut = np.empty(256, np.uint8)
+        self.lib.vso_convert_scale_lut.restype = None
+        self.lib.vso_convert_scale_lut.argtypes = [C.c_double, C.c_double, u8p]
+        self.lib.vso_convert_scale_lut(alpha, beta, _p(lut, u8p))
+        return lut
+
+    def wb_scales(self, sums, npix, alpha):
+        sums = np.ascontiguousarray(sums, np.uint64)
+        out = np.empty(3, np.float64)
+        self.lib.vso_wb_scales.restype = None
+        self.lib.vso_wb_scales.argtypes = [C.c_void_p, C.c_uint64, C.c_float, f64p]
+        self.lib.vso_wb_scales(sums.ctypes.data, npix, alpha, _p(out, f64p))
+        return out
+
+    def gamma_lut(self, gamma):
+        lut = np.empty(256, np.uint8)
+        self.lib.vso_gamma_lut.restype = None
+        self.lib.vso_gamma_lut.argtypes = [C.c_float, u8p]
+        self.lib.vso_gamma_lut(gamma, _p(lut, u8p))
+        return lut
+
+    def cvt_color(self, code, px):
+        px = np.ascontiguousarray(px, np.uint8).reshape(-1, 3)
+        out = np.empty_like(px)
+        f = getattr(self.lib, "vso_" + code)
+        f.restype = None
+        f.argtypes = [u8p, C.c_size_t, u8p]
+        f(_p(px, u8p), len(px), _p(out, u8p))
+        return out
+
+    def vibrance(self, px, alpha):
+        px = np.ascontiguousarray(px, np.uint8).reshape(-1, 3).copy()
+        self.lib.vso_vibrance.restype = None
+        self.lib.vso_vibrance.argtypes = [u8p, C.c_size_t, C.c_float]
+        self.lib.vso_vibrance(_p(px, u8p), len(px), alpha)
+        return px
+
+    def gaussian_kernel_q8(self, sigma):
+        k = np.zeros(256, np.uint16)
+        self.lib.vso_gaussian_kernel_q8.argtypes = [C.c_double, C.c_void_p, C.c_int]
+        n = self.lib.vso_gaussian_kernel_q8(sigma, k.ctypes.data, 256)
+        return k[:max(n, 0)].copy()
+
+    def gaussian_blur(self, img, sigma):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty_like(img)
+        self.lib.vso_gaussian_blur_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_double, u8p, C.c_size_t]
+        n = self.lib.vso_gaussian_blur_u8(_p(img, u8p), w, h, w * cn, cn, sigma, _p(out, u8p), w * cn)
+        assert n > 0
+        return out
+
+    def add_weighted(self, a, alpha, b, beta, gamma=0.0):
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+        out = np.empty_like(a)
+        self.lib.vso_add_weighted_u8.restype = None
+        self.lib.vso_add_weighted_u8.argtypes = [u8p, C.c_double, u8p, C.c_double, C.c_double, u8p, C.c_size_t]
+        self.lib.vso_add_weighted_u8(_p(a, u8p), alpha, _p(b, u8p), beta, gamma, _p(out, u8p), a.size)
+        return out
+
+    def clahe(self, plane, clip_limit, tiles, want_lut=False):
+        plane = np.ascontiguousarray(plane, np.uint8)
+        h, w = plane.shape
+        out = np.empty_like(plane)
+        lut = np.zeros((tiles * tiles, 256), np.uint8)
+        self.lib.vso_clahe_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int, u8p, C.c_size_t, u8p]
+        rc = self.lib.vso_clahe_u8(_p(plane, u8p), w, h, w, clip_limit, tiles, _p(out, u8p), w, _p(lut, u8p))
+        assert rc == 0
+        return (out, lut) if want_lut else out
+
+    def enhance(self, frame, params):
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        out = np.empty_like(frame)
+        self.lib.vso_enhance.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, u8p, C.c_size_t]
+        rc = self.lib.vso_enhance(_p(frame, u8p), w, h, w * 3, C.cast(C.byref(params), C.c_void_p), _p(out, u8p), w * 3)
+        if rc != 0:
+            raise RuntimeError("vso_enhance: %d" % rc)
+        return out
+
     def roll_params(self, **kw):
         p = self.VsRollParams()
         self.lib.vso_roll_params_default(C.byref(p))

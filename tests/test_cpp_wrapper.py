@@ -68,3 +68,37 @@ def test_roll_wrapper_runs_example_loop(gpu):
     assert r.returncode == 0, r.stdout + r.stderr
     n, ow, oh, _ = r.stdout.split()
     assert (int(n), int(ow), int(oh)) == (6, 640, 360)
+
+
+ENH_EXE = os.path.join(ROOT, "tests", "cpp", "_build", "enhance_smoke")
+
+
+def build_enh():
+    os.makedirs(os.path.dirname(ENH_EXE), exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "tests", "mock_opencv"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "enhance_smoke.cpp"), os.path.join(ROOT, "video-stab_amd", "host", "Enhancer.cpp"),
+           "-L" + CSRC, "-lvideo-stab", "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", ENH_EXE]
+    subprocess.check_call(cmd)
+
+
+def test_enhancer_wrapper_compiles_and_fails_loudly_without_gpu(vs):
+    build_enh()
+    if vs.lib.vs_device_count() > 0:
+        return
+    r = subprocess.run([ENH_EXE], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_enhancer_wrapper_matches_oracle(gpu, oracle):
+    """examples/vs.cpp:547-550 with examples/config.yaml:23-47 through the C++ class."""
+    import numpy as np
+    build_enh()
+    w, h = 333, 201
+    r = subprocess.run([ENH_EXE, str(w), str(h)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    yy, xx = np.mgrid[0:h, 0:w]
+    frame = np.stack([(xx * 3 + yy * 5) & 255, (xx ^ yy) & 255, (xx * yy) & 255], 2).astype(np.uint8)
+    p = oracle.enh_params(brightness=1.5, contrast=1.1, enable_unsharp=1, sharpness=2.0, blur_sigma=1.0, gamma=1.2, use_cuda=1)
+    want = int(oracle.enhance(frame, p).astype(np.uint64).sum())
+    assert r.stdout.split() == [str(w), str(h), str(want)]

