@@ -241,61 +241,102 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 }
 
+typedef const uint8_t __attribute__((address_space(1)))* gptr_c;   // global address space: global_load/store, not flat
+typedef uint8_t __attribute__((address_space(1)))* gptr;
+
+// One composed table per side of the blur at fixed LDS addresses: lookups need no address arithmetic.
+__device__ __forceinline__ void compose_luts(const Chain& ch, const uint8_t* g_lut, uint8_t* s_tab, int tid) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int v = tid;
+#pragma unroll
+        for (int k = 0; k < CHAIN_MAX; k++)
+            if (k < ch.n) v = g_lut[ch.slot[k] * SLOT_BYTES + c * 256 + v];
+        s_tab[c * 256 + tid] = (uint8_t)v;
+    }
+}
+
 template <int R>
 __global__ __launch_bounds__(E_NT) void enh_unsharp_kernel(const UnsharpArgs a) {
     constexpr int RA = (R + 3) / 4 * 4;             // halo along x rounded up to whole 4-px groups
     constexpr int SW = E_TW + 2 * RA, SH = E_TH + 2 * R, GW = SW / 4;
     constexpr int N = 2 * R + 1, NQ = (N + 3) / 4;
     constexpr int NDW = ((RA + R + 3) >> 2) + 1;    // dwords of a staged row one output group reads
-    __shared__ uint32_t s_plane[3][SH][GW];         // staged samples behind the front tables, 4 px per dword
-    __shared__ uint32_t s_h2[3][SH / 2][E_TW];      // horizontal sums of rows (2p, 2p+1) as (lo, hi) halves
-    __shared__ __attribute__((aligned(16))) uint8_t s_lut[LUT_SLOTS * SLOT_BYTES];
+    constexpr int NU = SH * GW, NRND = (NU + E_NT - 1) / E_NT;
+    constexpr int HP = SH / 2;                      // row pairs
+    __shared__ uint32_t s_plane[3 * SH][GW];        // staged samples behind the front table, 4 px per dword; row c*SH + y
+    __shared__ uint32_t s_h2[3 * HP][E_TW];         // horizontal sums of rows (2p, 2p+1) as (lo, hi) halves; row c*HP + p
+    __shared__ uint8_t s_pre[SLOT_BYTES], s_post[SLOT_BYTES];
 
     const int tid = threadIdx.x;
-    const uint8_t* src = a.src;
-    uint8_t* dst = a.dst;
-    if (a.table) { src = (const uint8_t*)a.table[blockIdx.z].src; dst = (uint8_t*)a.table[blockIdx.z].dst; }
+    gptr_c src = (gptr_c)a.src;
+    gptr dst = (gptr)a.dst;
+    if (a.table) { src = (gptr_c)a.table[blockIdx.z].src; dst = (gptr)a.table[blockIdx.z].dst; }
     const int x0 = blockIdx.x * E_TW, y0 = blockIdx.y * E_TH;
-    load_luts(s_lut, a.luts, tid, E_NT);
-    __syncthreads();
+    const bool has_pre = a.pre.n > 0, has_post = a.post.n > 0;
 
-    // 1. stage tile + halo: interleaved BGR -> front tables -> planar
-    for (int u = tid; u < SH * GW; u += E_NT) {
-        const int ry = u / GW, gx = u - ry * GW;
-        const int sy = reflect101(y0 - R + ry, a.h);
-        const int px = x0 - RA + 4 * gx;
-        const uint8_t* row = src + (size_t)sy * a.sstride;
-        int b[4], g[4], r[4];
-        if (a.src_aligned && px >= 0 && px + 3 < a.w) {
-            const uint32_t* p = (const uint32_t*)(row + (size_t)px * 3);
-            unpack12(p[0], p[1], p[2], b, g, r);
-        } else {
+    // 1a. raw loads of tile + halo (all rounds in flight), table composition meanwhile
+    uint32_t raw[NRND][3];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint8_t* q = row + (size_t)reflect101(px + i, a.w) * 3;
-                b[i] = q[0]; g[i] = q[1]; r[i] = q[2];
+    for (int k = 0; k < NRND; k++) {
+        const int u = tid + k * E_NT;
+        raw[k][0] = raw[k][1] = raw[k][2] = 0;
+        if (NU % E_NT == 0 || u < NU) {
+            const int ry = u / GW, gx = u - ry * GW;
+            int sy = y0 - R + ry;
+            if ((unsigned)sy >= (unsigned)a.h) sy = reflect101(sy, a.h);
+            const int px = x0 - RA + 4 * gx;
+            const uint32_t roff = (uint32_t)sy * (uint32_t)a.sstride;
+            if (a.src_aligned && px >= 0 && px + 3 < a.w) {
+                const uint32_t __attribute__((address_space(1)))* p =
+                    (const uint32_t __attribute__((address_space(1)))*)(src + (roff + (uint32_t)px * 3u));
+                raw[k][0] = p[0]; raw[k][1] = p[1]; raw[k][2] = p[2];
+            } else {
+                uint32_t by[12];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    gptr_c q = src + (roff + (uint32_t)reflect101(px + i, a.w) * 3u);
+                    by[3 * i] = q[0]; by[3 * i + 1] = q[1]; by[3 * i + 2] = q[2];
+                }
+                raw[k][0] = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
+                raw[k][1] = by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24);
+                raw[k][2] = by[8] | (by[9] << 8) | (by[10] << 16) | (by[11] << 24);
             }
         }
+    }
+    if (has_pre) compose_luts(a.pre, a.luts, s_pre, tid);
+    if (has_post) compose_luts(a.post, a.luts, s_post, tid);
+    __syncthreads();
+
+    // 1b. front table, interleaved -> planar
 #pragma unroll
-        for (int i = 0; i < 4; i++) apply_luts(a.pre, s_lut, b[i], g[i], r[i]);
-        s_plane[0][ry][gx] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
-        s_plane[1][ry][gx] = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
-        s_plane[2][ry][gx] = (uint32_t)r[0] | ((uint32_t)r[1] << 8) | ((uint32_t)r[2] << 16) | ((uint32_t)r[3] << 24);
+    for (int k = 0; k < NRND; k++) {
+        const int u = tid + k * E_NT;
+        if (NU % E_NT == 0 || u < NU) {
+            const int ry = u / GW, gx = u - ry * GW;
+            int b[4], g[4], r[4];
+            unpack12(raw[k][0], raw[k][1], raw[k][2], b, g, r);
+            if (has_pre) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { b[i] = s_pre[b[i]]; g[i] = s_pre[256 + g[i]]; r[i] = s_pre[512 + r[i]]; }
+            }
+            s_plane[ry][gx] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+            s_plane[SH + ry][gx] = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
+            s_plane[2 * SH + ry][gx] = (uint32_t)r[0] | ((uint32_t)r[1] << 8) | ((uint32_t)r[2] << 16) | ((uint32_t)r[3] << 24);
+        }
     }
     __syncthreads();
 
-    // 2. horizontal pass: exact 16-bit sums (kernel sums to 256), two rows per item
+    // 2. horizontal pass: exact 16-bit sums (kernel sums to 256); item = (row pair of one channel, 4-px group)
     if (!a.ident) {
-        for (int it = tid; it < 3 * (SH / 2) * (E_TW / 4); it += E_NT) {
-            const int c = it / ((SH / 2) * (E_TW / 4));
-            const int rem = it - c * ((SH / 2) * (E_TW / 4));
-            const int p = rem / (E_TW / 4), g = rem - p * (E_TW / 4);
+        const int g = tid & 15;
+        for (int pr = tid >> 4; pr < 3 * HP; pr += E_NT / 16) {
             uint32_t hsum[2][4];
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
                 uint32_t D[NDW];
 #pragma unroll
-                for (int k = 0; k < NDW; k++) D[k] = s_plane[c][2 * p + rr][g + k];
+                for (int k = 0; k < NDW; k++) D[k] = s_plane[2 * pr + rr][g + k];
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     uint32_t acc = 0;
@@ -316,63 +357,74 @@ __global__ __launch_bounds__(E_NT) void enh_unsharp_kernel(const UnsharpArgs a) 
             v.y = hsum[0][1] | (hsum[1][1] << 16);
             v.z = hsum[0][2] | (hsum[1][2] << 16);
             v.w = hsum[0][3] | (hsum[1][3] << 16);
-            *(uint4*)&s_h2[c][p][4 * g] = v;
+            *(uint4*)&s_h2[pr][4 * g] = v;
         }
         __syncthreads();
     }
 
-    // 3. vertical pass on row pairs + addWeighted + back tables + store: thread = (4-px group, row pair)
+    // 3. vertical pass on row pairs + addWeighted + back table + store: thread = (4-px group, row pair)
     const int g = tid & 15, P = tid >> 4;
     const int xg = x0 + 4 * g, yA = y0 + 2 * P;
     if (xg >= a.w || yA >= a.h) return;
-    int out[2][3][4];
+    uint32_t idx[2][3][4];                         // results as integers 0..255
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const uint32_t sA = s_plane[c][2 * P + R][RA / 4 + g], sB = s_plane[c][2 * P + R + 1][RA / 4 + g];
-        uint32_t accE[4] = {32768u, 32768u, 32768u, 32768u}, accO[4] = {32768u, 32768u, 32768u, 32768u};
-        if (!a.ident) {
+        const uint32_t sA = s_plane[c * SH + 2 * P + R][RA / 4 + g], sB = s_plane[c * SH + 2 * P + R + 1][RA / 4 + g];
+        float fa[4], fb[4], ba[4], bb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { fa[i] = (float)((sA >> (8 * i)) & 255u); fb[i] = (float)((sB >> (8 * i)) & 255u); }
+        if (a.ident) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ba[i] = fa[i]; bb[i] = fb[i]; }
+        } else {
+            uint32_t accE[4] = {32768u, 32768u, 32768u, 32768u}, accO[4] = {32768u, 32768u, 32768u, 32768u};
 #pragma unroll
             for (int j = 0; j <= R; j++) {
-                const uint4 v = *(const uint4*)&s_h2[c][P + j][4 * g];
+                const uint4 v = *(const uint4*)&s_h2[c * HP + P + j][4 * g];
                 const uint32_t e = a.we[j], o = a.wo[j];
                 accE[0] = udot2(v.x, e, accE[0]); accO[0] = udot2(v.x, o, accO[0]);
                 accE[1] = udot2(v.y, e, accE[1]); accO[1] = udot2(v.y, o, accO[1]);
                 accE[2] = udot2(v.z, e, accE[2]); accO[2] = udot2(v.z, o, accO[2]);
                 accE[3] = udot2(v.w, e, accE[3]); accO[3] = udot2(v.w, o, accO[3]);
             }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ba[i] = (float)((accE[i] >> 16) & 255u); bb[i] = (float)((accO[i] >> 16) & 255u); }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float fa = (float)((sA >> (8 * i)) & 255u), fb = (float)((sB >> (8 * i)) & 255u);
-            const float ba = a.ident ? fa : (float)((accE[i] >> 16) & 255u);
-            const float bb = a.ident ? fb : (float)((accO[i] >> 16) & 255u);
-            out[0][c][i] = clamp255(f_round(__fmaf_rn(fa, a.alpha, __fmul_rn(ba, a.beta))));
-            out[1][c][i] = clamp255(f_round(__fmaf_rn(fb, a.alpha, __fmul_rn(bb, a.beta))));
+            // v_cvt_pk_u8_f32: round to nearest even and saturate to 0..255 = saturate_cast<uchar>(cvRound(x))
+            idx[0][c][i] = __builtin_amdgcn_cvt_pk_u8_f32(__fmaf_rn(fa[i], a.alpha, __fmul_rn(ba[i], a.beta)), 0, 0);
+            idx[1][c][i] = __builtin_amdgcn_cvt_pk_u8_f32(__fmaf_rn(fb[i], a.alpha, __fmul_rn(bb[i], a.beta)), 0, 0);
         }
     }
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         if (yA + rr >= a.h) break;
+        int ob[4], og[4], orr[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) apply_luts(a.post, s_lut, out[rr][0][i], out[rr][1][i], out[rr][2][i]);
-        uint8_t* drow = dst + (size_t)(yA + rr) * a.dstride + (size_t)xg * 3;
+        for (int i = 0; i < 4; i++) {
+            ob[i] = has_post ? s_post[idx[rr][0][i]] : idx[rr][0][i];
+            og[i] = has_post ? s_post[256 + idx[rr][1][i]] : idx[rr][1][i];
+            orr[i] = has_post ? s_post[512 + idx[rr][2][i]] : idx[rr][2][i];
+        }
+        gptr drow = dst + ((uint32_t)(yA + rr) * (uint32_t)a.dstride + (uint32_t)xg * 3u);
         if (a.dst_aligned && xg + 3 < a.w) {
             uint32_t d0, d1, d2;
-            pack12(out[rr][0], out[rr][1], out[rr][2], d0, d1, d2);
-            uint32_t* q = (uint32_t*)drow;
+            pack12(ob, og, orr, d0, d1, d2);
+            uint32_t __attribute__((address_space(1)))* q = (uint32_t __attribute__((address_space(1)))*)drow;
             q[0] = d0; q[1] = d1; q[2] = d2;
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (xg + i < a.w) {
-                    drow[3 * i] = (uint8_t)out[rr][0][i]; drow[3 * i + 1] = (uint8_t)out[rr][1][i]; drow[3 * i + 2] = (uint8_t)out[rr][2][i];
-                }
+                if (xg + i < a.w) { drow[3 * i] = (uint8_t)ob[i]; drow[3 * i + 1] = (uint8_t)og[i]; drow[3 * i + 2] = (uint8_t)orr[i]; }
         }
     }
 }
 
 // ---- per-pixel kernel, channel sums, CLAHE histograms ---------------------------------------------
-constexpr int P_ROWS = 32;   // rows per workgroup (256 threads = 64 groups of 4 px x 4 rows per step)
+// rows per workgroup (256 threads = 64 groups of 4 px x 4 rows per step): few for one frame (more workgroups in flight),
+// many when the launch is large anyway or ends in atomics
+constexpr int P_ROWS_SMALL = 8, P_ROWS_LARGE = 32;
 
 struct PointArgs {
     const uint8_t* src; uint8_t* dst;
@@ -384,26 +436,28 @@ struct PointArgs {
     PointCtx pc;
     int32_t src_aligned, dst_aligned;
     int32_t heavy;                  // chain has a non-table stage
+    int32_t rows;                   // rows per workgroup (multiple of 4)
     unsigned long long* sums;       // sums kernel: 3 accumulators
 };
 
 template <bool SUMS>
 __global__ __launch_bounds__(256) void enh_point_kernel(const PointArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_lut[LUT_SLOTS * SLOT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lut[LUT_SLOTS * SLOT_BYTES];   // heavy chains: every slot; else [0,768): the composed table
     __shared__ unsigned long long s_sum[3];
     const int tid = threadIdx.x;
     const uint8_t* src = a.src;
     uint8_t* dst = a.dst;
     if (a.table) { src = (const uint8_t*)a.table[blockIdx.z].src; dst = (uint8_t*)a.table[blockIdx.z].dst; }
-    load_luts(s_lut, a.luts, tid, 256);
+    if (a.heavy) load_luts(s_lut, a.luts, tid, 256);
+    else compose_luts(a.chain, a.luts, s_lut, tid);
     if (SUMS && tid < 3) s_sum[tid] = 0;
     __syncthreads();
     const int gx = tid & 63, ry = tid >> 6;
     const int px = (blockIdx.x * 64 + gx) * 4;
     unsigned int acc[3] = {0, 0, 0};
     if (px < a.w) {
-        for (int k = 0; k < P_ROWS / 4; k++) {
-            const int y = blockIdx.y * P_ROWS + k * 4 + ry;
+        for (int k = 0; k < a.rows / 4; k++) {
+            const int y = blockIdx.y * a.rows + k * 4 + ry;
             if (y >= a.h) break;
             const uint8_t* row = src + (size_t)y * a.sstride + (size_t)px * 3;
             int b[4], g[4], r[4];
@@ -424,7 +478,7 @@ __global__ __launch_bounds__(256) void enh_point_kernel(const PointArgs a) {
                 for (int i = 0; i < 4; i++) apply_chain(a.chain, s_lut, a.pc, px + i, y, b[i], g[i], r[i]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) apply_luts(a.chain, s_lut, b[i], g[i], r[i]);
+                for (int i = 0; i < 4; i++) { b[i] = s_lut[b[i]]; g[i] = s_lut[256 + g[i]]; r[i] = s_lut[512 + r[i]]; }
             }
             if (SUMS) {
 #pragma unroll
@@ -732,7 +786,8 @@ int run_pass(PlanCtx& c, Pending& pd, uint8_t* out, size_t out_stride) {
         a.src = c.cur; a.dst = out; a.table = c.table; a.sstride = c.cur_stride; a.dstride = out_stride;
         a.w = c.w; a.h = c.h; a.luts = e->d_luts; a.chain = pd.pre; a.pc = c.pc; a.src_aligned = sal; a.dst_aligned = dal;
         a.heavy = pd.pre_heavy; a.sums = nullptr;
-        dim3 grid((c.w + 255) / 256, (c.h + P_ROWS - 1) / P_ROWS, c.table ? c.frames : 1);
+        a.rows = (c.table && c.frames >= 4) ? P_ROWS_LARGE : P_ROWS_SMALL;
+        dim3 grid((c.w + 255) / 256, (c.h + a.rows - 1) / a.rows, c.table ? c.frames : 1);
         hipLaunchKernelGGL(enh_point_kernel<false>, grid, dim3(256), 0, e->st, a);
     }
     E_HIP(e, hipGetLastError());
@@ -830,7 +885,8 @@ int stats_wb(PlanCtx& c, Pending& pd) {
     PointArgs a{};
     a.src = c.cur; a.dst = nullptr; a.table = nullptr; a.sstride = c.cur_stride; a.w = c.w; a.h = c.h; a.luts = e->d_luts;
     a.chain = pd.pre; a.pc = c.pc; a.src_aligned = aligned4(c.cur, c.cur_stride); a.heavy = pd.pre_heavy; a.sums = e->d_sums;
-    dim3 grid((c.w + 255) / 256, (c.h + P_ROWS - 1) / P_ROWS, 1);
+    a.rows = P_ROWS_LARGE;
+    dim3 grid((c.w + 255) / 256, (c.h + a.rows - 1) / a.rows, 1);
     hipLaunchKernelGGL(enh_point_kernel<true>, grid, dim3(256), 0, e->st, a);
     hipLaunchKernelGGL(enh_wb_lut_kernel, dim3(1), dim3(256), 0, e->st, e->d_sums, (unsigned long long)c.w * c.h, c.p->wb_strength,
                        e->d_luts + SLOT_WB * SLOT_BYTES);
