@@ -255,9 +255,19 @@ int vs_stab_set_batch(vs_stab* s, int frames);
  * must stay valid and unchanged until the result of the same push count has been produced
  * (clamp(smoothingRadius,5,35) further pushes plus twice the batch depth: the warps of a
  * batch are issued with the next one) and vs_stab_sync has returned, or the queue has been
- * drained with vs_stab_flush_dev.  Frames must be tightly packed.  The frame queue must be
+ * drained with vs_stab_flush_dev.  Rows may be padded (decoder pitch); all frames in flight
+ * share one pitch, which may change only while nothing is queued.  The frame queue must be
  * empty when the mode is switched. */
 int vs_stab_set_zero_copy(vs_stab* s, int enable);
+/* Decoder hand-off (the step in front of the path: the reference's capture strings end in
+ * `nvv4l2decoder ! nvvidconv ! BGR`, src/CamCap.cpp:49-52,66-72).  Hardware decoders export
+ * NV12 surfaces as a Y plane and an interleaved UV plane with a common pitch, the UV plane
+ * `uv_offset` bytes behind the Y pointer (rocDecode: pitch * aligned surface height; VA-API:
+ * offsets[1]) - not as one block of h*3/2 rows.  Sets that offset for the frames given to
+ * vs_stab_push_dev (`in`) and for the surfaces it fills (`out`); 0 = contiguous (h * pitch).
+ * With zero-copy input the stabilizer then reads decoder surfaces and writes encoder surfaces
+ * in place: no repacking blit on either side.  The frame queue must be empty. */
+int vs_stab_set_nv12_layout(vs_stab* s, size_t in_uv_offset, size_t out_uv_offset);
 
 /* Per-stage device timing with HIP events recorded on the instance stream
  * (SURVEY.md section 5 "Tracing").  mode 0 = off, 1 = warp stage only,

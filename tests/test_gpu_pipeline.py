@@ -384,6 +384,53 @@ def test_batch_mode_nv12(gpu, size, batch):
     s1.close(); s2.close()
 
 
+@pytest.mark.parametrize("mode", ["per_frame_copy", "per_frame_zero_copy", "batch_zero_copy"])
+def test_nv12_decoder_surfaces(gpu, mode):
+    """Decoder hand-off: NV12 surfaces with a padded pitch and the UV plane at
+    pitch * aligned_height behind the Y pointer (rocDecode / VA-API layout), read in place and written
+    into surfaces of another such layout: same planes as with packed frames, flush included."""
+    w, h, n = 322, 198, 40
+    clip = [synth.bgr_to_nv12(f) for f in synth.make_clip(synth.SEED_CONFIG3 + 9, w, h, n)]
+    in_pitch, in_rows = 512, 208                      # 256-byte pitch, height aligned to 16
+    out_pitch, out_rows = 384, 224
+    in_uv, out_uv = in_pitch * in_rows, out_pitch * out_rows
+    in_bytes, out_bytes = in_pitch * (in_rows + in_rows // 2), out_pitch * (out_rows + out_rows // 2)
+    p = gpu.params(smoothing_radius=6, max_corners=300)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    if mode == "batch_zero_copy":
+        s2.set_batch(8)
+    if mode != "per_frame_copy":
+        s2.set_zero_copy(True)
+    s2.set_nv12_layout(in_uv, out_uv)
+    fb = clip[0].nbytes
+    d_in, d_ref = capi.DevBuf(gpu, fb * n), capi.DevBuf(gpu, fb * n)
+    d_surf, d_got = capi.DevBuf(gpu, in_bytes * n), capi.DevBuf(gpu, out_bytes * n)
+    rng = np.random.default_rng(3)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+        surf = rng.integers(0, 256, (in_rows + in_rows // 2, in_pitch), dtype=np.uint8)   # padding holds garbage
+        surf[:h, :w] = f[:h]
+        surf[in_rows:in_rows + h // 2, :w] = f[h:]
+        d_surf.upload(surf, i * in_bytes)
+    d_got.zero()
+    k1 = k2 = 0
+    for i in range(n):
+        k1 += s1.push_dev(d_in.ptr + i * fb, w, h, w, capi.FMT_NV12, d_ref.ptr + k1 * fb, w)
+        k2 += s2.push_dev(d_surf.ptr + i * in_bytes, w, h, in_pitch, capi.FMT_NV12, d_got.ptr + k2 * out_bytes, out_pitch)
+    while s1.flush_dev(d_ref.ptr + k1 * fb, w):
+        k1 += 1
+    while s2.flush_dev(d_got.ptr + k2 * out_bytes, out_pitch):
+        k2 += 1
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n
+    ref = d_ref.download((n, h * 3 // 2, w), np.uint8)
+    got = d_got.download((n, out_rows + out_rows // 2, out_pitch), np.uint8)
+    assert np.array_equal(got[:, :h, :w], ref[:, :h])
+    assert np.array_equal(got[:, out_rows:out_rows + h // 2, :w], ref[:, h:])
+    assert not got[:, :h, w:].any() and not got[:, h:out_rows].any() and not got[:, out_rows + h // 2:].any()   # padding untouched
+    s1.close(); s2.close()
+
+
 def test_batch_mode_output_pitch_may_change(gpu):
     """A different output pitch closes the batch being collected (one pitch per batched warp launch)."""
     n = 30
@@ -443,10 +490,12 @@ def test_zero_copy_input_matches_queued_copy(gpu, batch):
     s1.sync(); s2.sync()
     assert k1 == k2 == n
     assert np.array_equal(d_ref.download((n, 240, 320, 3), np.uint8), d_got.download((n, 240, 320, 3), np.uint8))
-    with pytest.raises(capi.VsError):      # a padded stride cannot be read in place
-        s3 = gpu.stabilizer(p)
-        s3.set_zero_copy(True)
-        s3.push_dev(d_in.ptr, 316, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr, 316 * 3)
+    s3 = gpu.stabilizer(p)                 # padded rows are read in place too, but all queued frames share one pitch
+    s3.set_zero_copy(True)
+    s3.push_dev(d_in.ptr, 316, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr, 316 * 3)
+    with pytest.raises(capi.VsError):
+        s3.push_dev(d_in.ptr + fb, 316, 240, 316 * 3, capi.FMT_BGR8, d_got.ptr, 316 * 3)
+    s3.sync(); s3.close()
     s1.close(); s2.close()
 
 

@@ -103,6 +103,8 @@ struct vs_stab {
     bool allocated = false;
     int w = 0, h = 0, fmt = VS_FMT_BGR8, cn = 3;
     size_t row_bytes = 0, frame_bytes = 0;
+    size_t src_pitch = 0;               // row pitch of the frames the pipeline reads: row_bytes (queue ring) or the caller's (zero-copy)
+    size_t in_uv_off = 0, out_uv_off = 0;   // NV12 surfaces of the device entry points: UV plane offset, 0 = h * pitch
     int rows_total = 0;
     int aw = 960, ah = 540;
     int levels = 0;                 // max pyramid level actually used
@@ -327,6 +329,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->rows_total = fmt == VS_FMT_NV12 ? h * 3 / 2 : h;
     s->row_bytes = (size_t)w * s->cn;
     s->frame_bytes = s->row_bytes * s->rows_total;
+    s->src_pitch = s->row_bytes;
     analysis_size(s, w, h, &s->aw, &s->ah);
     if (s->aw < 3 || s->ah < 3) return fail(s, VS_ERR_INVALID_ARG, "analysis size too small");
     // buildOpticalFlowPyramid: levels that fit the window
@@ -476,12 +479,24 @@ int build_pyramid(vs_stab* s, int k, hipStream_t st) {
     return VS_OK;
 }
 
+// NV12: where the interleaved UV plane of a queued frame / of an output surface starts
+inline size_t src_uv(const vs_stab* s) { return (s->zero_copy && s->in_uv_off) ? s->in_uv_off : (size_t)s->h * s->src_pitch; }
+inline size_t dst_uv(const vs_stab* s, const uint8_t* d_out, size_t out_stride) {
+    return (d_out != s->d_out && s->out_uv_off) ? s->out_uv_off : (size_t)s->h * out_stride;   // s->d_out: staging of the host entry points
+}
+
 // `pre` stream, part 1: the frame enters the queue ring (waits until the slot's last reader is done)
 int enqueue_copy_in(vs_stab* s, int slot, const void* src, size_t stride, hipMemcpyKind kind) {
     if (s->slot_valid[slot]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_slot[slot], 0));
     StageScope t(s, VS_STAGE_COPY_IN, s->st_pre);
-    S_HIP(s, hipMemcpy2DAsync(s->d_ring + (size_t)slot * s->frame_bytes, s->row_bytes, src, stride, s->row_bytes,
-                              s->rows_total, kind, s->st_pre));
+    uint8_t* dst = s->d_ring + (size_t)slot * s->frame_bytes;
+    if (s->fmt == VS_FMT_NV12 && kind == hipMemcpyDeviceToDevice && s->in_uv_off) {      // decoder surface: planes apart
+        S_HIP(s, hipMemcpy2DAsync(dst, s->row_bytes, src, stride, s->row_bytes, s->h, kind, s->st_pre));
+        S_HIP(s, hipMemcpy2DAsync(dst + (size_t)s->h * s->row_bytes, s->row_bytes, (const uint8_t*)src + s->in_uv_off, stride,
+                                  s->row_bytes, s->h / 2, kind, s->st_pre));
+        return VS_OK;
+    }
+    S_HIP(s, hipMemcpy2DAsync(dst, s->row_bytes, src, stride, s->row_bytes, s->rows_total, kind, s->st_pre));
     return VS_OK;
 }
 
@@ -495,7 +510,7 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame, int f) {
     if (f - 3 >= 1 && s->det_valid[(f - 3) % EVR]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_det[(f - 3) % EVR], 0));
     {
         StageScope t(s, VS_STAGE_GRAY, s->st_pre);
-        S_TRY(s, launch_resize_gray(d_frame, s->row_bytes, s->w, s->h, s->fmt, s->pyr[c].img[0], s->aw, s->aw, s->ah, s->st_pre));  // :448-450
+        S_TRY(s, launch_resize_gray(d_frame, s->src_pitch, s->w, s->h, s->fmt, s->pyr[c].img[0], s->aw, s->aw, s->ah, s->st_pre));  // :448-450
     }
     S_HIP(s, hipEventRecord(s->ev_gray[c], s->st_pre));
     {
@@ -588,7 +603,7 @@ int flush_warps(vs_stab* s, bool on_main) {
     int rc;
     {
         StageScope t(s, VS_STAGE_WARP, ws);
-        rc = launch_warp_affine_list(srcs, dsts, n, s->row_bytes, s->w, s->h, s->pend_stride, s->w, s->h, s->cn,
+        rc = launch_warp_affine_list(srcs, dsts, n, s->src_pitch, s->w, s->h, s->pend_stride, s->w, s->h, s->cn,
                                      s->d_MinvB[set], 12, ws);
     }
     if (hipEventRecord(s->ev_warp[set], ws) == hipSuccess) s->warp_valid[set] = true;
@@ -633,17 +648,17 @@ int launch_ready(vs_stab* s) {
     for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes 16 frames per launch
         const int m = std::min(WARP_BATCH_MAX, R.n - i0);
         StageScope t(s, VS_STAGE_WARP, st);
-        rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->row_bytes, s->w, s->h, R.stride, s->w, s->h, s->cn,
+        rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->src_pitch, s->w, s->h, R.stride, s->w, s->h, s->cn,
                                      s->d_MinvB[R.set] + 12 * i0, 12, st);
         if (rc == VS_OK && s->fmt == VS_FMT_NV12) {
             // interleaved chroma plane: half size, two channels, the map with the halved translation
             const uint8_t* us[WARP_BATCH_MAX];
             uint8_t* ud[WARP_BATCH_MAX];
             for (int i = 0; i < m; i++) {
-                us[i] = R.srcs[i0 + i] + (size_t)s->h * s->row_bytes;
-                ud[i] = R.dsts[i0 + i] + (size_t)s->h * R.stride;
+                us[i] = R.srcs[i0 + i] + src_uv(s);
+                ud[i] = R.dsts[i0 + i] + dst_uv(s, R.dsts[i0 + i], R.stride);
             }
-            rc = launch_warp_affine_list(us, ud, m, s->row_bytes, s->w / 2, s->h / 2, R.stride, s->w / 2, s->h / 2, 2,
+            rc = launch_warp_affine_list(us, ud, m, s->src_pitch, s->w / 2, s->h / 2, R.stride, s->w / 2, s->h / 2, 2,
                                          s->d_MinvB[R.set] + 12 * i0 + 6, 12, st);
         }
     }
@@ -685,32 +700,34 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
         // flush): the queued frame is returned as is, at its own size (no border pad).
         if (ow != s->w || oh != s->h)
             S_HIP(s, hipMemset2DAsync(d_out, out_stride, 0, (size_t)ow * s->cn, oh, st));
-        S_HIP(s, hipMemcpy2DAsync(d_out, out_stride, frame, s->row_bytes, s->row_bytes, s->rows_total,
-                                  hipMemcpyDeviceToDevice, st));
+        S_HIP(s, hipMemcpy2DAsync(d_out, out_stride, frame, s->src_pitch, s->row_bytes, s->h, hipMemcpyDeviceToDevice, st));
+        if (s->fmt == VS_FMT_NV12)
+            S_HIP(s, hipMemcpy2DAsync(d_out + dst_uv(s, d_out, out_stride), out_stride, frame + src_uv(s), s->src_pitch, s->row_bytes,
+                                      s->h / 2, hipMemcpyDeviceToDevice, st));
         s->last_out_w = s->w; s->last_out_h = s->h;
     } else if (s->fmt == VS_FMT_NV12) {
         StageScope t(s, VS_STAGE_WARP, st);
-        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_Minv, 1, st);
+        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_Minv, 1, st);
         if (rc == VS_OK)
-            rc = launch_warp_affine(frame + (size_t)s->h * s->row_bytes, s->row_bytes, 0, s->w / 2, s->h / 2,
-                                    d_out + (size_t)s->h * out_stride, out_stride, 0, s->w / 2, s->h / 2, 2,
+            rc = launch_warp_affine(frame + src_uv(s), s->src_pitch, 0, s->w / 2, s->h / 2,
+                                    d_out + dst_uv(s, d_out, out_stride), out_stride, 0, s->w / 2, s->h / 2, 2,
                                     s->d_Minv + 6, 1, st);
     } else if (p.border_size > 0 && !p.crop_n_zoom) {                                 // :981-990
         const int b = p.border_size, bw = s->w + 2 * b, bh = s->h + 2 * b;
-        rc = launch_make_border(frame, s->row_bytes, s->w, s->h, s->cn, s->d_tmp, (size_t)bw * s->cn, b, p.border_type, st);
+        rc = launch_make_border(frame, s->src_pitch, s->w, s->h, s->cn, s->d_tmp, (size_t)bw * s->cn, b, p.border_type, st);
         StageScope t(s, VS_STAGE_WARP, st);
         if (rc == VS_OK)
             rc = launch_warp_affine(s->d_tmp, (size_t)bw * s->cn, 0, bw, bh, d_out, out_stride, 0, bw, bh, s->cn, s->d_Minv, 1, st);
     } else if (p.crop_n_zoom && p.border_size > 0 && s->w - 2 * p.border_size > 0 && s->h - 2 * p.border_size > 0) {  // :1108-1124
         const int b = p.border_size;
         StageScope t(s, VS_STAGE_WARP, st);
-        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, s->d_tmp, s->row_bytes, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
+        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, s->d_tmp, s->row_bytes, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
         if (rc == VS_OK)
             rc = launch_resize_linear(s->d_tmp + ((size_t)b * s->w + b) * s->cn, s->row_bytes, s->w - 2 * b, s->h - 2 * b,
                                       s->cn, d_out, out_stride, s->orig_w, s->orig_h, st);
     } else {                                                                          // :1056-1060
         StageScope t(s, VS_STAGE_WARP, st);
-        rc = launch_warp_affine(frame, s->row_bytes, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
+        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
     }
     // the slot may be overwritten once this warp has read it
     if (slot >= 0) {
@@ -805,7 +822,7 @@ int run_batch(vs_stab* s) {
         {
             StageScope t(s, VS_STAGE_GRAY, s->st_pre);
             // NV12: the Y plane is the gray image (no reference path; same policy as the per-frame pipeline)
-            S_TRY(s, launch_resize_gray_batch(s->d_pairs, n, s->row_bytes, s->w, s->h, s->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s->fmt,
+            S_TRY(s, launch_resize_gray_batch(s->d_pairs, n, s->src_pitch, s->w, s->h, s->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s->fmt,
                                               s->aw, s->aw, s->ah, aligned, s->st_pre));  // :448-450
         }
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
@@ -940,7 +957,7 @@ int push_common(vs_stab* s, int slot, const uint8_t* zc_frame, uint8_t* d_out, s
     s->counters.frames_in++;
     if (p.crop_n_zoom && s->orig_w == 0) { s->orig_w = s->w; s->orig_h = s->h; }   // :267-269
     if (s->first) {                                                                  // :271-368
-        S_TRY(s, launch_resize_gray(frame, s->row_bytes, s->w, s->h, s->fmt, s->d_first_gray, 480, 480, 270, s->st_pre));  // :304-305
+        S_TRY(s, launch_resize_gray(frame, s->src_pitch, s->w, s->h, s->fmt, s->d_first_gray, 480, 480, 270, s->st_pre));  // :304-305
         S_HIP(s, hipEventRecord(s->ev_first, s->st_pre));
         S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_first, 0));
         S_TRY(s, launch_gftt(s->d_first_gray, 480, 480, 270, p.max_corners, p.quality_level, p.min_distance,
@@ -1169,7 +1186,12 @@ int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride
     if (rc != VS_OK) return rc;
     if (s->zero_copy) {
         // the frame is read where it is: it must stay valid and unchanged until its own result has been produced
-        if (stride != s->row_bytes) return fail(s, VS_ERR_INVALID_ARG, "zero-copy mode: frames must be tightly packed (stride == width*channels)");
+        // one pitch for all frames in flight (the batched launches take it once): it may change when nothing is queued
+        if (stride != s->src_pitch) {
+            if (!s->q_slot.empty() || !s->bq.empty() || !s->pend.empty() || s->ready.valid)
+                return fail(s, VS_ERR_INVALID_ARG, "zero-copy mode: the row pitch may only change while no frame is queued");
+            s->src_pitch = stride;
+        }
         return push_common(s, -1, (const uint8_t*)d_data, (uint8_t*)d_out, out_stride, produced, true);
     }
     int slot;
@@ -1200,6 +1222,8 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
     if (!data) return VS_OK;
     int rc = prepare(s, w, h, fmt, stride);
     if (rc != VS_OK) return rc;
+    if (s->zero_copy && (s->src_pitch != s->row_bytes || (s->fmt == VS_FMT_NV12 && s->in_uv_off)))
+        return fail(s, VS_ERR_INVALID_ARG, "push: host frames cannot join a queue of pitched zero-copy surfaces");
     int slot;
     S_TRY(s, take_slot(s, &slot));
     S_TRY(s, enqueue_copy_in(s, slot, data, stride, hipMemcpyHostToDevice));
@@ -1269,6 +1293,17 @@ int vs_stab_set_zero_copy(vs_stab* s, int enable) {
     if (!s) return VS_ERR_INVALID_ARG;
     if (!s->q_slot.empty()) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_zero_copy: the frame queue must be empty");
     s->zero_copy = enable != 0;
+    s->src_pitch = s->row_bytes;
+    return VS_OK;
+}
+
+// NV12 surfaces of the device entry points as hardware decoders export them (rocDecode, VA-API): Y and interleaved
+// UV plane with a common pitch, the UV plane `uv_offset` bytes behind the Y pointer.  0 = contiguous (h * pitch).
+int vs_stab_set_nv12_layout(vs_stab* s, size_t in_uv_offset, size_t out_uv_offset) {
+    if (!s) return VS_ERR_INVALID_ARG;
+    if (!s->q_slot.empty()) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_nv12_layout: the frame queue must be empty");
+    s->in_uv_off = in_uv_offset;
+    s->out_uv_off = out_uv_offset;
     return VS_OK;
 }
 

@@ -166,6 +166,7 @@ class VsLib:
         L.vs_stab_set_warp_batch.argtypes = [vp, C.c_int]
         L.vs_stab_set_batch.argtypes = [vp, C.c_int]
         L.vs_stab_set_zero_copy.argtypes = [vp, C.c_int]
+        L.vs_stab_set_nv12_layout.argtypes = [vp, C.c_size_t, C.c_size_t]
         L.vs_stab_set_profiling.argtypes = [vp, C.c_int]
         L.vs_stab_get_stage_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.vs_dev_set_device.argtypes = [C.c_int]
@@ -685,6 +686,9 @@ class Stabilizer:
 
     def set_batch(self, frames):
         self.vs.check(self.lib.vs_stab_set_batch(self.h, int(frames)), self.h)
+
+    def set_nv12_layout(self, in_uv_offset=0, out_uv_offset=0):
+        self.vs.check(self.lib.vs_stab_set_nv12_layout(self.h, in_uv_offset, out_uv_offset), self.h)
 
     def set_zero_copy(self, on=True):
         self.vs.check(self.lib.vs_stab_set_zero_copy(self.h, int(on)), self.h)
