@@ -101,6 +101,9 @@ def main():
                     help="batch mode: analysis stages of this many consecutive pushes run as one launch each (1 = per-frame pipeline)")
     ap.add_argument("--warp-batch", type=int, default=8,
                     help="deferred output: results of this many consecutive pushes are warped by one launch (1 = one launch per push)")
+    ap.add_argument("--fanout", action="store_true",
+                    help="N > 1 only: rank 0 owns ingest - it generates the clips of ALL streams and scatters them to the "
+                         "owning ranks (RCCL send/recv over xGMI) before the timed region; timed separately, reported as `fanout`")
     args = ap.parse_args()
 
     comm = vsdist.Comm()           # nccl (= RCCL) when WORLD_SIZE > 1, nothing otherwise
@@ -121,14 +124,37 @@ def main():
     clips, d_in = [], []
     my_streams = vsdist.streams_of_rank(rank, n_gpus, S * n_gpus)
     assert len(my_streams) == S
-    for g in my_streams:
-        seed = synth.SEED_CONFIG2 + g
-        frames = synth.make_clip(seed, W, H, args.clip_frames)
-        clips.append(frames)
-        buf = capi.DevBuf(vs, fb * len(frames))
-        for i, f in enumerate(frames):
-            buf.upload(f, i * fb)
-        d_in.append(buf)
+    fanout = None
+    if args.fanout and world > 1:
+        # ingest on rank 0: the frame payloads travel to the owning GPUs with one scatter; the received
+        # device memory is what the stabilizers read (zero-copy), so the timed region is unchanged
+        import numpy as np
+        payloads = None
+        if rank == 0:
+            payloads = [np.concatenate([np.stack(synth.make_clip(synth.SEED_CONFIG2 + g, W, H, args.clip_frames)).reshape(-1)
+                                        for g in vsdist.streams_of_rank(r, n_gpus, S * n_gpus)]) for r in range(world)]
+        nbytes = fb * args.clip_frames * S
+        recv, secs = comm.fan_out(payloads, nbytes)
+
+        class _View:                      # same interface as DevBuf for the step loop; `recv` keeps the memory alive
+            def __init__(self, ptr):
+                self.ptr = ptr
+        for j in range(S):
+            d_in.append(_View(recv.data_ptr() + j * fb * args.clip_frames))
+        if rank == 0:
+            clips.append(list(payloads[0][:fb * args.clip_frames].reshape(args.clip_frames, H, W, 3)))
+        sent = nbytes * (world - 1)
+        fanout = {"bytes": sent, "ms": round(secs * 1e3, 3), "GBps": round(sent / secs / 1e9, 2) if secs > 0 else None,
+                  "what": "scatter of %d frames per stream from rank 0 to %d ranks (torch.distributed.scatter, RCCL)" % (args.clip_frames, world - 1)}
+    else:
+        for g in my_streams:
+            seed = synth.SEED_CONFIG2 + g
+            frames = synth.make_clip(seed, W, H, args.clip_frames)
+            clips.append(frames)
+            buf = capi.DevBuf(vs, fb * len(frames))
+            for i, f in enumerate(frames):
+                buf.upload(f, i * fb)
+            d_in.append(buf)
     BT = max(1, min(32, args.batch))
     WB = max(1, min(16, args.warp_batch if BT == 1 else BT))
     NOUT = max(2 * WB, 3 * BT)        # a result stays untouched until its batch and the next one have been issued
@@ -228,6 +254,8 @@ def main():
                          "frames_per_launch": round(frames_per_launch, 3),
                          "avg_launch_us": round(warp_avg_ms * 1e3, 3), "launches": stage_n[7]},
         }
+        if fanout is not None:
+            out["fanout"] = fanout
         if args.profile_stages:
             names = ["copy_in", "gray", "pyramid", "lk", "ransac", "traj", "gftt", "warp"]
             out["stage_us_per_launch"] = {names[k]: round(stage_ms[k] / max(stage_n[k], 1) * 1e3, 2) for k in range(8)}

@@ -17,8 +17,15 @@ WORKER = textwrap.dedent("""
     c.barrier()
     mx = c.max_over_ranks(1.0 + c.rank)             # elapsed of the slowest rank
     allc = c.gather_counters([c.rank, len(mine), 100.0 * (c.rank + 1)])
+    # frame fan-out from the ingest rank: rank r must receive exactly its own payload
+    import numpy as np
+    nbytes = 3 * 64 * 48 * 3
+    payloads = [np.full(nbytes, 10 + r, np.uint8) + (np.arange(nbytes) %% 7).astype(np.uint8) for r in range(c.world)] if c.rank == 0 else None
+    got, secs = c.fan_out(payloads, nbytes, src=0)
+    want = np.full(nbytes, 10 + c.rank, np.uint8) + (np.arange(nbytes) %% 7).astype(np.uint8)
+    ok = c.gather_counters([float(np.array_equal(got.cpu().numpy(), want)), float(secs >= 0)])
     if c.rank == 0:
-        print(json.dumps({"world": c.world, "max": mx, "gathered": allc, "mine": mine}))
+        print(json.dumps({"world": c.world, "max": mx, "gathered": allc, "mine": mine, "fanout_ok": ok}))
     c.close()
 """) % ROOT
 
@@ -37,6 +44,7 @@ def test_gloo_world2(tmp_path):
     assert out["world"] == 2 and out["max"] == 2.0
     assert out["gathered"] == [[0.0, 4.0, 100.0], [1.0, 3.0, 200.0]]
     assert out["mine"] == [0, 2, 4, 6]
+    assert out["fanout_ok"] == [[1.0, 1.0], [1.0, 1.0]]
 
 
 def test_sharding_is_a_partition():

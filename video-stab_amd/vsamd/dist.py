@@ -5,7 +5,10 @@ stream with NO data-path collective: global stream g lives on rank g % world
 (static).  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU
 hosts) is used only for the barrier around the timed region, the
 max-over-ranks of the elapsed time and the gather of the per-rank throughput
-counters.
+counters - and, when one rank owns ingest/decode (`fan_out`), for the scatter of
+the frame payloads to the ranks that own the streams: the one real exchange
+step of the batch-of-streams mode (point-to-point over xGMI, no reduction of
+image data anywhere).
 """
 import os
 
@@ -64,6 +67,30 @@ class Comm:
         out = [self.torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return [[float(x) for x in o.tolist()] for o in out]
+
+    def fan_out(self, payloads, nbytes, src=0):
+        """Scatter of frame payloads from the ingest rank: `payloads` (on `src` only) is a list with one
+        uint8 numpy array of `nbytes` bytes per rank (the frames of the streams that rank owns); every
+        rank gets its share as a uint8 tensor on its device (nccl) or in host memory (gloo).  Returns
+        (tensor, seconds): the time is bracketed by a barrier and device syncs on both sides.
+        Single process: the payload itself, 0 s."""
+        import time
+        if self.dist is None:
+            import numpy as np
+            return np.ascontiguousarray(payloads[0]).reshape(-1), 0.0
+        torch = self.torch
+        recv = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        chunks = None
+        if self.rank == src:
+            assert len(payloads) == self.world and all(p.nbytes == nbytes for p in payloads)
+            chunks = [torch.from_numpy(p.reshape(-1)).to(self.device) for p in payloads]   # staged on the ingest GPU first
+        self.device_sync()
+        self.dist.barrier()
+        t0 = time.perf_counter()
+        self.dist.scatter(recv, chunks, src=src)
+        self.device_sync()
+        self.dist.barrier()
+        return recv, time.perf_counter() - t0
 
     def close(self):
         if self.dist is not None:
