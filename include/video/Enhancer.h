@@ -24,7 +24,7 @@ public:
         bool enableClahe = false;           ///< CLAHE on L of Lab
         float claheClipLimit = 2.0f;
         int claheTileGridSize = 8;
-        bool enableDenoise = false;         ///< not available in this build: enhanceImage throws if set with strength > 0
+        bool enableDenoise = false;         ///< cv::fastNlMeansDenoisingColored(h = hColor = denoiseStrength, 7, 21)
         float denoiseStrength = 10.0f;
         float gamma = 1.0f;                 ///< applied when |gamma - 1| > 1e-3
         /// The reference runs its stages in a different ORDER in its CUDA branch (Enhancer.cpp:183-233)

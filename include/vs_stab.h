@@ -169,7 +169,7 @@ typedef struct vs_enh_params_c {
     int32_t enable_clahe;            /* 0                                      */
     float   clahe_clip_limit;        /* 2                                      */
     int32_t clahe_tile_grid_size;    /* 8   (1..16)                            */
-    int32_t enable_denoise;          /* 0   (VS_ERR_UNSUPPORTED if set with strength > 0) */
+    int32_t enable_denoise;          /* 0   fastNlMeansDenoisingColored(h, h, 7, 21) */
     float   denoise_strength;        /* 10                                     */
     float   gamma;                   /* 1                                      */
     int32_t use_cuda;                /* 0: stage order of the reference's CPU branch, 1: of its CUDA branch */
@@ -423,8 +423,8 @@ const char* vs_enh_last_error(const vs_enh* e);
  * BGR8 in, BGR8 out of the same size; synchronous.  Stage order: params->use_cuda = 0 the CPU
  * branch (:142-181: white balance, brightness/contrast, CLAHE, vibrance, unsharp, gamma),
  * 1 the CUDA branch (:183-233: brightness/contrast, unsharp, white balance, vibrance, CLAHE,
- * gamma); each stage computes what the CPU OpenCV primitive computes.  enable_denoise with
- * denoise_strength > 0 (:165-169) returns VS_ERR_UNSUPPORTED. */
+ * gamma; fastNlMeansDenoisingColored, :165-169, follows the unsharp mask in both); each stage
+ * computes what the CPU OpenCV primitive computes. */
 int vs_enh_apply(vs_enh* e, const vs_enh_params_c* params, const uint8_t* data, int w, int h,
                  size_t stride, uint8_t* out, size_t out_stride);
 /* Same with frames in HBM (d_out must not alias d_data); left in flight on the object's
@@ -432,7 +432,8 @@ int vs_enh_apply(vs_enh* e, const vs_enh_params_c* params, const uint8_t* data, 
 int vs_enh_apply_dev(vs_enh* e, const vs_enh_params_c* params, const void* d_data, int w, int h,
                      size_t stride, void* d_out, size_t out_stride);
 /* n frames of one geometry; one launch per pass over all frames when the stage list has no
- * per-frame statistic (no white balance / CLAHE), frame by frame otherwise. */
+ * per-frame statistic or multi-pass stage (no white balance / CLAHE / denoise), frame by
+ * frame otherwise. */
 int vs_enh_apply_batch_dev(vs_enh* e, const vs_enh_params_c* params, const void* const* d_frames,
                            void* const* d_outs, int n, int w, int h, size_t stride,
                            size_t out_stride);

@@ -152,7 +152,18 @@ void vso_add_weighted_u8(const uint8_t* a, double alpha, const uint8_t* b, doubl
 int  vso_clahe_u8(const uint8_t* src, int w, int h, size_t stride, double clip_limit, int tiles, uint8_t* dst,
                   size_t dstride, uint8_t* lut_out);
 int  vso_clahe_bgr(uint8_t* bgr, int w, int h, float clip_limit, int tiles);   /* :59-69 */
-/* enhanceImage (:138-239), BGR8; 0 ok, -1 bad argument, -2 stage not restated (denoise) */
+/* cvtColor COLOR_LBGR2Lab / COLOR_Lab2LBGR (linear RGB), as fastNlMeansDenoisingColored uses them */
+void vso_lbgr2lab(const uint8_t* src, size_t n, uint8_t* dst);
+void vso_lab2lbgr(const uint8_t* src, size_t n, uint8_t* dst);
+/* weight table of cv::fastNlMeansDenoising for 8-bit data (table may be NULL: returns the length);
+ * info2 = {bin shift, fixed-point multiplier} */
+int  vso_nlm_weights(float h, int cn, int template_size, int search_size, int32_t* table, int cap, int32_t* info2);
+/* cv::fastNlMeansDenoising(src, dst, h, template, search) for CV_8UC1 / CV_8UC2, brute force */
+int  vso_fast_nl_means(const uint8_t* src, int w, int h, size_t stride, int cn, float hp, int template_size,
+                       int search_size, uint8_t* dst, size_t dstride);
+/* cv::fastNlMeansDenoisingColored(img, img, h, hColor, 7, 21) (:165-169), in place on packed BGR */
+int  vso_denoise_colored(uint8_t* bgr, int w, int h, float hl, float hc);
+/* enhanceImage (:138-239), BGR8; 0 ok, -1 bad argument */
 int  vso_enhance(const uint8_t* src, int w, int h, size_t stride, const vs_enh_params_c* p, uint8_t* out,
                  size_t out_stride);
 

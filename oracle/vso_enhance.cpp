@@ -58,6 +58,8 @@ struct LabTabs {
     int ab2xz[kAbTabSize];            // abToXZ_b
     uint16_t inv_gamma[kInvGammaTabSize];  // sRGBInvGammaTab_b
     int inv[9];                       // Lab2RGBinteger coeffs for B,G,R destination order
+    uint16_t lin_gamma[256];          // linearGammaTab_b (COLOR_LBGR2Lab)
+    uint16_t lin_inv_gamma[kInvGammaTabSize];  // linearInvGammaTab_b (COLOR_Lab2LBGR)
 };
 
 const LabTabs& lab_tabs() {
@@ -107,7 +109,9 @@ const LabTabs& lab_tabs() {
             float x = (float)i / (float)(kInvGammaTabSize - 1);
             float g = x <= 0.0031308f ? x * 12.92f : 1.055f * powf(x, 1.f / 2.4f) - 0.055f;
             T.inv_gamma[i] = (uint16_t)rne(255.f * g);
+            T.lin_inv_gamma[i] = (uint16_t)(int)(255.f * x);          // cvTrunc
         }
+        for (int i = 0; i < 256; i++) T.lin_gamma[i] = (uint16_t)(i * (1 << kGammaShift));
         for (int i = 0; i < 3; i++) {   // column i of XYZ; rows ordered so that out0 = R, out1 = G, out2 = B
             T.inv[i + 0] = rne((double)(1 << kLabShift) * xyz2rgb[0 * 3 + i] * D65[i]);
             T.inv[i + 3] = rne((double)(1 << kLabShift) * xyz2rgb[1 * 3 + i] * D65[i]);
@@ -118,11 +122,12 @@ const LabTabs& lab_tabs() {
 }
 
 // RGB2Lab_b::operator() scalar body, one pixel
-inline void bgr2lab_px(const LabTabs& T, const uint8_t* s, uint8_t* d) {
+inline void bgr2lab_px(const LabTabs& T, const uint8_t* s, uint8_t* d, bool srgb = true) {
     const int Lscale = (116 * 255 + 50) / 100;
     const int Lshift = -((16 * 255 * (1 << kLabShift2) + 50) / 100);
     const int* C = T.fwd;
-    int B = T.gamma[s[0]], G = T.gamma[s[1]], R = T.gamma[s[2]];
+    const uint16_t* gt = srgb ? T.gamma : T.lin_gamma;
+    int B = gt[s[0]], G = gt[s[1]], R = gt[s[2]];
     int fX = T.cbrt_[descale(B * C[0] + G * C[1] + R * C[2], kLabShift)];
     int fY = T.cbrt_[descale(B * C[3] + G * C[4] + R * C[5], kLabShift)];
     int fZ = T.cbrt_[descale(B * C[6] + G * C[7] + R * C[8], kLabShift)];
@@ -133,7 +138,8 @@ inline void bgr2lab_px(const LabTabs& T, const uint8_t* s, uint8_t* d) {
 }
 
 // Lab2RGBinteger::process + Lab2RGB_b store, one pixel
-inline void lab2bgr_px(const LabTabs& T, const uint8_t* s, uint8_t* d) {
+inline void lab2bgr_px(const LabTabs& T, const uint8_t* s, uint8_t* d, bool srgb = true) {
+    const uint16_t* igt = srgb ? T.inv_gamma : T.lin_inv_gamma;
     const int LL = s[0], aa = s[1], bb = s[2];
     int y = T.l2yf[LL * 2], ify = T.l2yf[LL * 2 + 1];
     int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * kBase / 500;
@@ -148,7 +154,7 @@ inline void lab2bgr_px(const LabTabs& T, const uint8_t* s, uint8_t* d) {
     ro = std::max(0, std::min(kInvGammaTabSize - 1, ro));
     go = std::max(0, std::min(kInvGammaTabSize - 1, go));
     bo = std::max(0, std::min(kInvGammaTabSize - 1, bo));
-    d[0] = sat_u8(T.inv_gamma[bo]); d[1] = sat_u8(T.inv_gamma[go]); d[2] = sat_u8(T.inv_gamma[ro]);
+    d[0] = sat_u8(igt[bo]); d[1] = sat_u8(igt[go]); d[2] = sat_u8(igt[ro]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,9 +439,101 @@ int vso_clahe_bgr(uint8_t* bgr, int w, int h, float clip_limit, int tiles) {
     return 0;
 }
 
+// COLOR_LBGR2Lab / COLOR_Lab2LBGR (linear RGB, no sRGB curve): what fastNlMeansDenoisingColored converts with
+void vso_lbgr2lab(const uint8_t* src, size_t n, uint8_t* dst) {
+    const LabTabs& T = lab_tabs();
+    for (size_t i = 0; i < n; i++) bgr2lab_px(T, src + 3 * i, dst + 3 * i, false);
+}
+void vso_lab2lbgr(const uint8_t* src, size_t n, uint8_t* dst) {
+    const LabTabs& T = lab_tabs();
+    for (size_t i = 0; i < n; i++) lab2bgr_px(T, src + 3 * i, dst + 3 * i, false);
+}
+
+// almost_dist2weight_ of FastNlMeansDenoisingInvoker<.., DistSquared, int> (fast_nlmeans_denoising_invoker.hpp):
+// weights for (sum of squared differences over the template) >> shift.  Returns the table length.
+int vso_nlm_weights(float h, int cn, int template_size, int search_size, int32_t* table, int cap, int32_t* shift_out) {
+    const int tsq = template_size * template_size;
+    int shift = 0;
+    while ((1 << shift) < tsq) shift++;
+    const double mult = (double)(1 << shift) / tsq;                     // almost_dist2actual_dist_multiplier
+    const int max_dist = 255 * 255 * cn;
+    const int almost_max = (int)(max_dist / mult + 1);
+    const int max_est = search_size * search_size * 255;
+    const int fixed_point_mult = (int)std::min<long long>(2147483647LL / max_est, 2147483647LL);
+    if (shift_out) { shift_out[0] = shift; shift_out[1] = fixed_point_mult; }
+    if (table) {
+        for (int a = 0; a < almost_max && a < cap; a++) {
+            const double dist = a * mult;
+            double w = std::exp(-dist / (h * h * cn));                  // float h*h, then * channels
+            if (std::isnan(w)) w = 1.0;
+            int weight = rne(fixed_point_mult * w);
+            if (weight < 0.001 * fixed_point_mult) weight = 0;
+            table[a] = weight;
+        }
+    }
+    return almost_max;
+}
+
+// cv::fastNlMeansDenoising(src, dst, h, 7, 21) for CV_8UC(cn), cn = 1 or 2 (photo/src/denoising.cpp):
+// every pixel becomes the weighted mean of the pixels of its 21x21 search window, weights from the 7x7
+// patch distance.  Evaluated by brute force; OpenCV's sliding sums are exact integer arithmetic.
+int vso_fast_nl_means(const uint8_t* src, int w, int h, size_t stride, int cn, float hp, int template_size, int search_size,
+                      uint8_t* dst, size_t dstride) {
+    if (cn < 1 || cn > 2 || w <= 0 || h <= 0 || !(template_size & 1) || !(search_size & 1)) return -1;
+    const int th = template_size / 2, sh = search_size / 2, border = th + sh;
+    int32_t info[2];
+    const int n_tab = vso_nlm_weights(hp, cn, template_size, search_size, nullptr, 0, info);
+    std::vector<int32_t> tab(n_tab);
+    vso_nlm_weights(hp, cn, template_size, search_size, tab.data(), n_tab, info);
+    const int shift = info[0];
+    const int ew = w + 2 * border, eh = h + 2 * border;
+    std::vector<uint8_t> ext((size_t)ew * eh * cn);                    // copyMakeBorder(BORDER_DEFAULT)
+    for (int y = 0; y < eh; y++)
+        for (int x = 0; x < ew; x++)
+            for (int c = 0; c < cn; c++)
+                ext[((size_t)y * ew + x) * cn + c] = src[(size_t)reflect101(y - border, h) * stride + (size_t)reflect101(x - border, w) * cn + c];
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            long long est[2] = {0, 0};
+            long long wsum = 0;
+            for (int y = -sh; y <= sh; y++)
+                for (int x = -sh; x <= sh; x++) {
+                    int dist = 0;
+                    for (int ty = -th; ty <= th; ty++) {
+                        const uint8_t* a = &ext[((size_t)(border + i + ty) * ew + (border + j - th)) * cn];
+                        const uint8_t* b = &ext[((size_t)(border + i + y + ty) * ew + (border + j + x - th)) * cn];
+                        for (int k = 0; k < template_size * cn; k++) { const int d = (int)a[k] - (int)b[k]; dist += d * d; }
+                    }
+                    const int wgt = tab[dist >> shift];
+                    const uint8_t* p = &ext[((size_t)(border + i + y) * ew + (border + j + x)) * cn];
+                    for (int c = 0; c < cn; c++) est[c] += (long long)wgt * p[c];
+                    wsum += wgt;
+                }
+            for (int c = 0; c < cn; c++) {
+                const unsigned v = ((unsigned)est[c] + (unsigned)wsum / 2) / (unsigned)wsum;     // divByWeightsSum
+                dst[(size_t)i * dstride + (size_t)j * cn + c] = sat_u8((int)v);
+            }
+        }
+    return 0;
+}
+
+// cv::fastNlMeansDenoisingColored(img, img, h, hColor, 7, 21) (Enhancer.cpp:165-169), in place on packed BGR
+int vso_denoise_colored(uint8_t* bgr, int w, int h, float hl, float hc) {
+    const size_t n = (size_t)w * h;
+    std::vector<uint8_t> lab(n * 3), L(n), ab(n * 2), L2(n), ab2(n * 2);
+    vso_lbgr2lab(bgr, n, lab.data());
+    for (size_t i = 0; i < n; i++) { L[i] = lab[3 * i]; ab[2 * i] = lab[3 * i + 1]; ab[2 * i + 1] = lab[3 * i + 2]; }
+    if (vso_fast_nl_means(L.data(), w, h, w, 1, hl, 7, 21, L2.data(), w)) return -1;
+    if (vso_fast_nl_means(ab.data(), w, h, (size_t)w * 2, 2, hc, 7, 21, ab2.data(), (size_t)w * 2)) return -1;
+    for (size_t i = 0; i < n; i++) { lab[3 * i] = L2[i]; lab[3 * i + 1] = ab2[2 * i]; lab[3 * i + 2] = ab2[2 * i + 1]; }
+    vso_lab2lbgr(lab.data(), n, bgr);
+    return 0;
+}
+
+
 // Enhancer::enhanceImage (Enhancer.cpp:138-239) for a BGR8 frame.  use_cuda selects the stage ORDER of the
 // reference's CUDA branch (:183-233); the arithmetic of each stage is the CPU primitive in both cases.
-// Returns 0, -1 bad argument, -2 stage not restated (denoise).
+// Returns 0, -1 bad argument.
 int vso_enhance(const uint8_t* src, int w, int h, size_t stride, const vs_enh_params_c* p, uint8_t* out, size_t out_stride) {
     if (!src || !out || !p || w <= 0 || h <= 0) return -1;
     const size_t n = (size_t)w * h;
@@ -473,17 +571,19 @@ int vso_enhance(const uint8_t* src, int w, int h, size_t stride, const vs_enh_pa
     const bool do_unsharp = p->enable_unsharp && p->sharpness > 0.f;
     const bool do_denoise = p->enable_denoise && p->denoise_strength > 0.f;
     const bool do_gamma = std::fabs(p->gamma - 1.f) > 1e-3;
-    if (do_denoise) return -2;
+    auto denoise = [&]() -> int { return vso_denoise_colored(img.data(), w, h, p->denoise_strength, p->denoise_strength); };   // :165-169 / :108-114
     if (!p->use_cuda) {
         if (p->enable_white_balance) wb();
         cb();
         if (p->enable_clahe && vso_clahe_bgr(img.data(), w, h, p->clahe_clip_limit, p->clahe_tile_grid_size)) return -1;
         if (p->enable_vibrance) vso_vibrance(img.data(), n, p->vibrance_strength);
         if (do_unsharp && unsharp()) return -1;
+        if (do_denoise && denoise()) return -1;
         if (do_gamma) gamma();
     } else {
         cb();
         if (do_unsharp && unsharp()) return -1;
+        if (do_denoise && denoise()) return -1;
         if (p->enable_white_balance) wb();
         if (p->enable_vibrance) vso_vibrance(img.data(), n, p->vibrance_strength);
         if (p->enable_clahe && vso_clahe_bgr(img.data(), w, h, p->clahe_clip_limit, p->clahe_tile_grid_size)) return -1;

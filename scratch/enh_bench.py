@@ -12,7 +12,7 @@ frames = [scene(W, H, seed=s) for s in range(2)]
 ins = [capi.DevBuf.from_array(vs, frames[i % 2]) for i in range(NB)]
 outs = [capi.DevBuf(vs, W * H * 3) for _ in range(NB)]
 e = capi.Enhancer(vs)
-for name in ("shipped", "cb_only", "vibrance_only", "wb_only", "clahe_only", "unsharp_wide", "all_cpu_order", "all_cuda_order"):
+for name in ("shipped", "cb_only", "vibrance_only", "wb_only", "clahe_only", "unsharp_wide", "all_cpu_order", "all_cuda_order", "denoise_only"):
     p = capi.Enhancer.default_params(vs, **CONFIGS[name])
     def run(iters, batch):
         for _ in range(iters):
@@ -24,8 +24,9 @@ for name in ("shipped", "cb_only", "vibrance_only", "wb_only", "clahe_only", "un
         e.sync()
     res = []
     for batch in (0, 1):
-        run(3, batch)
-        t0 = time.perf_counter(); run(20, batch); dt = time.perf_counter() - t0
-        res.append(dt / (20 * NB) * 1e6)
+        run(1 if name.startswith('denoise') else 3, batch)
+        iters = 2 if name.startswith('denoise') else 20
+        t0 = time.perf_counter(); run(iters, batch); dt = time.perf_counter() - t0
+        res.append(dt / (iters * NB) * 1e6)
     print("%-16s %dx%d passes=%d  single %.1f us/frame  batch16 %.1f us/frame  (%.1f GB/s algorithmic at 6 B/px)" % (
         name, W, H, e.passes(), res[0], res[1], W * H * 6 / (res[1] * 1e-6) / 1e9), flush=True)

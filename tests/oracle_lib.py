@@ -390,6 +390,32 @@ class Oracle:
         assert rc == 0
         return (out, lut) if want_lut else out
 
+    def nlm_weights(self, h, cn, template=7, search=21):
+        info = np.zeros(2, np.int32)
+        self.lib.vso_nlm_weights.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, i32p]
+        n = self.lib.vso_nlm_weights(h, cn, template, search, None, 0, _p(info, i32p))
+        tab = np.zeros(n, np.int32)
+        self.lib.vso_nlm_weights(h, cn, template, search, tab.ctypes.data, n, _p(info, i32p))
+        return tab, int(info[0]), int(info[1])
+
+    def fast_nl_means(self, img, h, template=7, search=21):
+        img = np.ascontiguousarray(img, np.uint8)
+        hh, ww = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty_like(img)
+        self.lib.vso_fast_nl_means.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int, u8p, C.c_size_t]
+        rc = self.lib.vso_fast_nl_means(_p(img, u8p), ww, hh, ww * cn, cn, h, template, search, _p(out, u8p), ww * cn)
+        assert rc == 0
+        return out
+
+    def denoise_colored(self, img, h, hc):
+        img = np.ascontiguousarray(img, np.uint8).copy()
+        hh, ww = img.shape[:2]
+        self.lib.vso_denoise_colored.argtypes = [u8p, C.c_int, C.c_int, C.c_float, C.c_float]
+        rc = self.lib.vso_denoise_colored(_p(img, u8p), ww, hh, h, hc)
+        assert rc == 0
+        return img
+
     def enhance(self, frame, params):
         frame = np.ascontiguousarray(frame)
         h, w = frame.shape[:2]

@@ -284,12 +284,21 @@ def enhance_by_parts(oracle, img, p):
     def gamma(cur):
         return oracle.gamma_lut(p.gamma)[cur]
 
+    def denoise(cur):
+        lab = oracle.cvt_color("lbgr2lab", cur)
+        L = oracle.fast_nl_means(lab[:, 0].reshape(h, w), p.denoise_strength)
+        ab = oracle.fast_nl_means(np.ascontiguousarray(lab[:, 1:]).reshape(h, w, 2), p.denoise_strength)
+        return oracle.cvt_color("lab2lbgr", np.concatenate([L.reshape(-1, 1), ab.reshape(-1, 2)], 1))
+
     do_unsharp = p.enable_unsharp and p.sharpness > 0
     do_gamma = abs(p.gamma - 1.0) > 1e-3
+    do_denoise = p.enable_denoise and p.denoise_strength > 0
     if not p.use_cuda:
-        order = [(p.enable_white_balance, wb), (True, cb), (p.enable_clahe, clahe), (p.enable_vibrance, vib), (do_unsharp, unsharp), (do_gamma, gamma)]
+        order = [(p.enable_white_balance, wb), (True, cb), (p.enable_clahe, clahe), (p.enable_vibrance, vib), (do_unsharp, unsharp),
+                 (do_denoise, denoise), (do_gamma, gamma)]
     else:
-        order = [(True, cb), (do_unsharp, unsharp), (p.enable_white_balance, wb), (p.enable_vibrance, vib), (p.enable_clahe, clahe), (do_gamma, gamma)]
+        order = [(True, cb), (do_unsharp, unsharp), (do_denoise, denoise), (p.enable_white_balance, wb), (p.enable_vibrance, vib),
+                 (p.enable_clahe, clahe), (do_gamma, gamma)]
     for on, f in order:
         if on:
             cur = np.ascontiguousarray(f(cur))
@@ -314,13 +323,20 @@ CONFIGS = {
                            enable_unsharp=1, sharpness=1.0, blur_sigma=1.2, enable_clahe=1, gamma=0.9, use_cuda=1),
     "cuda_vib_after_unsharp": dict(contrast=0.9, enable_vibrance=1, enable_unsharp=1, sharpness=0.5, blur_sigma=0.8, use_cuda=1),
     "cuda_wb_after_unsharp": dict(enable_white_balance=1, enable_unsharp=1, sharpness=1.0, use_cuda=1),
+    "denoise_only": dict(enable_denoise=1, denoise_strength=10.0),
+    "denoise_strong": dict(enable_denoise=1, denoise_strength=25.0, gamma=1.1),
+    "denoise_after_unsharp": dict(contrast=1.1, enable_unsharp=1, sharpness=1.0, enable_denoise=1, denoise_strength=6.0, gamma=0.9),
+    "everything_cpu_order": dict(brightness=2.0, enable_white_balance=1, wb_strength=0.4, enable_clahe=1, enable_vibrance=1, vibrance_strength=0.1,
+                                 enable_unsharp=1, sharpness=0.7, enable_denoise=1, denoise_strength=8.0, gamma=1.1),
+    "everything_cuda_order": dict(brightness=2.0, enable_white_balance=1, wb_strength=0.4, enable_clahe=1, enable_vibrance=1, vibrance_strength=0.1,
+                                  enable_unsharp=1, sharpness=0.7, enable_denoise=1, denoise_strength=8.0, gamma=1.1, use_cuda=1),
 }
 
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_enhance_is_the_composition_of_its_stages(oracle, name):
     p = oracle.enh_params(**CONFIGS[name])
-    img = scene(75, 58, seed=3)
+    img = scene(75, 58, seed=3) if not p.enable_denoise else scene(41, 33, seed=3)
     assert (oracle.enhance(img, p) == enhance_by_parts(oracle, img, p)).all()
 
 
@@ -331,8 +347,77 @@ def test_enhance_defaults_and_denoise(oracle, vs):
     assert (a.contrast, a.wb_strength, a.blur_sigma, a.clahe_clip_limit, a.clahe_tile_grid_size, a.gamma) == (1.0, 1.0, 1.0, 2.0, 8, 1.0)
     img = scene(20, 12)
     assert (oracle.enhance(img, a) == img).all()                     # identity with the defaults
-    with pytest.raises(RuntimeError):                                # fastNlMeans is not restated
-        oracle.enhance(img, oracle.enh_params(enable_denoise=1))
+
+
+def nlm_numpy(plane, h, template=7, search=21):
+    """Independent statement of cv::fastNlMeansDenoising on 8-bit data: integral-image patch distances per
+    search offset, fixed-point weights, rounded weighted mean."""
+    img = plane if plane.ndim == 3 else plane[..., None]
+    H, W, cn = img.shape
+    t, s = template // 2, search // 2
+    b = t + s
+    ext = np.pad(img.astype(np.int64), ((b, b), (b, b), (0, 0)), mode="reflect")
+    shift = 6                                                         # 2^6 is the power of two next to 7*7
+    fpm = (2 ** 31 - 1) // (search * search * 255)
+    est = np.zeros((H, W, cn), np.int64)
+    wsum = np.zeros((H, W), np.int64)
+    centre = ext[s:s + H + 2 * t, s:s + W + 2 * t]
+    for dy in range(-s, s + 1):
+        for dx in range(-s, s + 1):
+            other = ext[s + dy:s + dy + H + 2 * t, s + dx:s + dx + W + 2 * t]
+            d2 = ((centre - other) ** 2).sum(2)
+            ii = np.pad(d2.cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+            dist = ii[template:, template:] - ii[:-template, template:] - ii[template:, :-template] + ii[:-template, :-template]
+            actual = (dist >> shift) * (2 ** shift / template ** 2)
+            wgt = np.rint(fpm * np.exp(-actual / (np.float32(h) * np.float32(h) * cn))).astype(np.int64)
+            wgt[wgt < 0.001 * fpm] = 0
+            pix = ext[b + dy:b + dy + H, b + dx:b + dx + W]
+            est += wgt[..., None] * pix
+            wsum += wgt
+    out = (est + (wsum // 2)[..., None]) // wsum[..., None]
+    return np.clip(out, 0, 255).astype(np.uint8).reshape(plane.shape)
+
+
+def test_nlm_weight_table(oracle):
+    tab, shift, fpm = oracle.nlm_weights(10.0, 1)
+    assert (shift, fpm, len(tab)) == (6, 19096, 255 * 255 * 49 // 64 + 1)     # INT_MAX / (21*21*255); 2^6 >= 49
+    assert tab[0] == fpm and (np.diff(tab) <= 0).all()
+    a = np.arange(len(tab))
+    want = np.rint(fpm * np.exp(-(a * 64 / 49) / 100.0))
+    want[want < 0.001 * fpm] = 0
+    assert (tab == want).all()
+    assert np.flatnonzero(tab)[-1] == int(np.floor(100 * np.log(1000 + 0.5 / 19.096) * 49 / 64)) or tab[528] == 0
+    tab2, _, _ = oracle.nlm_weights(10.0, 2)
+    assert len(tab2) == 2 * 255 * 255 * 49 // 64 + 1 and tab2[2] == int(np.rint(fpm * np.exp(-(2 * 64 / 49) / 200.0)))
+
+
+@pytest.mark.parametrize("w,h,cn,strength", [(40, 31, 1, 10.0), (33, 26, 2, 10.0), (9, 7, 1, 20.0), (25, 40, 2, 4.0)])
+def test_nlm_against_numpy(oracle, w, h, cn, strength):
+    rng = np.random.default_rng(w * h + cn)
+    base = scene(w, h, seed=5)[..., :cn].astype(np.float64)
+    img = np.clip(base + rng.normal(0, 6, base.shape), 0, 255).astype(np.uint8)
+    img = np.ascontiguousarray(img[..., 0] if cn == 1 else img)
+    assert (oracle.fast_nl_means(img, strength) == nlm_numpy(img, strength)).all()
+
+
+def test_nlm_properties(oracle):
+    flat = np.full((24, 30), 99, np.uint8)
+    assert (oracle.fast_nl_means(flat, 10.0) == 99).all()            # every weight equal: the mean of a constant
+    rng = np.random.default_rng(0)
+    clean = np.tile(np.linspace(50, 200, 64)[None, :], (48, 1))
+    noisy = np.clip(clean + rng.normal(0, 8, clean.shape), 0, 255).astype(np.uint8)
+    out = oracle.fast_nl_means(noisy, 10.0)
+    assert np.abs(out - clean).mean() < 0.4 * np.abs(noisy - clean).mean()
+    assert (oracle.fast_nl_means(noisy, 0.05) == noisy).all()        # tiny h: only the pixel itself keeps a weight
+
+
+def test_linear_lab_round_trip(oracle):
+    px = np.array([[0, 0, 0], [255, 255, 255], [128, 128, 128], [255, 0, 0], [0, 255, 0], [0, 0, 255]], np.uint8)
+    lab = oracle.cvt_color("lbgr2lab", px)
+    # no sRGB curve: mid-gray is L* = 116*cbrt(0.502)-16 = 76.1 -> 194; the primaries keep the chroma of the sRGB case
+    assert lab.tolist() == [[0, 128, 128], [255, 128, 128], [194, 128, 128], [82, 207, 20], [224, 42, 211], [136, 208, 195]]
+    back = oracle.cvt_color("lab2lbgr", lab).astype(int)
+    assert np.abs(back - px).max() <= 1
 
 
 # ------------------------------------------------------------------------------------------------
@@ -385,7 +470,7 @@ def test_gpu_enhance_pass_counts(oracle, enh):
     """The stage list is compiled into the fewest passes over the frame the dependencies allow."""
     img = scene(128, 96)
     want = {"shipped": 1, "cb_only": 1, "defaults": 1, "vibrance_only": 1, "wb_only": 2, "clahe_only": 2,
-            "all_cpu_order": 4, "all_cuda_order": 4, "cuda_vib_after_unsharp": 2}
+            "all_cpu_order": 4, "all_cuda_order": 4, "cuda_vib_after_unsharp": 2, "denoise_only": 6, "denoise_after_unsharp": 6}
     for name, n in want.items():
         enh.apply(img, oracle.enh_params(**CONFIGS[name]))
         assert enh.passes() == n, (name, enh.passes())
@@ -420,8 +505,6 @@ def test_gpu_enhance_device_entry_points(oracle, gpu, enh):
         for f, o in zip(frames, outs):
             got = o.download((h, pitch), np.uint8)[:, :w * 3].reshape(h, w, 3)
             assert (got == oracle.enhance(f, p)).all(), cfg
-    with pytest.raises(Exception):
-        enh.apply(frames[0], oracle.enh_params(enable_denoise=1))    # VS_ERR_UNSUPPORTED, not a silent skip
     with pytest.raises(Exception):
         enh.apply(frames[0], oracle.enh_params(enable_unsharp=1, sharpness=1.0, blur_sigma=9.0))   # 55 taps
 

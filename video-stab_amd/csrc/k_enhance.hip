@@ -46,6 +46,7 @@ struct EnhTables {
     uint16_t cbrt_[kCbrtTabSize];
     uint16_t l2yf[512];
     uint16_t inv_gamma[kInvGammaTabSize];
+    uint16_t lin_inv_gamma[kInvGammaTabSize];   // linearInvGammaTab_b (COLOR_Lab2LBGR)
     int32_t fwd[9], inv[9];
 };
 
@@ -108,10 +109,12 @@ __device__ __forceinline__ int bgr2L(const EnhTables* T, int b, int g, int r) {
     return clamp255(descale(Lscale * fY + Lshift, kLabShift2));
 }
 
+template <bool SRGB = true>
 __device__ __forceinline__ void bgr2lab_px(const EnhTables* T, int b, int g, int r, int& Lo, int& ao, int& bo) {
     const int Lscale = (116 * 255 + 50) / 100;
     const int Lshift = -((16 * 255 * (1 << kLabShift2) + 50) / 100);
-    const int B = T->gamma[b], G = T->gamma[g], R = T->gamma[r];
+    // COLOR_LBGR2Lab: linearGammaTab_b[i] = i << gamma_shift
+    const int B = SRGB ? T->gamma[b] : b << kGammaShift, G = SRGB ? T->gamma[g] : g << kGammaShift, R = SRGB ? T->gamma[r] : r << kGammaShift;
     const int fX = T->cbrt_[descale(B * T->fwd[0] + G * T->fwd[1] + R * T->fwd[2], kLabShift)];
     const int fY = T->cbrt_[descale(B * T->fwd[3] + G * T->fwd[4] + R * T->fwd[5], kLabShift)];
     const int fZ = T->cbrt_[descale(B * T->fwd[6] + G * T->fwd[7] + R * T->fwd[8], kLabShift)];
@@ -126,7 +129,9 @@ __device__ __forceinline__ int ab2xz(int i) {
     return i * i / kBase * i / kBase;
 }
 
+template <bool SRGB = true>
 __device__ __forceinline__ void lab2bgr_px(const EnhTables* T, int LL, int aa, int bb, int& bo, int& go, int& ro) {
+    const uint16_t* igt = SRGB ? T->inv_gamma : T->lin_inv_gamma;
     const int y = T->l2yf[LL * 2], ify = T->l2yf[LL * 2 + 1];
     const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * kBase / 500;
     const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * kBase / 200 + 1;
@@ -138,7 +143,7 @@ __device__ __forceinline__ void lab2bgr_px(const EnhTables* T, int LL, int aa, i
     r0 = max(0, min(kInvGammaTabSize - 1, r0));
     g0 = max(0, min(kInvGammaTabSize - 1, g0));
     b0 = max(0, min(kInvGammaTabSize - 1, b0));
-    bo = clamp255(T->inv_gamma[b0]); go = clamp255(T->inv_gamma[g0]); ro = clamp255(T->inv_gamma[r0]);
+    bo = clamp255(igt[b0]); go = clamp255(igt[g0]); ro = clamp255(igt[r0]);
 }
 
 // vibranceCPU, Enhancer.cpp:41-57
@@ -608,6 +613,146 @@ __global__ void enh_cvt_color_kernel(const EnhTables* T, const uint8_t* src, uin
     dst[3 * i] = (uint8_t)o0; dst[3 * i + 1] = (uint8_t)o1; dst[3 * i + 2] = (uint8_t)o2;
 }
 
+// ---- cv::fastNlMeansDenoisingColored (Enhancer.cpp:165-169) -------------------------------------------------------------
+// BGR -> Lab without the sRGB curve (COLOR_LBGR2Lab), L and (a,b) as separate planes (photo/src/denoising.cpp)
+__global__ void enh_split_lab_kernel(const EnhTables* T, const uint8_t* src, size_t stride, int w, int h, uint8_t* L, uint8_t* ab) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* p = src + (size_t)y * stride + (size_t)x * 3;
+    int l, a, b;
+    bgr2lab_px<false>(T, p[0], p[1], p[2], l, a, b);
+    const size_t i = (size_t)y * w + x;
+    L[i] = (uint8_t)l; ab[2 * i] = (uint8_t)a; ab[2 * i + 1] = (uint8_t)b;
+}
+__global__ void enh_merge_lab_kernel(const EnhTables* T, const uint8_t* L, const uint8_t* ab, int w, int h, uint8_t* dst, size_t dstride) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const size_t i = (size_t)y * w + x;
+    int b, g, r;
+    lab2bgr_px<false>(T, L[i], ab[2 * i], ab[2 * i + 1], b, g, r);
+    uint8_t* p = dst + (size_t)y * dstride + (size_t)x * 3;
+    p[0] = (uint8_t)b; p[1] = (uint8_t)g; p[2] = (uint8_t)r;
+}
+
+// cv::fastNlMeansDenoising(src, dst, h, 7, 21) on a CN-channel 8-bit plane (FastNlMeansDenoisingInvoker, DistSquared,
+// fixed-point weights).  One workgroup = 32x32 output pixels.  For each of the 21x21 search offsets the squared
+// differences of the two shifted copies of the staged tile are box-filtered 7x7 (rows, then columns, through LDS), which
+// gives the patch distance of every output pixel at that offset at once; every step is exact integer arithmetic, so the
+// result equals OpenCV's sliding-sum evaluation.
+constexpr int N_TW = 32, N_TH = 32, N_T = 3, N_S = 10, N_B = N_T + N_S;
+constexpr int N_SW = N_TW + 2 * N_B, N_SH = N_TH + 2 * N_B;      // staged tile: 58 x 58 pixels
+constexpr int N_DW = N_TW + 2 * N_T, N_DH = N_TH + 2 * N_T;      // squared differences: 38 x 38
+constexpr int N_DP = N_DW + 1;                                   // pitch of s_D
+constexpr int N_EL = (N_DW * N_DH + 255) / 256;                  // difference elements per thread
+constexpr int NLM_TAB_LDS = 4096;
+
+struct NlmArgs {
+    const uint8_t* src; uint8_t* dst;
+    size_t stride, dstride;
+    int32_t w, h;
+    const int32_t* wtab;       // almost_dist2weight_ (device), entries >= tabn are 0
+    int32_t tabn, shift;
+};
+
+template <int CN>
+__global__ __launch_bounds__(256) void nlm_kernel(const NlmArgs a) {
+    constexpr int PITCH = (N_SW * CN + 3) & ~3;
+    __shared__ uint8_t s_px[N_SH * PITCH];
+    __shared__ uint32_t s_D[N_DH * N_DP];
+    __shared__ uint32_t s_H[N_DH * N_TW];
+    __shared__ int32_t s_w[NLM_TAB_LDS];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * N_TW, y0 = blockIdx.y * N_TH;
+    for (int i = tid; i < NLM_TAB_LDS; i += 256) s_w[i] = i < a.tabn ? a.wtab[i] : 0;
+    for (int i = tid; i < N_SH * N_SW; i += 256) {                 // copyMakeBorder(BORDER_DEFAULT) on the fly
+        const int sy = i / N_SW, sx = i - sy * N_SW;
+        const uint8_t* p = a.src + (size_t)reflect101(y0 - N_B + sy, a.h) * a.stride + (size_t)reflect101(x0 - N_B + sx, a.w) * CN;
+#pragma unroll
+        for (int c = 0; c < CN; c++) s_px[sy * PITCH + sx * CN + c] = p[c];
+    }
+    // this thread's share of the difference image: LDS offset of the centre pixel, s_D offset (-1: none)
+    int e_px[N_EL], e_d[N_EL];
+#pragma unroll
+    for (int k = 0; k < N_EL; k++) {
+        const int e = tid + 256 * k;
+        const int ry = e / N_DW, rx = e - ry * N_DW;
+        e_px[k] = (ry + N_S) * PITCH + (rx + N_S) * CN;
+        e_d[k] = e < N_DW * N_DH ? ry * N_DP + rx : -1;
+    }
+    // row pass: item = (row of s_D, group of 4 outputs); column pass + accumulation: thread = (column, block of 4 rows)
+    const int cx = tid & 31, cy = (tid >> 5) * 4;
+    unsigned int est[4][CN], wsum[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        wsum[r] = 0;
+#pragma unroll
+        for (int c = 0; c < CN; c++) est[r][c] = 0;
+    }
+    __syncthreads();
+    for (int dy = -N_S; dy <= N_S; dy++) {
+        for (int dx = -N_S; dx <= N_S; dx++) {
+            const int sh_off = dy * PITCH + dx * CN;
+            // A: squared differences between the tile and its copy shifted by (dx, dy)
+#pragma unroll
+            for (int k = 0; k < N_EL; k++) {
+                if (e_d[k] >= 0) {
+                    unsigned int d2 = 0;
+#pragma unroll
+                    for (int c = 0; c < CN; c++) {
+                        const int d = (int)s_px[e_px[k] + c] - (int)s_px[e_px[k] + sh_off + c];
+                        d2 += (unsigned)(d * d);
+                    }
+                    s_D[e_d[k]] = d2;
+                }
+            }
+            __syncthreads();
+            // B: sums of 7 along x, four outputs per item with a sliding window
+            for (int it = tid; it < N_DH * (N_TW / 4); it += 256) {
+                const int ry = it >> 3, g4 = (it & 7) * 4;
+                const uint32_t* dr = &s_D[ry * N_DP + g4];
+                uint32_t v[10];
+#pragma unroll
+                for (int j = 0; j < 10; j++) v[j] = dr[j];
+                uint32_t s0 = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6];
+                const uint32_t s1 = s0 - v[0] + v[7], s2 = s1 - v[1] + v[8], s3 = s2 - v[2] + v[9];
+                uint32_t* hr = &s_H[ry * N_TW + g4];
+                hr[0] = s0; hr[1] = s1; hr[2] = s2; hr[3] = s3;
+            }
+            __syncthreads();
+            // C: sums of 7 along y -> patch distance -> weight -> weighted accumulation of the shifted pixel
+            {
+                uint32_t hv[10];
+#pragma unroll
+                for (int j = 0; j < 10; j++) hv[j] = s_H[(cy + j) * N_TW + cx];
+                uint32_t dist = hv[0] + hv[1] + hv[2] + hv[3] + hv[4] + hv[5] + hv[6];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (r > 0) dist = dist - hv[r - 1] + hv[r + 6];
+                    const uint32_t idx = dist >> a.shift;
+                    const int wgt = idx < (uint32_t)NLM_TAB_LDS ? s_w[idx] : (idx < (uint32_t)a.tabn ? a.wtab[idx] : 0);
+                    const uint8_t* p = &s_px[(cy + r + N_B + dy) * PITCH + (cx + N_B + dx) * CN];
+#pragma unroll
+                    for (int c = 0; c < CN; c++) est[r][c] += (unsigned)wgt * p[c];
+                    wsum[r] += (unsigned)wgt;
+                }
+            }
+            // the next A writes s_D while C may still read s_H: distinct buffers; the barrier after A orders C before the next B
+        }
+    }
+    const int x = x0 + cx;
+    if (x < a.w) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int y = y0 + cy + r;
+            if (y < a.h) {
+#pragma unroll
+                for (int c = 0; c < CN; c++)
+                    a.dst[(size_t)y * a.dstride + (size_t)x * CN + c] = (uint8_t)min((est[r][c] + wsum[r] / 2) / wsum[r], 255u);   // divByWeightsSum
+            }
+        }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 inline int h_rne(float v) { return (int)lrintf(v); }
 inline int h_rne(double v) { return (int)lrint(v); }
@@ -658,6 +803,7 @@ void build_tables(EnhTables& T) {
         const float x = (float)i / (float)(kInvGammaTabSize - 1);
         const float gm = x <= 0.0031308f ? x * 12.92f : 1.055f * powf(x, 1.f / 2.4f) - 0.055f;
         T.inv_gamma[i] = (uint16_t)h_rne(255.f * gm);
+        T.lin_inv_gamma[i] = (uint16_t)(int)(255.f * x);      // cvTrunc
     }
 }
 
@@ -730,7 +876,10 @@ struct vs_enh {
     unsigned long long* d_sums = nullptr;
     unsigned int* d_hist = nullptr;     // MAX_TILES^2 x 256
     uint8_t* d_clahe_lut = nullptr;     // MAX_TILES^2 x 256
-    uint8_t* d_tmp = nullptr;  size_t tmp_bytes = 0;
+    uint8_t* d_tmp[2] = {nullptr, nullptr};  size_t tmp_bytes[2] = {0, 0};   // intermediate frames (ping-pong)
+    uint8_t* d_planes = nullptr; size_t planes_bytes = 0;                    // denoise: L, ab, L', ab' planes
+    int32_t* d_nlm_tab[2] = {nullptr, nullptr}; int nlm_tabn[2] = {0, 0}; int nlm_cap[2] = {0, 0}; float nlm_h[2] = {NAN, NAN};
+    int nlm_shift = 6;
     uint8_t* d_in = nullptr;   uint8_t* d_out = nullptr; size_t io_bytes = 0;
     ImgPair* d_table = nullptr; int table_cap = 0;
     int passes = 0;                     // frame passes of the last apply (for tests / docs)
@@ -795,24 +944,29 @@ int run_pass(PlanCtx& c, Pending& pd, uint8_t* out, size_t out_stride) {
     return VS_OK;
 }
 
-int ensure_tmp(vs_enh* e, size_t bytes) {
-    if (e->tmp_bytes >= bytes) return VS_OK;
-    if (e->d_tmp) { E_HIP(e, hipStreamSynchronize(e->st)); (void)hipFree(e->d_tmp); e->d_tmp = nullptr; e->tmp_bytes = 0; }
-    E_HIP(e, hipMalloc((void**)&e->d_tmp, bytes));
-    e->tmp_bytes = bytes;
+// one of the two intermediate frames, the one the current data does not live in
+int other_tmp(PlanCtx& c, size_t bytes, int* which) {
+    vs_enh* e = c.e;
+    const int k = c.cur == e->d_tmp[0] ? 1 : 0;
+    if (e->tmp_bytes[k] < bytes) {
+        if (e->d_tmp[k]) { E_HIP(e, hipStreamSynchronize(e->st)); (void)hipFree(e->d_tmp[k]); e->d_tmp[k] = nullptr; e->tmp_bytes[k] = 0; }
+        E_HIP(e, hipMalloc((void**)&e->d_tmp[k], bytes));
+        e->tmp_bytes[k] = bytes;
+    }
+    *which = k;
     return VS_OK;
 }
 
-// materialise the pending stages into the scratch frame (single-frame mode only)
+// materialise the pending stages into an intermediate frame (single-frame mode only)
 int flush_mid(PlanCtx& c, Pending& pd) {
     if (c.table) E_FAIL(c.e, VS_ERR_UNSUPPORTED, "enhancer: this stage list needs an intermediate frame (single-frame entry point only)");
     const size_t pitch = ((size_t)c.w * 3 + 3) & ~(size_t)3;
-    int rc = ensure_tmp(c.e, pitch * c.h);
+    int k;
+    int rc = other_tmp(c, pitch * c.h, &k);
     if (rc != VS_OK) return rc;
-    if (c.cur == c.e->d_tmp) E_FAIL(c.e, VS_ERR_UNSUPPORTED, "enhancer: stage list needs more than one intermediate frame");
-    rc = run_pass(c, pd, c.e->d_tmp, pitch);
+    rc = run_pass(c, pd, c.e->d_tmp[k], pitch);
     if (rc != VS_OK) return rc;
-    c.cur = c.e->d_tmp; c.cur_stride = pitch;
+    c.cur = c.e->d_tmp[k]; c.cur_stride = pitch;
     pd = Pending{};
     return VS_OK;
 }
@@ -923,18 +1077,86 @@ int stats_clahe(PlanCtx& c, Pending& pd) {
     return VS_OK;
 }
 
-enum { ST_WB, ST_CB, ST_CLAHE, ST_VIB, ST_UNSHARP, ST_GAMMA };
+// almost_dist2weight_ of cv::fastNlMeansDenoising for 8-bit data (fast_nlmeans_denoising_invoker.hpp, DistSquared, int weights):
+// host libm exp in double like the reference; uploaded when h changes.  k = 0: L plane (1 channel), k = 1: ab plane (2).
+int refresh_nlm_table(vs_enh* e, int k, float h) {
+    if (e->nlm_h[k] == h && e->d_nlm_tab[k]) return VS_OK;
+    const int cn = k + 1, tsq = 49, search = 21;
+    int shift = 0;
+    while ((1 << shift) < tsq) shift++;
+    const double mult = (double)(1 << shift) / tsq;
+    const int almost_max = (int)(255 * 255 * cn / mult + 1);
+    const int fixed_point_mult = (int)(2147483647LL / (search * search * 255));
+    std::vector<int32_t> tab(almost_max);
+    int tabn = 0;
+    for (int a = 0; a < almost_max; a++) {
+        const double dist = a * mult;
+        double w = std::exp(-dist / (h * h * cn));
+        if (std::isnan(w)) w = 1.0;
+        int weight = (int)lrint(fixed_point_mult * w);
+        if (weight < 0.001 * fixed_point_mult) weight = 0;
+        tab[a] = weight;
+        if (weight) tabn = a + 1;
+    }
+    if (e->nlm_cap[k] < std::max(tabn, 1)) {
+        E_HIP(e, hipStreamSynchronize(e->st));
+        if (e->d_nlm_tab[k]) (void)hipFree(e->d_nlm_tab[k]);
+        e->d_nlm_tab[k] = nullptr; e->nlm_cap[k] = 0;
+        E_HIP(e, hipMalloc((void**)&e->d_nlm_tab[k], sizeof(int32_t) * std::max(tabn, 1)));
+        e->nlm_cap[k] = std::max(tabn, 1);
+    }
+    E_HIP(e, hipStreamSynchronize(e->st));       // kernels of an earlier call may still read the table
+    E_HIP(e, hipMemcpy(e->d_nlm_tab[k], tab.data(), sizeof(int32_t) * std::max(tabn, 1), hipMemcpyHostToDevice));
+    e->nlm_tabn[k] = tabn; e->nlm_h[k] = h; e->nlm_shift = shift;
+    return VS_OK;
+}
+
+// cv::fastNlMeansDenoisingColored(img, img, h, h, 7, 21), Enhancer.cpp:165-169: LBGR2Lab, NLM on L and on (a,b), Lab2LBGR
+int run_denoise(PlanCtx& c, Pending& pd) {
+    vs_enh* e = c.e;
+    int rc = VS_OK;
+    if (pd.pre.n > 0 || pd.unsharp) { rc = flush_mid(c, pd); if (rc != VS_OK) return rc; }
+    else if (c.table) E_FAIL(e, VS_ERR_UNSUPPORTED, "enhancer: denoise runs frame by frame");
+    const size_t n = (size_t)c.w * c.h;
+    if (e->planes_bytes < 6 * n) {
+        E_HIP(e, hipStreamSynchronize(e->st));
+        if (e->d_planes) (void)hipFree(e->d_planes);
+        e->d_planes = nullptr; e->planes_bytes = 0;
+        E_HIP(e, hipMalloc((void**)&e->d_planes, 6 * n));
+        e->planes_bytes = 6 * n;
+    }
+    uint8_t *L = e->d_planes, *ab = L + n, *L2 = ab + 2 * n, *ab2 = L2 + n;
+    if ((rc = refresh_nlm_table(e, 0, c.p->denoise_strength)) != VS_OK) return rc;
+    if ((rc = refresh_nlm_table(e, 1, c.p->denoise_strength)) != VS_OK) return rc;
+    const size_t pitch = ((size_t)c.w * 3 + 3) & ~(size_t)3;
+    int k;
+    if ((rc = other_tmp(c, pitch * c.h, &k)) != VS_OK) return rc;
+    const dim3 pgrid((c.w + 255) / 256, c.h), tgrid((c.w + N_TW - 1) / N_TW, (c.h + N_TH - 1) / N_TH);
+    hipLaunchKernelGGL(enh_split_lab_kernel, pgrid, dim3(256), 0, e->st, e->d_tabs, c.cur, c.cur_stride, c.w, c.h, L, ab);
+    NlmArgs a{};
+    a.w = c.w; a.h = c.h; a.shift = e->nlm_shift;
+    a.src = L; a.dst = L2; a.stride = a.dstride = (size_t)c.w; a.wtab = e->d_nlm_tab[0]; a.tabn = e->nlm_tabn[0];
+    hipLaunchKernelGGL(nlm_kernel<1>, tgrid, dim3(256), 0, e->st, a);
+    a.src = ab; a.dst = ab2; a.stride = a.dstride = (size_t)c.w * 2; a.wtab = e->d_nlm_tab[1]; a.tabn = e->nlm_tabn[1];
+    hipLaunchKernelGGL(nlm_kernel<2>, tgrid, dim3(256), 0, e->st, a);
+    hipLaunchKernelGGL(enh_merge_lab_kernel, pgrid, dim3(256), 0, e->st, e->d_tabs, L2, ab2, c.w, c.h, e->d_tmp[k], pitch);
+    E_HIP(e, hipGetLastError());
+    c.cur = e->d_tmp[k]; c.cur_stride = pitch;
+    e->passes += 4;
+    return VS_OK;
+}
+
+enum { ST_WB, ST_CB, ST_CLAHE, ST_VIB, ST_UNSHARP, ST_GAMMA, ST_DENOISE };
 
 // Enhancer::enhanceImage, :138-239.  Frames in HBM; everything is left in flight on e->st.
 int enh_run(vs_enh* e, const vs_enh_params_c* p, const uint8_t* d_src, size_t sstride, const ImgPair* table, int frames, int w, int h,
             uint8_t* d_dst, size_t dstride) {
-    if (p->enable_denoise && p->denoise_strength > 0.f)
-        E_FAIL(e, VS_ERR_UNSUPPORTED, "enhancer: fastNlMeansDenoisingColored (enable_denoise) is not implemented");
+    const bool do_denoise = p->enable_denoise && p->denoise_strength > 0.f;
     const bool do_unsharp = p->enable_unsharp && p->sharpness > 0.f;
     const bool do_gamma = std::fabs(p->gamma - 1.f) > 1e-3;
     if (p->enable_clahe && (p->clahe_tile_grid_size < 1 || p->clahe_tile_grid_size > MAX_TILES))
         E_FAIL(e, VS_ERR_UNSUPPORTED, "enhancer: clahe_tile_grid_size must be 1..16");
-    if (table && (p->enable_white_balance || p->enable_clahe))
+    if (table && (p->enable_white_balance || p->enable_clahe || do_denoise))
         E_FAIL(e, VS_ERR_UNSUPPORTED, "enhancer: batch entry point supports table stages, vibrance and unsharp only");
     int rc = refresh_luts(e, p);
     if (rc != VS_OK) return rc;
@@ -951,10 +1173,12 @@ int enh_run(vs_enh* e, const vs_enh_params_c* p, const uint8_t* d_src, size_t ss
         if (p->enable_clahe) stages[ns++] = ST_CLAHE;
         if (p->enable_vibrance) stages[ns++] = ST_VIB;
         if (do_unsharp) stages[ns++] = ST_UNSHARP;
+        if (do_denoise) stages[ns++] = ST_DENOISE;
         if (do_gamma) stages[ns++] = ST_GAMMA;
     } else {                                               // :183-233
         stages[ns++] = ST_CB;
         if (do_unsharp) stages[ns++] = ST_UNSHARP;
+        if (do_denoise) stages[ns++] = ST_DENOISE;
         if (p->enable_white_balance) stages[ns++] = ST_WB;
         if (p->enable_vibrance) stages[ns++] = ST_VIB;
         if (p->enable_clahe) stages[ns++] = ST_CLAHE;
@@ -967,6 +1191,7 @@ int enh_run(vs_enh* e, const vs_enh_params_c* p, const uint8_t* d_src, size_t ss
             case ST_CB: rc = add_point(c, pd, OP_LUT, SLOT_CB); break;
             case ST_GAMMA: rc = add_point(c, pd, OP_LUT, SLOT_GAMMA); break;
             case ST_VIB: rc = add_point(c, pd, OP_VIB, 0); break;
+            case ST_DENOISE: rc = run_denoise(c, pd); break;
             case ST_UNSHARP:
                 if (pd.unsharp || pd.pre_heavy) rc = flush_mid(c, pd);
                 if (rc == VS_OK) pd.unsharp = true;
@@ -1045,7 +1270,11 @@ void vs_enh_destroy(vs_enh* e) {
     if (e->d_sums) (void)hipFree(e->d_sums);
     if (e->d_hist) (void)hipFree(e->d_hist);
     if (e->d_clahe_lut) (void)hipFree(e->d_clahe_lut);
-    if (e->d_tmp) (void)hipFree(e->d_tmp);
+    for (int k = 0; k < 2; k++) {
+        if (e->d_tmp[k]) (void)hipFree(e->d_tmp[k]);
+        if (e->d_nlm_tab[k]) (void)hipFree(e->d_nlm_tab[k]);
+    }
+    if (e->d_planes) (void)hipFree(e->d_planes);
     if (e->d_in) (void)hipFree(e->d_in);
     if (e->d_out) (void)hipFree(e->d_out);
     if (e->d_table) (void)hipFree(e->d_table);
@@ -1082,7 +1311,7 @@ int vs_enh_apply_batch_dev(vs_enh* e, const vs_enh_params_c* p, const void* cons
         if (!d_frames[i] || !d_outs[i] || d_frames[i] == d_outs[i]) return VS_ERR_INVALID_ARG;
         al = al && ((uintptr_t)d_frames[i] & 3) == 0 && ((uintptr_t)d_outs[i] & 3) == 0;
     }
-    if (!al || p->enable_white_balance || p->enable_clahe) {      // per-frame statistics or odd alignment: frame by frame
+    if (!al || p->enable_white_balance || p->enable_clahe || (p->enable_denoise && p->denoise_strength > 0.f)) {      // per-frame statistics or odd alignment: frame by frame
         for (int i = 0; i < n; i++) {
             int rc = enh_run(e, p, (const uint8_t*)d_frames[i], stride, nullptr, 1, w, h, (uint8_t*)d_outs[i], out_stride);
             if (rc != VS_OK) return rc;
