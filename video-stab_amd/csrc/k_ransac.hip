@@ -389,6 +389,8 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     __shared__ int32_t l_info[TB][4];
     __shared__ int l_nprev[TB], l_hpg[TB], l_due[TB], l_oidx[TB];
     __shared__ float l_t3[TB][4];
+    __shared__ int l_ncnt[TB];                       // transforms appended after push i
+    __shared__ vs_debug_frame l_dbg_scratch[16];     // per wave: record of a release that is not the batch's last
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     TrajState* g_state = table[0].traj;
     vs_debug_frame* g_dbg = table[0].dbg;
@@ -417,24 +419,38 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(&l_dbg)[i] = reinterpret_cast<const uint32_t*>(g_dbg)[i];
     __syncthreads();
-    // phase 2, ordered, wave 0 alone (no workgroup barriers): append the measured transform of frame i, then
-    // smooth around the frame that push i releases -> its transform (dx, dy, da)
-    if (wave == 0) {
+    // phase 2a, ordered, one lane: append the measured transforms of all frames (Stabilizer.cpp:660-693), remembering how
+    // long the trajectory was after each push
+    if (tid == 0) {
         for (int i = 0; i < n; i++) {
-            if (lane == 0) traj_append_device(&l_state, l_tp, l_model[i], l_info[i], l_nprev[i], &l_dbg, l_hpg[i]);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (l_due[i]) traj_emit_lds_wave0(&l_state, l_tp, l_oidx[i], &l_dbg, l_t3[i]);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            traj_append_device(&l_state, l_tp, l_model[i], l_info[i], l_nprev[i], &l_dbg, l_hpg[i]);
+            l_ncnt[i] = l_state.n;
         }
+    }
+    int last_due = -1;
+    for (int i = 0; i < n; i++) if (l_due[i]) last_due = i;
+    __syncthreads();
+    // phase 2b: smooth around the frame that push i releases -> its transform (dx, dy, da).  The release of push i must
+    // see exactly the transforms appended up to push i (:380-389): it is given that length, and the later entries of the
+    // rings lie beyond everything it reads (ring of 256, at most 32 pushes ahead).  Box and Gaussian smoothing keep no
+    // state of their own, so the releases of a batch run on different waves; the Kalman recursion (:1416-1458) advances a
+    // filter state from release to release and stays on wave 0, in order.  The debug record keeps the last release.
+    if (l_tp.method == VS_SMOOTH_KALMAN) {
+        if (wave == 0) {
+            for (int i = 0; i < n; i++) {
+                if (l_due[i]) traj_emit_lds_wave0(&l_state, l_tp, l_oidx[i], l_ncnt[i], &l_dbg, l_t3[i]);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else {
+        for (int i = wave; i < n; i += nwaves)
+            if (l_due[i]) traj_emit_lds_wave0(&l_state, l_tp, l_oidx[i], l_ncnt[i], i == last_due ? &l_dbg : &l_dbg_scratch[wave], l_t3[i]);
     }
     __syncthreads();
     // phase 3: the matrices and inverse maps of all due outputs, one lane each (cosf / sinf / the double
     // inversions leave the ordered chain); the last due output also leaves its matrix in the debug record
     {
-        int last_due = -1;
-        for (int i = 0; i < n; i++) if (l_due[i]) last_due = i;
         if (tid < n && l_due[tid]) {
             float Mt[12];
             traj_matrix_lane(l_t3[tid], Mt, l_minv[tid], nullptr);

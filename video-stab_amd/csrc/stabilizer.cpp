@@ -200,7 +200,7 @@ struct vs_stab {
     std::vector<ImgPair> h_pairs;                    // (source, destination) of the batched gray / pyramid launches
     uint8_t *d_lk_table = nullptr, *d_rs_table = nullptr, *d_gf_table = nullptr, *d_tail_table = nullptr;
     ImgPair* d_pairs = nullptr;
-    hipEvent_t ev_bpre = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
+    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
     bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
     int last_det_batch = -1;
     // what the debug getters read (last analysed frame)
@@ -810,10 +810,16 @@ int run_batch(vs_stab* s) {
         // pair tables: [0] frame -> img[0]; [1..levels] img[l-1] -> img[l]; [levels+1 ..] img[l] -> der[l]
         const int L = s->levels;
         int aligned = 1;
+        // level-0 pairs: the frames that re-detect first, so that the detector can start after a first, smaller launch
+        int n_first = 0, n_rest = 0;
+        for (int i = 0; i < n; i++) n_first += s->bq[i].detect ? 1 : 0;
+        const int n_detect = n_first;
+        n_first = 0;
         for (int i = 0; i < n; i++) {
             const vs_stab::BFrame& b = s->bq[i];
             const Pyramid& P = s->pyr[b.c];
-            s->h_pairs[i] = ImgPair{b.frame, P.img[0]};
+            const int slot = b.detect ? n_first++ : n_detect + n_rest++;
+            s->h_pairs[slot] = ImgPair{b.frame, P.img[0]};
             if ((uintptr_t)b.frame % 8) aligned = 0;
             for (int l = 1; l <= L; l++) s->h_pairs[(size_t)l * n + i] = ImgPair{P.img[l - 1], P.img[l]};
             for (int l = 0; l <= L; l++) s->h_pairs[(size_t)(L + 1 + l) * n + i] = ImgPair{P.img[l], P.der[l]};
@@ -822,8 +828,12 @@ int run_batch(vs_stab* s) {
         {
             StageScope t(s, VS_STAGE_GRAY, s->st_pre);
             // NV12: the Y plane is the gray image (no reference path; same policy as the per-frame pipeline)
-            S_TRY(s, launch_resize_gray_batch(s->d_pairs, n, s->src_pitch, s->w, s->h, s->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s->fmt,
-                                              s->aw, s->aw, s->ah, aligned, s->st_pre));  // :448-450
+            const int gfmt = s->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s->fmt;
+            const int n_a = (n_detect > 0 && n_detect < n) ? n_detect : n;
+            S_TRY(s, launch_resize_gray_batch(s->d_pairs, n_a, s->src_pitch, s->w, s->h, gfmt, s->aw, s->aw, s->ah, aligned, s->st_pre));  // :448-450
+            S_HIP(s, hipEventRecord(s->ev_bgray, s->st_pre));  // the detector needs the analysis images of its frames only
+            if (n_a < n)
+                S_TRY(s, launch_resize_gray_batch(s->d_pairs + n_a, n - n_a, s->src_pitch, s->w, s->h, gfmt, s->aw, s->aw, s->ah, aligned, s->st_pre));
         }
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
         for (int l = 1; l <= L; l++)
@@ -845,7 +855,9 @@ int run_batch(vs_stab* s) {
     }
     s->last_detected = s->bq[n - 1].detect;
     if (ndet > 0) {
-        S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_bpre, 0));
+        // starts as soon as the analysis images exist, next to the pyramid levels of this batch and the tracking of the
+        // previous one (VS_STAB_DET_AFTER_PRE=1: after the whole pre stage, the schedule before this was measured)
+        S_HIP(s, hipStreamWaitEvent(s->st_det, std::getenv("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
         // keypoint buffers are recycled after B + 4 detections (two batches): the tracking of the batch before
         // the previous one must have read them (the GFTT scratch is only touched on this stream)
         if (k >= 2) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 2) % 4], 0));
@@ -860,12 +872,7 @@ int run_batch(vs_stab* s) {
     s->bdet_valid[k % 4] = ndet > 0;
     // ---- main: tracking and hypothesis scoring of all frames, one launch each
     hipStream_t st = s->st;
-    S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
-    if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
-    if (s->last_det_batch >= 0 && s->last_det_batch >= k - 1) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
-    // `main` has now waited for this batch's gray/pyramid/detection work: the warps of the PREVIOUS batch go out
-    // here, alone on the GPU, before this batch's tracking
-    S_TRY(s, launch_ready(s));
+    // argument tables first: their upload does not depend on this batch's images and then runs while `main` would wait
     int n_max = 0;
     for (int i = 0; i < n; i++) {
         const vs_stab::BFrame& b = s->bq[i];
@@ -885,6 +892,29 @@ int run_batch(vs_stab* s) {
     }
     S_HIP(s, hipMemcpyAsync(s->d_lk_table, s->h_lk.data(), lk_item_bytes() * n, hipMemcpyHostToDevice, st));
     S_HIP(s, hipMemcpyAsync(s->d_rs_table, s->h_rs.data(), ransac_item_bytes() * n, hipMemcpyHostToDevice, st));
+    // the tail's table as well (which outputs become due and where their maps go is known on the host)
+    S_TRY(s, flush_warps(s));                      // the list of pending warps starts empty
+    const int set = s->pend_set;
+    bool tail_any = false;
+    for (int i = 0; i < n; i++) tail_any |= s->bq[i].out_due;
+    for (int i = 0; i < n; i++) {
+        const vs_stab::BFrame& b = s->bq[i];
+        double* minv = nullptr;
+        if (b.out_due) {
+            if (!s->pend.empty() && s->pend_stride != b.out_stride) return fail(s, VS_ERR_INVALID_ARG, "batch mode: the output stride must not change within a batch");
+            minv = s->d_MinvB[set] + 12 * s->pend.size();
+            s->pend.push_back({b.out_frame, b.d_out, b.out_slot});
+            s->pend_stride = b.out_stride;
+        }
+        tail_fill_item(s->h_tail.data() + tail_item_bytes() * i, b.out_due ? 1 : 0, b.out_idx, minv);
+    }
+    S_HIP(s, hipMemcpyAsync(s->d_tail_table, s->h_tail.data(), tail_item_bytes() * n, hipMemcpyHostToDevice, st));
+    S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
+    if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
+    if (s->last_det_batch >= 0 && s->last_det_batch >= k - 1) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
+    // `main` has now waited for this batch's gray/pyramid/detection work: the warps of the PREVIOUS batch go out
+    // here, alone on the GPU, before this batch's tracking
+    S_TRY(s, launch_ready(s));
     {
         StageScope t(s, VS_STAGE_LK, st);
         S_TRY(s, launch_pyr_lk_batch(s->d_lk_table, n, n_max, p.lk_win_size, st));
@@ -897,27 +927,11 @@ int run_batch(vs_stab* s) {
     // ---- ordered tail, ONE launch: per frame in push order, selection + trajectory append (:644-693), then the
     // map of the output that has become due (applyNextSmoothTransform sees exactly the transforms appended so
     // far); all due warps of the batch then leave as one launch.
-    S_TRY(s, flush_warps(s));                      // the list of pending warps starts empty
     {
-        const int set = s->pend_set;
-        bool any = false;
-        for (int i = 0; i < n; i++) any |= s->bq[i].out_due;
-        if (any && s->warp_valid[set]) {           // the previous user of this set of maps must have read them
+        if (tail_any && s->warp_valid[set]) {      // the previous user of this set of maps must have read them
             S_HIP(s, hipStreamWaitEvent(st, s->ev_warp[set], 0));
             s->warp_valid[set] = false;
         }
-        for (int i = 0; i < n; i++) {
-            const vs_stab::BFrame& b = s->bq[i];
-            double* minv = nullptr;
-            if (b.out_due) {
-                if (!s->pend.empty() && s->pend_stride != b.out_stride) return fail(s, VS_ERR_INVALID_ARG, "batch mode: the output stride must not change within a batch");
-                minv = s->d_MinvB[set] + 12 * s->pend.size();
-                s->pend.push_back({b.out_frame, b.d_out, b.out_slot});
-                s->pend_stride = b.out_stride;
-            }
-            tail_fill_item(s->h_tail.data() + tail_item_bytes() * i, b.out_due ? 1 : 0, b.out_idx, minv);
-        }
-        S_HIP(s, hipMemcpyAsync(s->d_tail_table, s->h_tail.data(), tail_item_bytes() * n, hipMemcpyHostToDevice, st));
         {
             StageScope t(s, VS_STAGE_TRAJ, st);
             S_TRY(s, launch_ransac_tail_batch(s->d_rs_table, s->d_tail_table, n, s->d_M, st));
@@ -1027,7 +1041,7 @@ void destroy_events(vs_stab* s) {
     for (auto& e : s->ev_slot) kill(e);
     kill(s->ev_first);
     kill(s->ev_emit); kill(s->ev_warp[0]); kill(s->ev_warp[1]);
-    kill(s->ev_bpre);
+    kill(s->ev_bpre); kill(s->ev_bgray);
     for (auto& e : s->ev_bdet) kill(e);
     for (auto& e : s->ev_blk) kill(e);
 }
@@ -1042,6 +1056,7 @@ int create_events(vs_stab* s) {
     S_HIP(s, mk(s->ev_first));
     S_HIP(s, mk(s->ev_emit)); S_HIP(s, mk(s->ev_warp[0])); S_HIP(s, mk(s->ev_warp[1]));
     S_HIP(s, mk(s->ev_bpre));
+    S_HIP(s, mk(s->ev_bgray));
     for (auto& e : s->ev_bdet) S_HIP(s, mk(e));
     for (auto& e : s->ev_blk) S_HIP(s, mk(e));
     return VS_OK;

@@ -251,8 +251,8 @@ __device__ __forceinline__ void traj_intent_samples(const float (*l_tr)[3], int 
 }
 
 // The same for a trajectory state that already lives in LDS (batch tail): wave 0 only, no workgroup barrier.
-__device__ __forceinline__ void traj_emit_lds_wave0(TrajState* s, const TrajParams& p, int idx, vs_debug_frame* dbg, float* t3) {
-    const int n = s->n;
+// n: transforms appended when this output is released (the rings may already hold later ones).  Any full wave.
+__device__ __forceinline__ void traj_emit_lds_wave0(TrajState* s, const TrajParams& p, int idx, int n, vs_debug_frame* dbg, float* t3) {
     const int istart = idx - 15 > 0 ? idx - 15 : 0;
     float mg, dr;
     traj_intent_samples(s->transforms, idx, n, istart, mg, dr);
