@@ -112,7 +112,7 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
-    vs = capi.load()
+    vs = capi.load(os.environ.get("VS_LIB"))    # VS_LIB: another build of the library (A/B measurements)
     if vs.lib.vs_device_count() <= 0:
         raise SystemExit("bench.py: no GPU visible - libvideo-stab has no CPU fallback")
     vs.check(vs.lib.vs_dev_set_device(local_rank))

@@ -8,7 +8,8 @@
 // (coarse to fine), so the whole tracker is a single launch: points are
 // independent, levels of one point are sequential.  The win*win window is
 // spread over the lanes (ceil(win^2/64) pixels per lane, kept in registers as
-// int16 I / dIx / dIy); the 2x2 normal-equation sums (A11,A12,A22 and per
+// int16 I / dIx / dIy; every sample of the iteration comes from a search region staged in LDS, which
+// is staged again around the point if it walks out of it); the 2x2 normal-equation sums (A11,A12,A22 and per
 // iteration b1,b2) are exact int64 wave reductions, so the float solve that
 // follows is bit-identical to the oracle's.  Latency-bound gather kernel
 // (SURVEY.md 8a L1): images are <= 0.5 MB and stay in L2.
@@ -88,15 +89,6 @@ __device__ __forceinline__ Weights make_weights(float a, float b) {
     return w;
 }
 
-// bilinear image sample, REFLECT_101 padding (pyramid border), descaled by 9
-__device__ __forceinline__ int sample_img(const uint8_t* __restrict__ img, size_t stride, int w, int h,
-                                          int X, int Y, const Weights& wt) {
-    const int xa = reflect101(X, w), xb = reflect101(X + 1, w);
-    const uint8_t* r0 = img + (size_t)reflect101(Y, h) * stride;
-    const uint8_t* r1 = img + (size_t)reflect101(Y + 1, h) * stride;
-    return descale(r0[xa] * wt.w00 + r0[xb] * wt.w01 + r1[xa] * wt.w10 + r1[xb] * wt.w11, 9);
-}
-
 __device__ __forceinline__ short2 load_deriv(const int16_t* __restrict__ d, int w, int h, int x, int y) {
     if ((unsigned)x >= (unsigned)w || (unsigned)y >= (unsigned)h) return make_short2(0, 0);
     return *reinterpret_cast<const short2*>(d + ((size_t)y * w + x) * 2);
@@ -104,8 +96,8 @@ __device__ __forceinline__ short2 load_deriv(const int16_t* __restrict__ d, int 
 
 constexpr int LK_MARGIN = 6;                       // search region = window + 1 + 2*margin
 constexpr int LK_WIN_MAX = 31;
-constexpr int LK_PW_MAX = LK_WIN_MAX + 1;          // template patch side (bilinear needs +1)
-constexpr int LK_REG_MAX = LK_WIN_MAX + 1 + 2 * LK_MARGIN;
+
+
 
 // i / d and i % d for 0 <= i < 4096, 1 <= d <= 64 (exact: the float product is
 // off by < 1e-3 from the true quotient and we add 0.5/d of slack)
@@ -119,9 +111,14 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
     // Per level everything the wave will touch is staged into LDS with ONE round of
     // global loads: the template patch of the previous image, its derivative patch,
     // and the search region of the next image (pyramid padding already applied).
-    __shared__ uint8_t pI[LK_PW_MAX * LK_PW_MAX];
-    __shared__ short2 pD[LK_PW_MAX * LK_PW_MAX];
-    __shared__ uint8_t region[LK_REG_MAX * LK_REG_MAX];
+    // sized by the window class of the instantiation (NPX pixels per lane: windows up to 16 / 21 / 31): with the
+    // arrays of the largest class a 21x21 tracker held 7 KB, 22 waves fitted a CU and the 6400 points of a
+    // 32-frame batch took two rounds on 5632 slots; 3.6 KB leaves the wave limit (32 per CU) as the only one
+    constexpr int WM = NPX <= 4 ? 16 : (NPX <= 7 ? 21 : LK_WIN_MAX);
+    constexpr int PWM = WM + 1, RWM = WM + 1 + 2 * LK_MARGIN;
+    __shared__ uint8_t pI[PWM * PWM];
+    __shared__ short2 pD[PWM * PWM];
+    __shared__ uint8_t region[RWM * RWM];
     const int lane = threadIdx.x;
     int n = a.n;
     if (a.d_n) { int dn = *a.d_n; n = dn < n ? dn : n; }
@@ -130,18 +127,20 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
     const int PW = win + 1;
     const int RW = win + 1 + 2 * LK_MARGIN;
     const float inv_pw = 1.0f / (float)PW, inv_rw = 1.0f / (float)RW, inv_win = 1.0f / (float)win;
-    int poff[NPX], roff[NPX], ox[NPX], oy[NPX];
-    bool valid[NPX];
+    // per window pixel of this lane: offsets into the template patch (low half) and the search region (high half);
+    // kept packed, and the (x, y) of a pixel is recomputed where the rare out-of-region path needs it: the register
+    // budget decides how many points a SIMD tracks at once
+    uint32_t off[NPX];
 #pragma unroll
     for (int k = 0; k < NPX; k++) {
         const int p = lane + 64 * k;
-        valid[k] = p < area;
         int yy = 0, xx = 0;
-        if (valid[k]) divmod_small(p, win, inv_win, yy, xx);
-        ox[k] = xx; oy[k] = yy;
-        poff[k] = yy * PW + xx;
-        roff[k] = yy * RW + xx;
+        if (p < area) divmod_small(p, win, inv_win, yy, xx);
+        off[k] = (uint32_t)(yy * PW + xx) | ((uint32_t)(yy * RW + xx) << 16);
     }
+#define LK_VALID(k) (lane + 64 * (k) < area)
+#define LK_POFF(k) ((int)(off[k] & 0xFFFFu))
+#define LK_ROFF(k) ((int)(off[k] >> 16))
     // lane-strided walks over the PW x PW patch and the RW x RW region: start and step
     int p_y0, p_x0, p_sy, p_sx, r_y0, r_x0, r_sy, r_sx;
     divmod_small(lane, PW, inv_pw, p_y0, p_x0);
@@ -168,7 +167,7 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
             continue;
         }
         float cx = outx - halfWin, cy = outy - halfWin;
-        const int rx0 = f_floor(cx) - LK_MARGIN, ry0 = f_floor(cy) - LK_MARGIN;
+        int rx0 = f_floor(cx) - LK_MARGIN, ry0 = f_floor(cy) - LK_MARGIN;
         // ---- stage (all loads of the level are in flight together).  Lane-strided element
         // walk with incremental (row, col); patches that lie inside the image (the common
         // case) skip the border arithmetic.
@@ -189,7 +188,9 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
                 if (x >= PW) { x -= PW; y++; }
             }
         }
-        {
+        // the search region of the next image around (rx0, ry0); staged again, re-centred, if the point walks out
+        // of it (more than LK_MARGIN pixels at one level), so every sample of the iteration comes from LDS
+        auto stage_region = [&]() {
             const bool inside = rx0 >= 0 && ry0 >= 0 && rx0 + RW <= L.w && ry0 + RW <= L.h;
             int y = r_y0, x = r_x0;
             for (int i = lane; i < RW * RW; i += 64) {
@@ -199,7 +200,8 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
                 x += r_sx; y += r_sy;
                 if (x >= RW) { x -= RW; y++; }
             }
-        }
+        };
+        stage_region();
         __syncthreads();
         // ---- template window, its gradients and the 2x2 matrix
         Weights wt = make_weights(prevx - ipx, prevy - ipy);
@@ -208,7 +210,7 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
 #pragma unroll
         for (int k = 0; k < NPX; k++) {
             // invalid slots read offset 0 and are zeroed afterwards
-            const int o = poff[k];
+            const int o = LK_POFF(k);
             int ival = descale(__mul24((int)pI[o], wt.w00) + __mul24((int)pI[o + 1], wt.w01) +
                                __mul24((int)pI[o + PW], wt.w10) + __mul24((int)pI[o + PW + 1], wt.w11), 9);
             const short2 d00 = pD[o], d01 = pD[o + 1], d10 = pD[o + PW], d11 = pD[o + PW + 1];
@@ -216,7 +218,7 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
                                 __mul24((int)d10.x, wt.w10) + __mul24((int)d11.x, wt.w11), 14);
             int iyval = descale(__mul24((int)d00.y, wt.w00) + __mul24((int)d01.y, wt.w01) +
                                 __mul24((int)d10.y, wt.w10) + __mul24((int)d11.y, wt.w11), 14);
-            if (!valid[k]) { ival = 0; ixval = 0; iyval = 0; }
+            if (!LK_VALID(k)) { ival = 0; ixval = 0; iyval = 0; }
             Iw[k] = (short)ival; Ix[k] = (short)ixval; Iy[k] = (short)iyval;
             pA11 += __mul24(ixval, ixval);
             pA12 += __mul24(ixval, iyval);
@@ -240,31 +242,28 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
                 break;
             }
             wt = make_weights(cx - inx, cy - iny);
-            const int lx = inx - rx0, ly = iny - ry0;
-            const bool in_region = lx >= 0 && ly >= 0 && lx + win + 1 <= RW && ly + win + 1 <= RW;
+            int lx = inx - rx0, ly = iny - ry0;
+            if (!(lx >= 0 && ly >= 0 && lx + win + 1 <= RW && ly + win + 1 <= RW)) {    // wave-uniform
+                __syncthreads();
+                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                stage_region();
+                __syncthreads();
+                lx = LK_MARGIN; ly = LK_MARGIN;
+            }
             int pb1 = 0, pb2 = 0;
-            if (in_region) {
+            {
                 // every slot is computed unconditionally (invalid slots carry Ix = Iy = 0 and a
                 // safe offset), so the LDS reads of all pixels are in flight together
                 const int rbase = ly * RW + lx;
 #pragma unroll
                 for (int k = 0; k < NPX; k++) {
-                    const uint8_t* r0 = &region[rbase + roff[k]];
+                    const uint8_t* r0 = &region[rbase + LK_ROFF(k)];
                     // signed 24-bit multiplies: w11 = 2^14 - w00 - w01 - w10 can be -1
                     const int v = descale(__mul24((int)r0[0], wt.w00) + __mul24((int)r0[1], wt.w01) +
                                           __mul24((int)r0[RW], wt.w10) + __mul24((int)r0[RW + 1], wt.w11), 9);
                     const int diff = v - Iw[k];
                     pb1 += __mul24(diff, (int)Ix[k]);
                     pb2 += __mul24(diff, (int)Iy[k]);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < NPX; k++) {
-                    if (valid[k]) {
-                        const int diff = sample_img(L.next, L.stride, L.w, L.h, inx + ox[k], iny + oy[k], wt) - Iw[k];
-                        pb1 += diff * Ix[k];
-                        pb2 += diff * Iy[k];
-                    }
                 }
             }
             const long long sb1 = wave_sum(pb1), sb2 = wave_sum(pb2);
@@ -287,26 +286,24 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
                 status = 0;
             } else {
                 wt = make_weights(npx - inx, npy - iny);
-                const int lx = inx - rx0, ly = iny - ry0;
-                const bool in_region = lx >= 0 && ly >= 0 && lx + win + 1 <= RW && ly + win + 1 <= RW;
+                int lx = inx - rx0, ly = iny - ry0;
+                if (!(lx >= 0 && ly >= 0 && lx + win + 1 <= RW && ly + win + 1 <= RW)) {
+                    __syncthreads();
+                    rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                    stage_region();
+                    __syncthreads();
+                    lx = LK_MARGIN; ly = LK_MARGIN;
+                }
                 int es = 0;
-                if (in_region) {
+                {
                     const int rbase = ly * RW + lx;
 #pragma unroll
                     for (int k = 0; k < NPX; k++) {
-                        const uint8_t* r0 = &region[rbase + roff[k]];
+                        const uint8_t* r0 = &region[rbase + LK_ROFF(k)];
                         const int v = descale(__mul24((int)r0[0], wt.w00) + __mul24((int)r0[1], wt.w01) +
                                               __mul24((int)r0[RW], wt.w10) + __mul24((int)r0[RW + 1], wt.w11), 9);
                         const int diff = v - Iw[k];
-                        es += valid[k] ? (diff < 0 ? -diff : diff) : 0;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < NPX; k++) {
-                        if (valid[k]) {
-                            const int diff = sample_img(L.next, L.stride, L.w, L.h, inx + ox[k], iny + oy[k], wt) - Iw[k];
-                            es += diff < 0 ? -diff : diff;
-                        }
+                        es += LK_VALID(k) ? (diff < 0 ? -diff : diff) : 0;
                     }
                 }
                 const long long est = wave_sum(es);
@@ -314,6 +311,9 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
             }
         }
     }
+#undef LK_VALID
+#undef LK_POFF
+#undef LK_ROFF
     if (lane == 0) {
         a.next_pts[2 * pt] = outx;
         a.next_pts[2 * pt + 1] = outy;
