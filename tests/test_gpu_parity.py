@@ -159,6 +159,27 @@ def test_pyr_lk_exact(gpu, oracle, grays, win, levels, iters, eps):
     assert np.array_equal(eg.view(np.uint32), eo.view(np.uint32))
 
 
+@pytest.mark.parametrize("shift", [(23, 0), (-17, 29), (40, -35), (3, 60)])
+def test_pyr_lk_large_motion_restages_the_search_region(gpu, oracle, grays, shift):
+    """Motion of more than LK_MARGIN (6) pixels at a pyramid level: the tracker's search region is staged again
+    around the point (the oracle samples the image directly); points near the border take the reflected padding."""
+    g0 = grays[0]
+    dx, dy = shift
+    g1 = np.roll(np.roll(g0, dy, axis=0), dx, axis=1)               # wraps at the borders: some tracks fail, same on both sides
+    pts, _ = oracle.gftt(g0, 150, 0.02, 12.0, 3)
+    h, w = g0.shape
+    extra = np.array([[2.0, 3.0], [w - 3.0, h - 2.0], [w - 1.0, 5.5], [7.25, h - 1.0]], np.float32)
+    pts = np.vstack([pts, extra])
+    for win, levels in ((21, 2), (15, 3), (31, 1)):
+        no, so, eo = oracle.pyr_lk(g0, g1, pts, win, levels, 20, 0.03)
+        ng, sg, eg = gpu.pyr_lk(g0, g1, pts, win, levels, 20, 0.03)
+        assert np.array_equal(sg, so)
+        assert np.array_equal(ng.view(np.uint32), no.view(np.uint32))
+        assert np.array_equal(eg.view(np.uint32), eo.view(np.uint32))
+    moved = np.linalg.norm(no - pts, axis=1)[so.astype(bool)]
+    assert moved.size and np.median(moved) > 6                       # the case is what it claims to be
+
+
 # ---- R1 RANSAC ------------------------------------------------------------------------
 def _correspondences(seed, n, n_out, noise=0.2):
     rng = np.random.default_rng(seed)
