@@ -32,8 +32,6 @@ namespace {
 
 constexpr int TW = 64, TH = 16, NT = 256;
 constexpr int MAX_BS = 7;
-constexpr int GW_MAX = TW + MAX_BS - 1 + 2, GH_MAX = TH + MAX_BS - 1 + 2;
-constexpr int CW_MAX = TW + MAX_BS - 1, CH_MAX = TH + MAX_BS - 1;
 
 constexpr int SORT_CAP = 8192;
 constexpr int CELLS_MAX = 2560;
@@ -51,12 +49,16 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __uint_as_float(b);
 }
 
+// BS: block size known at compile time (loops unrolled, LDS arrays sized for it), 0: any block size up to MAX_BS
+template <int BS>
 __device__ __forceinline__ void min_eigen_tile(const uint8_t* __restrict__ gray, size_t stride, int w,
-                                               int h, int bs, float f1, float* __restrict__ eig,
+                                               int h, int bs_arg, float f1, float* __restrict__ eig,
                                                uint32_t* __restrict__ max_key) {
-    __shared__ uint8_t g[GH_MAX][GW_MAX + 2];
-    __shared__ float cxx[CH_MAX][CW_MAX + 1], cxy[CH_MAX][CW_MAX + 1], cyy[CH_MAX][CW_MAX + 1];
+    constexpr int BSM = BS ? BS : MAX_BS;
+    __shared__ uint8_t g[TH + BSM - 1 + 2][TW + BSM - 1 + 2 + 2];
+    __shared__ float cxx[TH + BSM - 1][TW + BSM - 1 + 1], cxy[TH + BSM - 1][TW + BSM - 1 + 1], cyy[TH + BSM - 1][TW + BSM - 1 + 1];
     __shared__ uint32_t smax[NT / 64];
+    const int bs = BS ? BS : bs_arg;
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int anchor = bs / 2, hi = bs - 1 - anchor;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void min_eigen_tile(const uint8_t* __restrict__ gray,
         const int x = x0 + tx, y = y0 + ty;
         if (x < w && y < h) {
             double s0 = 0, s1 = 0, s2 = 0;
-            for (int j = 0; j < bs; j++) {
+            for (int j = 0; j < bs; j++) {           // constant trip counts when BS != 0: unrolled
                 double r0 = 0, r1 = 0, r2 = 0;
                 for (int k = 0; k < bs; k++) {
                     r0 += (double)cxx[ty + j][tx + k];
@@ -128,10 +130,11 @@ __device__ __forceinline__ void min_eigen_tile(const uint8_t* __restrict__ gray,
     }
 }
 
+template <int BS>
 __global__ __launch_bounds__(NT) void min_eigen_kernel(const uint8_t* __restrict__ gray, size_t stride, int w,
                                                        int h, int bs, float f1, float* __restrict__ eig,
                                                        uint32_t* __restrict__ max_key) {
-    min_eigen_tile(gray, stride, w, h, bs, f1, eig, max_key);
+    min_eigen_tile<BS>(gray, stride, w, h, bs, f1, eig, max_key);
 }
 
 __device__ __forceinline__ void nms_row(const float* __restrict__ eig, int w, int h, double quality,
@@ -408,9 +411,10 @@ struct GfttItem {
 __global__ __launch_bounds__(64) void gftt_zero_batch_kernel(const GfttItem* __restrict__ table) {
     if (threadIdx.x < 16) table[blockIdx.x].counters[threadIdx.x] = 0;
 }
+template <int BS>
 __global__ __launch_bounds__(NT) void min_eigen_batch_kernel(const GfttItem* __restrict__ table) {
     const GfttItem& it = table[blockIdx.z];
-    min_eigen_tile(it.gray, it.stride, it.w, it.h, it.bs, it.f1, it.eig, (uint32_t*)&it.counters[1]);
+    min_eigen_tile<BS>(it.gray, it.stride, it.w, it.h, it.bs, it.f1, it.eig, (uint32_t*)&it.counters[1]);
 }
 __global__ __launch_bounds__(NT) void nms_batch_kernel(const GfttItem* __restrict__ table) {
     const GfttItem& it = table[blockIdx.z];
@@ -463,11 +467,14 @@ int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w,
 }
 
 // items images of one size (w x h), one launch per stage
-int launch_gftt_batch(const void* d_table, int items, int w, int h, hipStream_t st) {
-    if (!d_table || items < 1 || items > 65535 || w < 3 || h < 3) { set_last_error("gftt_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
+// block_size: the block size every item of the table was filled with
+int launch_gftt_batch(const void* d_table, int items, int w, int h, int block_size, hipStream_t st) {
+    if (!d_table || items < 1 || items > 65535 || w < 3 || h < 3 || block_size < 1 || block_size > MAX_BS) { set_last_error("gftt_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
     const GfttItem* t = static_cast<const GfttItem*>(d_table);
     hipLaunchKernelGGL(gftt_zero_batch_kernel, dim3(items), dim3(64), 0, st, t);
-    hipLaunchKernelGGL(min_eigen_batch_kernel, dim3((w + TW - 1) / TW, (h + TH - 1) / TH, items), dim3(NT), 0, st, t);
+    const dim3 eg((w + TW - 1) / TW, (h + TH - 1) / TH, items);
+    if (block_size == 3) hipLaunchKernelGGL(min_eigen_batch_kernel<3>, eg, dim3(NT), 0, st, t);
+    else hipLaunchKernelGGL(min_eigen_batch_kernel<0>, eg, dim3(NT), 0, st, t);
     hipLaunchKernelGGL(nms_batch_kernel, dim3((w + NT - 1) / NT, (h + NMS_ROWS - 1) / NMS_ROWS, items), dim3(NT), 0, st, t);
     hipLaunchKernelGGL(select_batch_kernel, dim3(items), dim3(SEL_NT), 0, st, t);
     VS_HIP_TRY(hipGetLastError());
@@ -500,8 +507,10 @@ int launch_gftt(const uint8_t* d_gray, size_t stride, int w, int h, int max_corn
     scale = 1.0 / scale;
     const float f1 = (float)scale;
     dim3 g1((w + TW - 1) / TW, (h + TH - 1) / TH);
-    hipLaunchKernelGGL(min_eigen_kernel, g1, dim3(NT), 0, st, d_gray, stride, w, h, block_size, f1, wk.eig,
-                       (uint32_t*)&wk.counters[1]);
+    if (block_size == 3)
+        hipLaunchKernelGGL(min_eigen_kernel<3>, g1, dim3(NT), 0, st, d_gray, stride, w, h, block_size, f1, wk.eig, (uint32_t*)&wk.counters[1]);
+    else
+        hipLaunchKernelGGL(min_eigen_kernel<0>, g1, dim3(NT), 0, st, d_gray, stride, w, h, block_size, f1, wk.eig, (uint32_t*)&wk.counters[1]);
     dim3 g2((w + NT - 1) / NT, (h + NMS_ROWS - 1) / NMS_ROWS);
     hipLaunchKernelGGL(nms_kernel, g2, dim3(NT), 0, st, wk.eig, w, h, quality, (const uint32_t*)&wk.counters[1],
                        (unsigned long long*)wk.cand, wk.cap, wk.counters);

@@ -64,7 +64,7 @@ int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items,
 size_t gftt_item_bytes();
 int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
                    double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
-int launch_gftt_batch(const void* d_table, int items, int w, int h, hipStream_t st);
+int launch_gftt_batch(const void* d_table, int items, int w, int h, int block_size, hipStream_t st);
 int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
                      hipStream_t st);
 int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st);
@@ -864,7 +864,7 @@ int run_batch(vs_stab* s) {
         S_HIP(s, hipMemcpyAsync(s->d_gf_table, s->h_gf.data(), gftt_item_bytes() * ndet, hipMemcpyHostToDevice, s->st_det));
         {
             StageScope t(s, VS_STAGE_GFTT, s->st_det);
-            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, s->st_det));
+            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det));   // :740-744: block size 3
         }
         S_HIP(s, hipEventRecord(s->ev_bdet[k % 4], s->st_det));
         s->last_det_batch = k;
