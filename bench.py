@@ -115,6 +115,8 @@ def main():
     vs = capi.load(os.environ.get("VS_LIB"))    # VS_LIB: another build of the library (A/B measurements)
     if vs.lib.vs_device_count() <= 0:
         raise SystemExit("bench.py: no GPU visible - libvideo-stab has no CPU fallback")
+    if os.environ.get("VS_BENCH_DEVICE"):          # rehearsal: several ranks on one GPU (with VS_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["VS_BENCH_DEVICE"])
     vs.check(vs.lib.vs_dev_set_device(local_rank))
 
     W, H = args.width, args.height
@@ -139,13 +141,19 @@ def main():
         class _View:                      # same interface as DevBuf for the step loop; `recv` keeps the memory alive
             def __init__(self, ptr):
                 self.ptr = ptr
+        if comm.device == "cuda":
+            base = recv.data_ptr()
+        else:                             # gloo rehearsal: the payload arrived in host memory
+            staged = capi.DevBuf.from_array(vs, recv.numpy())
+            base = staged.ptr
         for j in range(S):
-            d_in.append(_View(recv.data_ptr() + j * fb * args.clip_frames))
+            d_in.append(_View(base + j * fb * args.clip_frames))
         if rank == 0:
             clips.append(list(payloads[0][:fb * args.clip_frames].reshape(args.clip_frames, H, W, 3)))
         sent = nbytes * (world - 1)
         fanout = {"bytes": sent, "ms": round(secs * 1e3, 3), "GBps": round(sent / secs / 1e9, 2) if secs > 0 else None,
-                  "what": "scatter of %d frames per stream from rank 0 to %d ranks (torch.distributed.scatter, RCCL)" % (args.clip_frames, world - 1)}
+                  "what": "scatter of %d frames per stream from rank 0 to %d ranks (torch.distributed.scatter, %s)" % (
+                      args.clip_frames, world - 1, "RCCL" if comm.device == "cuda" else "gloo, host memory")}
     else:
         for g in my_streams:
             seed = synth.SEED_CONFIG2 + g

@@ -36,7 +36,8 @@ class Comm:
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # VS_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+                backend = os.environ.get("VS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = "cuda"
