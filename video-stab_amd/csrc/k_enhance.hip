@@ -1154,6 +1154,8 @@ int enh_run(vs_enh* e, const vs_enh_params_c* p, const uint8_t* d_src, size_t ss
     const bool do_denoise = p->enable_denoise && p->denoise_strength > 0.f;
     const bool do_unsharp = p->enable_unsharp && p->sharpness > 0.f;
     const bool do_gamma = std::fabs(p->gamma - 1.f) > 1e-3;
+    if ((unsigned long long)h * sstride >= (1ull << 32) || (unsigned long long)h * dstride >= (1ull << 32))
+        E_FAIL(e, VS_ERR_UNSUPPORTED, "enhancer: frames of 4 GiB and more are not supported (32-bit row offsets)");
     if (p->enable_clahe && (p->clahe_tile_grid_size < 1 || p->clahe_tile_grid_size > MAX_TILES))
         E_FAIL(e, VS_ERR_UNSUPPORTED, "enhancer: clahe_tile_grid_size must be 1..16");
     if (table && (p->enable_white_balance || p->enable_clahe || do_denoise))
