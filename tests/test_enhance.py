@@ -496,7 +496,7 @@ def test_gpu_enhance_device_entry_points(oracle, gpu, enh):
         padded[:, :w * 3] = f.reshape(h, w * 3)
         ins.append(DevBuf.from_array(gpu, padded))
         outs.append(DevBuf(gpu, h * pitch))
-    for cfg in ("shipped", "vibrance_only", "cuda_vib_after_unsharp", "wb_only"):
+    for cfg in ("shipped", "vibrance_only", "cuda_vib_after_unsharp", "wb_only", "denoise_after_unsharp"):
         p = oracle.enh_params(**CONFIGS[cfg])
         for o in outs:
             o.zero()

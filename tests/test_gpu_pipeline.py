@@ -499,6 +499,23 @@ def test_zero_copy_input_matches_queued_copy(gpu, batch):
     s1.close(); s2.close()
 
 
+def test_nv12_layout_and_zero_copy_switch_need_an_empty_queue(gpu):
+    w, h = 64, 48
+    f = synth.bgr_to_nv12(synth.make_clip(synth.SEED_CONFIG3, w, h, 1)[0])
+    d_in, d_out = capi.DevBuf.from_array(gpu, f), capi.DevBuf(gpu, f.nbytes)
+    s = gpu.stabilizer(gpu.params(smoothing_radius=5))
+    s.set_nv12_layout(0, 0)
+    s.push_dev(d_in.ptr, w, h, w, capi.FMT_NV12, d_out.ptr, w)
+    with pytest.raises(capi.VsError):
+        s.set_nv12_layout(w * 64, 0)          # a frame is queued
+    with pytest.raises(capi.VsError):
+        s.set_zero_copy(True)
+    while s.flush_dev(d_out.ptr, w):
+        pass
+    s.set_nv12_layout(w * 64, 0)              # queue drained: allowed again
+    s.sync(); s.close()
+
+
 def test_errors_are_loud(gpu):
     with pytest.raises(capi.VsError):
         gpu.stabilizer(gpu.params(enable_virtual_canvas=1))
