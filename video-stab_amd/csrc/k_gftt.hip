@@ -197,6 +197,48 @@ struct SelArgs {
     int32_t* out_count;
 };
 
+// In-place descending bitonic sort of keys[0 .. 256*E) by the 256 threads of the workgroup (thread t owns the keys
+// t + 256*r).  The network is the textbook one, so the result is the same as with one compare-exchange per pair.
+template <int E>
+__device__ __forceinline__ void bitonic_sort_desc(unsigned long long* keys, int tid) {
+    unsigned long long v[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) v[r] = keys[tid + SEL_NT * r];
+    const int n = SEL_NT * E;
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < 64) {
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const int i = tid + SEL_NT * r;
+                    const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)v[r], j, 64);
+                    const unsigned int hi = (unsigned int)__shfl_xor((int)(unsigned int)(v[r] >> 32), j, 64);
+                    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                    // the lower index of a pair keeps the larger key in a descending run, the upper one the smaller
+                    const bool keep_max = ((i & k) == 0) == ((i & j) == 0);
+                    v[r] = keep_max ? (v[r] > o ? v[r] : o) : (v[r] < o ? v[r] : o);
+                }
+            } else {
+                __syncthreads();                 // reads of the previous exchange through LDS are done
+#pragma unroll
+                for (int r = 0; r < E; r++) keys[tid + SEL_NT * r] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const int i = tid + SEL_NT * r;
+                    const unsigned long long o = keys[i ^ j];
+                    const bool keep_max = ((i & k) == 0) == ((i & j) == 0);
+                    v[r] = keep_max ? (v[r] > o ? v[r] : o) : (v[r] < o ? v[r] : o);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; r++) keys[tid + SEL_NT * r] = v[r];
+    __syncthreads();
+}
+
 __device__ __forceinline__ void select_corners(const SelArgs& a) {
     __shared__ unsigned long long keys[SORT_CAP];
     __shared__ uint32_t cell_cnt[CELLS_MAX];
@@ -261,23 +303,19 @@ __device__ __forceinline__ void select_corners(const SelArgs& a) {
         }
         __syncthreads();
         const int m = s_m < SORT_CAP ? s_m : SORT_CAP;
-        int np2 = 64;
+        int np2 = SEL_NT;                    // at least one key per thread
         while (np2 < m) np2 <<= 1;
         for (int i = m + tid; i < np2; i += SEL_NT) keys[i] = 0ull;
         __syncthreads();
-        // ---- bitonic sort, descending
-        for (int k = 2; k <= np2; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < np2; i += SEL_NT) {
-                    const int ixj = i ^ j;
-                    if (ixj > i) {
-                        const unsigned long long ki = keys[i], kj = keys[ixj];
-                        const bool desc = (i & k) == 0;
-                        if (desc ? (ki < kj) : (ki > kj)) { keys[i] = kj; keys[ixj] = ki; }
-                    }
-                }
-                __syncthreads();
-            }
+        // ---- bitonic sort, descending: every thread keeps its np2/256 keys in registers; exchanges at a distance below
+        // 64 stay inside the wave (shuffles, no barrier), the others go through LDS
+        switch (np2 / SEL_NT) {
+            case 1: bitonic_sort_desc<1>(keys, tid); break;
+            case 2: bitonic_sort_desc<2>(keys, tid); break;
+            case 4: bitonic_sort_desc<4>(keys, tid); break;
+            case 8: bitonic_sort_desc<8>(keys, tid); break;
+            case 16: bitonic_sort_desc<16>(keys, tid); break;
+            default: bitonic_sort_desc<32>(keys, tid); break;
         }
         // ---- decode the sorted keys in place: key -> (x | y<<16) | (xc | yc<<16) << 32
         // (integer divisions by w and by the cell size happen here, in parallel)
