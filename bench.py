@@ -164,7 +164,7 @@ def main():
                 buf.upload(f, i * fb)
             d_in.append(buf)
     BT = max(1, min(32, args.batch))
-    WB = max(1, min(16, args.warp_batch if BT == 1 else BT))
+    WB = max(1, min(32, args.warp_batch if BT == 1 else BT))
     NOUT = max(2 * WB, 3 * BT)        # a result stays untouched until its batch and the next one have been issued
     d_out = [[capi.DevBuf(vs, fb) for _ in range(NOUT)] for _ in range(S)]
     stabs = [vs.stabilizer(make_params(vs), device=local_rank) for _ in range(S)]

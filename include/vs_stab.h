@@ -233,7 +233,7 @@ void*       vs_stab_stream(vs_stab* s);    /* hipStream_t of the instance     */
  * DESIGN.md section 5); kept so that callers written against ABI 1 keep linking. */
 int vs_stab_enable_graph(vs_stab* s, int enable);
 /* Deferred output for vs_stab_push_dev / vs_stab_flush_dev (batch / file-to-file use): the
- * warps of up to `frames` (1..16) consecutive results are issued as ONE kernel launch, each
+ * warps of up to `frames` (1..32) consecutive results are issued as ONE kernel launch, each
  * result into the d_out its push named.  Results are complete after vs_stab_sync(); with
  * frames > 1 every push must be given its own d_out until then.  frames = 1 (default):
  * every push issues its own warp.  The host entry points (vs_stab_push / vs_stab_flush)

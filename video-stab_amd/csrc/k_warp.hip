@@ -36,7 +36,7 @@ constexpr int PX = 4;        // consecutive output pixels per lane
 constexpr int NT = 256;      // threads per workgroup
 constexpr int TXN = TW / PX; // 32 lanes along x
 constexpr int TYN = NT / TXN;// 8 lane-rows
-constexpr int MAXB = 16;     // matrices passed by value per launch
+constexpr int MAXB = 32;     // frames per launch (frame pointers and, for host matrices, the maps travel as kernel arguments)
 // fast path (near-identity maps): the source box of a tile is staged with a FIXED row pitch, so
 // the lower taps sit at an immediate offset and the tap address is one multiply-add
 constexpr int FPITCH = 136;  // staged row pitch in pixels (128 + tap + shear + 12-byte alignment slack)

@@ -77,7 +77,7 @@ constexpr int FRAME_RING = 128;     // <= 35 queued frames (clamp(smoothingRadiu
                                     // slot is reused several frames after the warp that released it
 constexpr int MAX_PYR = 8;
 constexpr int NPYR = 3;             // pyramid buffers: frame k writes k%3 while LK(k-1) still reads (k-1)%3,(k-2)%3
-constexpr int WARP_BATCH_MAX = 16;   // = the warp kernel's frames per launch (k_warp.hip MAXB)
+constexpr int WARP_BATCH_MAX = 32;   // = the warp kernel's frames per launch (k_warp.hip MAXB)
 constexpr int BATCH_MAX = 32;        // frames analysed per launch in batch mode (vs_stab_set_batch)
 constexpr int EVR = 4;              // per-frame event ring
 
@@ -645,7 +645,7 @@ int launch_ready(vs_stab* s) {
     if (!R.valid) return VS_OK;
     hipStream_t st = s->st;
     int rc = VS_OK;
-    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes 16 frames per launch
+    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes WARP_BATCH_MAX frames per launch
         const int m = std::min(WARP_BATCH_MAX, R.n - i0);
         StageScope t(s, VS_STAGE_WARP, st);
         rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->src_pitch, s->w, s->h, R.stride, s->w, s->h, s->cn,
