@@ -23,7 +23,7 @@
 // push, but the device work of `batch` consecutive frames is issued together - one
 // launch per stage over all frames (argument tables in device memory), one ordered
 // tail kernel (selection + trajectory append + smoothing, state in LDS), one warp
-// launch per 16 frames - see run_batch().  DESIGN.md section 5 has the schedule.
+// launch for the frames of a batch - see run_batch().  DESIGN.md section 5 has the schedule.
 #include <algorithm>
 #include <array>
 #include <cstring>
