@@ -390,6 +390,7 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     __shared__ int l_nprev[TB], l_hpg[TB], l_due[TB], l_oidx[TB];
     __shared__ float l_t3[TB][4];
     __shared__ int l_ncnt[TB];                       // transforms appended after push i
+    __shared__ float l_trf[TB][3];                   // measured (dx, dy, da) of frame i, decomposed by the frame's own wave
     __shared__ vs_debug_frame l_dbg_scratch[16];     // per wave: record of a release that is not the batch's last
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     TrajState* g_state = table[0].traj;
@@ -411,6 +412,15 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
         if (lane == 0) {
             l_nprev[f] = device_count(a); l_hpg[f] = a.have_prev_gray;
             l_due[f] = tail[f].out_due; l_oidx[f] = tail[f].out_idx;
+            // :644-662 for this frame (identity when the estimation failed or was skipped): the arctangent leaves the
+            // ordered chain below
+            float t3[3] = {0.f, 0.f, 0.f};
+            if (l_nprev[f] > 0 && a.have_prev_gray) {
+                float T[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+                if (a.info[0]) for (int i = 0; i < 6; i++) T[i] = (float)a.model[i];
+                t3[0] = T[2]; t3[1] = T[5]; t3[2] = atan2f(T[3], T[0]);
+            }
+            l_trf[f][0] = t3[0]; l_trf[f][1] = t3[1]; l_trf[f][2] = t3[2];
         }
     }
     __threadfence();
@@ -422,7 +432,28 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     // phase 2a, ordered, one lane: append the measured transforms of all frames (Stabilizer.cpp:660-693), remembering how
     // long the trajectory was after each push
     if (tid == 0) {
-        for (int i = 0; i < n; i++) {
+        const bool plain = !l_tp.drone && !l_tp.adaptive;   // no filter state between the measurement and the path
+        int i = 0;
+        if (plain) {
+            // path accumulation alone (:681-688), the running path kept in registers; the batch's last frame takes the
+            // full routine below, which also writes the debug record
+            int m = l_state.n;
+            float lp[3] = {l_state.last_path[0], l_state.last_path[1], l_state.last_path[2]};
+            for (; i < n - 1; i++) {
+                const int slot = m & (TRAJ_RING - 1);
+                for (int c = 0; c < 3; c++) {
+                    const float t = l_trf[i][c];
+                    lp[c] = m == 0 ? t : lp[c] + t;
+                    l_state.transforms[slot][c] = t;
+                    l_state.path[slot][c] = lp[c];
+                }
+                m++;
+                l_ncnt[i] = m;
+            }
+            l_state.n = m;
+            for (int c = 0; c < 3; c++) l_state.last_path[c] = lp[c];
+        }
+        for (; i < n; i++) {
             traj_append_device(&l_state, l_tp, l_model[i], l_info[i], l_nprev[i], &l_dbg, l_hpg[i]);
             l_ncnt[i] = l_state.n;
         }
