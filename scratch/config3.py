@@ -48,3 +48,18 @@ for _ in range(50):
 az.sync()
 t2 = time.perf_counter()
 print("4K BGR roll correction: %.2f ms/frame; auto zoom/crop: %.2f ms/frame (info %s)" % ((t1 - t0) / 50 * 1e3, (t2 - t1) / 50 * 1e3, az.info().tolist()))
+# the case the stage exists for: content rotated inside black borders (310-point contour, ~300 shrink rounds)
+yy, xx = np.mgrid[:H, :W]
+c, sn = np.cos(0.026), np.sin(0.026)
+u = c * (xx - W / 2) + sn * (yy - H / 2) + W / 2 - 40
+v = -sn * (xx - W / 2) + c * (yy - H / 2) + H / 2 + 25
+f2 = np.maximum(f, 8)
+f2[~((u >= 0) & (u < W) & (v >= 0) & (v < H))] = 0
+d_f2 = capi.DevBuf.from_array(vs, f2)
+for _ in range(5):
+    az.apply_dev(d_f2.ptr, W, H, W * 3, 3, d_z.ptr, W * 3); az.sync()
+t0 = time.perf_counter()
+for _ in range(50):
+    az.apply_dev(d_f2.ptr, W, H, W * 3, 3, d_z.ptr, W * 3)
+az.sync()
+print("4K BGR auto zoom/crop on rotated content: %.2f ms/frame (info %s)" % ((time.perf_counter() - t0) / 50 * 1e3, az.info().tolist()))

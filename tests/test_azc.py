@@ -198,6 +198,12 @@ def test_host_crop_logic_matches_oracle(oracle, vs):
     for _ in range(40):
         h, w = rng.integers(3, 60, 2)
         masks.append((rng.random((h, w)) < rng.random()).astype(np.uint8) * 255)
+    for w in (63, 64, 65, 128, 129, 200):                    # rows of several 64-pixel words, noise and blobs
+        masks.append((rng.random((40, w)) < 0.55).astype(np.uint8) * 255)
+        blobs = np.kron((rng.random((10, (w + 7) // 8)) < 0.6).astype(np.uint8), np.ones((6, 8), np.uint8))[:, :w] * 255
+        blobs[rng.random(blobs.shape) < 0.03] ^= 255
+        masks.append(blobs)
+    masks.append(np.full((5, 192), 255, np.uint8))
     for m in masks:
         ref = oracle.azc_crop_rect(m)
         got, filled = vs.azc_crop_from_mask(m, want_filled=True)

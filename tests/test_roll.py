@@ -112,7 +112,8 @@ def test_roll_params_default_match(oracle, vs):
 
 # ---------------------------------------------------------------- HIP parity (GPU)
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,seed", [((135, 240), 1), ((270, 480), 2), ((101, 67), 3), ((8, 8), 4)])
+@pytest.mark.parametrize("shape,seed", [((135, 240), 1), ((270, 480), 2), ((101, 67), 3), ((8, 8), 4),
+                                        ((200, 1100), 5), ((130, 1024), 6), ((63, 64), 7), ((62, 65), 8)])
 def test_canny_bit_exact(gpu, oracle, shape, seed):
     g = roll_scene.noisy_gray(shape[1], shape[0], seed)
     for lo, hi in ((50, 150), (10, 30), (150, 50)):
@@ -120,6 +121,29 @@ def test_canny_bit_exact(gpu, oracle, shape, seed):
         got = gpu.canny(g, lo, hi)
         assert np.array_equal(ref, got)
     assert shape[0] < 32 or oracle.canny(g, 10, 30).any()
+
+
+@pytest.mark.gpu
+def test_canny_hysteresis_follows_a_long_serpentine(gpu, oracle):
+    """One strong spot at the head of a weak serpentine bar: the growth has to cross the 62-row bands of the
+    hysteresis kernel a few dozen times (several groups of passes) and to run along rows and columns."""
+    h, w = 400, 300
+    g = np.full((h, w), 100, np.uint8)
+    xs = list(range(10, w - 20, 24))
+    for i, x in enumerate(xs):
+        g[20:h - 20, x:x + 6] = 112
+        if i + 1 < len(xs):
+            y = h - 26 if i % 2 == 0 else 20
+            g[y:y + 6, x:x + 30] = 112
+    g[20:26, 10:16] = 230
+    ref = oracle.canny(g, 20, 100)
+    assert ref[h // 2, xs[-1] - 1] or ref[h // 2, xs[-1]] or ref[h // 2, xs[-1] + 1]      # the far end is reached
+    assert np.array_equal(ref, gpu.canny(g, 20, 100))
+    weak_only = g.copy()
+    weak_only[20:26, 10:16] = 112
+    ref0 = oracle.canny(weak_only, 20, 100)
+    assert not ref0.any()
+    assert np.array_equal(ref0, gpu.canny(weak_only, 20, 100))
 
 
 @pytest.mark.gpu

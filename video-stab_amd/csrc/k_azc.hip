@@ -11,6 +11,7 @@
 //   device  warp_affine_kernel  : crop + scale to 640x360 (cv::warpAffine semantics, k_warp.hip)
 // Only the mask (w*h bytes) crosses PCIe between the two device stages; the frame stays in HBM.
 #include <algorithm>
+#include <climits>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -31,7 +32,8 @@ constexpr int W1 = TW + 4, H1 = TH + 4;         // dilated mask, halo 2
 // 5x5 MORPH_ELLIPSE: rows -1..1 are full, rows -2 and +2 hold the centre only
 template <int CN>
 __global__ __launch_bounds__(256) void content_mask_kernel(const uint8_t* __restrict__ src, size_t stride, int w, int h,
-                                                           uint8_t* __restrict__ mask, size_t mstride) {
+                                                           uint8_t* __restrict__ mask, size_t mstride,
+                                                           unsigned long long* __restrict__ bits, int bpitch) {
     __shared__ uint8_t m0[H0][W0 + 4];
     __shared__ uint8_t m1[H1][W1 + 4];
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
@@ -64,27 +66,35 @@ __global__ __launch_bounds__(256) void content_mask_kernel(const uint8_t* __rest
         m1[ly][lx] = v;
     }
     __syncthreads();
-    for (int i = tid; i < TW * TH; i += 256) {   // erode
+    for (int i = tid; i < TW * TH; i += 256) {   // erode; a wave is one row of the tile (TW = 64)
         const int ly = i / TW, lx = i - ly * TW;
         const int x = x0 + lx, y = y0 + ly;
-        if (x >= w || y >= h) continue;
+        const bool in = x < w && y < h;
         const int cy = ly + 2, cx = lx + 2;
         uint8_t v = m1[cy - 2][cx] & m1[cy + 2][cx];
 #pragma unroll
         for (int ky = -1; ky <= 1; ky++)
 #pragma unroll
             for (int kx = -2; kx <= 2; kx++) v &= m1[cy + ky][cx + kx];
-        mask[(size_t)y * mstride + x] = v ? 255 : 0;
+        if (bits) {                              // BitFrame layout (host side below): 64 pixels per word
+            const unsigned long long word = __ballot(in && v);
+            if (lx == 0 && in) bits[(size_t)(y + 1) * bpitch + (x0 >> 6) + 1] = word;
+        } else if (in) {
+            mask[(size_t)y * mstride + x] = v ? 255 : 0;
+        }
     }
 }
 
+static_assert(TW == 64, "one wave per tile row");
+
+// Either d_mask (0 / 255 bytes) or d_bits (a zero-framed BitFrame of pitch bpitch words) receives the result.
 int launch_content_mask(const uint8_t* d_src, size_t stride, int w, int h, int cn, uint8_t* d_mask, size_t mstride,
-                        hipStream_t st) {
-    if (!d_src || !d_mask || w <= 0 || h <= 0 || (cn != 1 && cn != 3)) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
+                        unsigned long long* d_bits, int bpitch, hipStream_t st) {
+    if (!d_src || (!d_mask && !d_bits) || w <= 0 || h <= 0 || (cn != 1 && cn != 3)) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
     dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH);
     if (grid.y > 65535) { set_last_error("content_mask: image too tall"); return VS_ERR_INVALID_ARG; }
-    if (cn == 3) hipLaunchKernelGGL(content_mask_kernel<3>, grid, dim3(256), 0, st, d_src, stride, w, h, d_mask, mstride);
-    else hipLaunchKernelGGL(content_mask_kernel<1>, grid, dim3(256), 0, st, d_src, stride, w, h, d_mask, mstride);
+    if (cn == 3) hipLaunchKernelGGL(content_mask_kernel<3>, grid, dim3(256), 0, st, d_src, stride, w, h, d_mask, mstride, d_bits, bpitch);
+    else hipLaunchKernelGGL(content_mask_kernel<1>, grid, dim3(256), 0, st, d_src, stride, w, h, d_mask, mstride, d_bits, bpitch);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -94,85 +104,141 @@ struct P2 { int x, y; };
 
 // Scratch kept between frames so that the per-frame host work allocates nothing.
 struct CropScratch {
-    std::vector<int8_t> img;          // labelled copy of the mask inside a zero frame
+    std::vector<uint64_t> bits;       // the mask as a BitFrame when it arrives as bytes
+    std::vector<uint64_t> ml, mr;     // marks on followed border pixels (same layout)
+    std::vector<size_t> touched;      // words of ml / mr that hold marks
     std::vector<P2> best, cur;        // SIMPLE points of the largest / current contour
     std::vector<int> chain_best, chain_cur;   // every border pixel (frame coordinates) of the same
     struct Span { int a, b; };                // filled pixels a..b (inclusive) of one row
     std::vector<std::vector<Span>> spans;     // the filled contour, row by row (merged, ascending)
     std::vector<int> sx, sy;
+    std::vector<int> one_a, one_b, multi;     // rows of exactly one span: its ends; rows of several: their numbers
     std::vector<std::vector<int>> rows;       // crossings per row
 };
 
-// Follows the outer borders of `mask` the way cv::findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
+// The mask as the host sees it: one bit per pixel, 64 pixels per word, inside a frame of zero words (one word left
+// and right of every row, one row above and below), so that a neighbour test never leaves the buffer.  The device
+// writes it in this form (content_mask_kernel, a ballot per 64 pixels): 1 MB instead of 8 MB over PCIe at 4K, and
+// the scan for contour starts below looks at 64 pixels per step.
+struct BitFrame {
+    int w = 0, h = 0, pitch = 0;      // pitch in words = ceil(w / 64) + 2
+    const uint64_t* F = nullptr;
+    static int pitch_for(int w) { return (w + 63) / 64 + 2; }
+    static size_t words_for(int w, int h) { return (size_t)pitch_for(w) * (h + 2); }
+};
+
+// Follows the outer borders of the mask the way cv::findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
 // numbers them and keeps the one with the most points (first wins ties, AutoZoomCrop.cpp:155-164).
-// Returns the number of contours.
-int trace_largest(const uint8_t* mask, int w, int h, size_t stride, CropScratch& S) {
-    const int W = w + 2;
-    S.img.assign((size_t)W * (h + 2), 0);
-    for (int y = 0; y < h; y++) {
-        const uint8_t* m = mask + (size_t)y * stride;
-        int8_t* d = &S.img[(size_t)(y + 1) * W + 1];
-        for (int x = 0; x < w; x++) d[x] = m[x] != 0;
-    }
-    int8_t* img = S.img.data();
-    // 8 directions counter-clockwise from east, image y pointing down
-    static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1}, DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-    int off[16];
-    for (int i = 0; i < 16; i++) off[i] = DY[i & 7] * W + DX[i & 7];
-    const int8_t LEFT_MARK = 2, RIGHT_MARK = (int8_t)0x82;
+// Border pixels already followed carry one of two marks (bit planes ML / MR beside the mask): MR where the
+// border passed with the outside to its east, ML elsewhere.  Scanning a row, an unmarked mask pixel with
+// background to its west starts a new outer border unless the last mark before it on the row is an ML (then the
+// scan is inside a component already followed: a hole, or something within a hole).  Returns the number of
+// contours.
+int trace_largest(const BitFrame& bf, CropScratch& S) {
+    const int w = bf.w, h = bf.h, P = bf.pitch, W = w + 2;
+    const uint64_t* F = bf.F;
+    // the mark planes start from zero: only the words the last call marked need wiping
+    const size_t n_words = (size_t)P * (h + 2);
+    if (S.ml.size() != n_words) { S.ml.assign(n_words, 0); S.mr.assign(n_words, 0); }
+    else for (size_t i : S.touched) S.ml[i] = S.mr[i] = 0;
+    S.touched.clear();
+    uint64_t* ML = S.ml.data();
+    uint64_t* MR = S.mr.data();
+    auto word_of = [P](int x, int y) { return (size_t)(y + 1) * P + ((x + 64) >> 6); };
+    auto fg = [&](int x, int y) { return (F[word_of(x, y)] >> ((x + 64) & 63)) & 1; };
+    // 8 directions counter-clockwise from east, image y pointing down (twice, so that a turn needs no wrap)
+    static const int DX[16] = {1, 1, 0, -1, -1, -1, 0, 1, 1, 1, 0, -1, -1, -1, 0, 1};
+    static const int DY[16] = {0, -1, -1, -1, 0, 1, 1, 1, 0, -1, -1, -1, 0, 1, 1, 1};
     S.best.clear(); S.chain_best.clear();
     int n_contours = 0;
-    for (int y = 1; y <= h; y++) {
-        int8_t* row = img + (size_t)y * W;
-        int last_label_x = 0;                    // last labelled pixel met on this row (column 0 = frame)
-        int before = 0;
-        for (int x = 1; x <= w; x++) {
-            const int v = row[x];
-            if (v == before) continue;
-            const bool outer_start = before == 0 && v == 1 && row[last_label_x] <= 0;
-            if (!outer_start) {
-                before = v;
-                if (v & ~1) last_label_x = x;
-                continue;
-            }
-            ++n_contours;
-            S.cur.clear(); S.chain_cur.clear();
-            const int start = y * W + x;
-            // first neighbour clockwise from west
-            int dir = 4, second = -1;
-            for (int k = 0; k < 7; k++) {
-                dir = (dir + 7) & 7;
-                if (img[start + off[dir]] != 0) { second = start + off[dir]; break; }
-            }
-            if (second < 0) {
-                img[start] = RIGHT_MARK;
-                S.cur.push_back({x - 1, y - 1});
-                S.chain_cur.push_back(start);
-            } else {
-                int at = start, last_dir = dir ^ 4;
-                P2 pos{x - 1, y - 1};
-                while (true) {
-                    const int from = dir;
-                    int next;
-                    do { next = at + off[++dir]; } while (img[next] == 0);
-                    dir &= 7;
-                    const bool passed_east = (unsigned)(dir - 1) < (unsigned)from;
-                    if (passed_east) img[at] = RIGHT_MARK;
-                    else if (img[at] == 1) img[at] = LEFT_MARK;
-                    S.chain_cur.push_back(at);
-                    if (dir != last_dir) { S.cur.push_back(pos); last_dir = dir; }
-                    pos.x += DX[dir]; pos.y += DY[dir];
-                    if (next == start && at == second) break;
-                    at = next;
-                    dir = (dir + 4) & 7;
+
+    auto follow = [&](int sx, int sy) {
+        S.cur.clear(); S.chain_cur.clear();
+        auto mark_right = [&](int x, int y) {
+            const size_t i = word_of(x, y); const uint64_t bit = 1ull << (x & 63);
+            MR[i] |= bit; ML[i] &= ~bit;
+            S.touched.push_back(i);
+        };
+        auto mark_left_if_new = [&](int x, int y) {
+            const size_t i = word_of(x, y); const uint64_t bit = 1ull << (x & 63);
+            if (!((ML[i] | MR[i]) & bit)) { ML[i] |= bit; S.touched.push_back(i); }
+        };
+        // first neighbour clockwise from west
+        int dir = 4;
+        bool alone = true;
+        for (int k = 0; k < 7; k++) {
+            dir = (dir + 7) & 7;
+            if (fg(sx + DX[dir], sy + DY[dir])) { alone = false; break; }
+        }
+        if (alone) {
+            mark_right(sx, sy);
+            S.cur.push_back({sx, sy});
+            S.chain_cur.push_back((sy + 1) * W + sx + 1);
+            return;
+        }
+        const int x2 = sx + DX[dir], y2 = sy + DY[dir];
+        int ax = sx, ay = sy, last_dir = dir ^ 4;
+        while (true) {
+            const int from = dir;
+            int nx, ny;
+            do { ++dir; nx = ax + DX[dir]; ny = ay + DY[dir]; } while (!fg(nx, ny));
+            dir &= 7;
+            const bool passed_east = (unsigned)(dir - 1) < (unsigned)from;
+            if (passed_east) mark_right(ax, ay);
+            else mark_left_if_new(ax, ay);
+            S.chain_cur.push_back((ay + 1) * W + ax + 1);
+            if (dir != last_dir) { S.cur.push_back({ax, ay}); last_dir = dir; }
+            if (nx == sx && ny == sy && ax == x2 && ay == y2) break;
+            ax = nx; ay = ny;
+            dir = (dir + 4) & 7;
+        }
+    };
+
+    const int wpr = P - 2;
+    for (int y = 0; y < h; y++) {
+        const size_t r = (size_t)(y + 1) * P + 1;
+        int last_mark = 0;                       // kind of the last mark met on this row: 0 none, 1 ML, 2 MR
+        uint64_t west = 0;                       // the pixel left of the word (bit 0)
+        for (int k = 0; k < wpr; k++) {
+            const uint64_t f = F[r + k];
+            if (f == 0) { west = 0; continue; }          // no pixels, hence no marks
+            uint64_t begins = f & ~((f << 1) | west);    // mask pixels with background to their west
+            west = f >> 63;
+            uint64_t cand = begins & ~(ML[r + k] | MR[r + k]);
+            while (cand) {
+                const int b = __builtin_ctzll(cand);
+                const uint64_t below = (1ull << b) - 1;
+                const uint64_t ml = ML[r + k] & below, mr = MR[r + k] & below;
+                int kind = last_mark;
+                if (ml | mr) kind = ml > mr ? 1 : 2;     // the higher bit is the later pixel
+                if (kind != 1) {
+                    ++n_contours;
+                    follow(k * 64 + b, y);
+                    if (S.cur.size() > S.best.size()) { S.best.swap(S.cur); S.chain_best.swap(S.chain_cur); }
                 }
+                // the planes may have changed under the scan: look again at what is left of the word
+                const uint64_t above = b == 63 ? 0 : ~((2ull << b) - 1);
+                cand = begins & ~(ML[r + k] | MR[r + k]) & above;
             }
-            if (S.cur.size() > S.best.size()) { S.best.swap(S.cur); S.chain_best.swap(S.chain_cur); }
-            before = row[x];
-            last_label_x = x;
+            const uint64_t ml = ML[r + k], mr = MR[r + k];
+            if (ml | mr) last_mark = ml > mr ? 1 : 2;
         }
     }
     return n_contours;
+}
+
+// 0 / non-zero bytes -> BitFrame planes in S.bits (the host-only entry point; the device hands over bits)
+BitFrame pack_mask(const uint8_t* mask, int w, int h, size_t stride, CropScratch& S) {
+    BitFrame bf;
+    bf.w = w; bf.h = h; bf.pitch = BitFrame::pitch_for(w);
+    S.bits.assign(BitFrame::words_for(w, h), 0);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* m = mask + (size_t)y * stride;
+        uint64_t* d = &S.bits[(size_t)(y + 1) * bf.pitch + 1];
+        for (int x = 0; x < w; x++) d[x >> 6] |= (uint64_t)(m[x] != 0) << (x & 63);   // host-only entry: not a hot path
+    }
+    bf.F = S.bits.data();
+    return bf;
 }
 
 // The filled contour (cv::drawContours FILLED) as row spans: interior by the even-odd rule on the border chain
@@ -215,10 +281,10 @@ void fill_spans(int w, int h, CropScratch& S, std::vector<uint8_t>* dump) {
 }
 
 // info = {n_contours, contour_points, x, y, w, h, iterations, valid}
-void crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, CropScratch& S, int32_t info[8],
-                    std::vector<uint8_t>* filled_dump) {
+void crop_from_mask(const BitFrame& bf, CropScratch& S, int32_t info[8], std::vector<uint8_t>* filled_dump) {
+    const int w = bf.w, h = bf.h;
     for (int i = 0; i < 8; i++) info[i] = 0;
-    info[0] = trace_largest(mask, w, h, stride, S);
+    info[0] = trace_largest(bf, S);
     if (info[0] == 0) return;
     info[1] = (int)S.best.size();
     fill_spans(w, h, S, filled_dump);
@@ -234,12 +300,22 @@ void crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, CropScratc
         }
         return (xb - xa) - filled;
     };
+    // Column queries dominate the loop (two per round, over the height of the rectangle), so rows of one span, the
+    // usual kind, are kept as two flat arrays the compiler can vectorise over; the others are fixed up one by one.
+    S.one_a.assign(h, INT_MAX); S.one_b.assign(h, INT_MIN); S.multi.clear();
+    for (int y = 0; y < h; y++) {
+        const std::vector<CropScratch::Span>& sp = S.spans[y];
+        if (sp.size() == 1) { S.one_a[y] = sp[0].a; S.one_b[y] = sp[0].b; }
+        else if (sp.size() > 1) S.multi.push_back(y);
+    }
     auto col_zeros = [&](int x, int ya, int yb) {   // zeros in column x, rows [ya, yb)
+        const int* A = S.one_a.data();
+        const int* B = S.one_b.data();
         int zeros = 0;
-        for (int y = ya; y < yb; y++) {
-            bool in = false;
-            for (const CropScratch::Span& q : S.spans[y]) if (q.a <= x && x <= q.b) { in = true; break; }
-            zeros += !in;
+        for (int y = ya; y < yb; y++) zeros += (x < A[y]) | (x > B[y]);
+        for (int y : S.multi) {
+            if (y < ya || y >= yb) continue;
+            for (const CropScratch::Span& q : S.spans[y]) if (q.a <= x && x <= q.b) { --zeros; break; }
         }
         return zeros;
     };
@@ -286,10 +362,11 @@ struct vs_azc {
     hipStream_t st = nullptr;
     std::string err;
     uint8_t* d_mask = nullptr;
-    uint8_t* h_mask = nullptr;        // pinned
+    uint8_t* h_mask = nullptr;        // pinned; both hold the mask as a BitFrame
     uint8_t* d_in = nullptr;
     uint8_t* d_out = nullptr;
-    size_t mask_bytes = 0, io_bytes = 0;
+    int mask_w = 0, mask_h = 0;       // the size d_mask / h_mask (a BitFrame) are laid out for
+    size_t io_bytes = 0;
     CropScratch scratch;
     int32_t info[8] = {0};
 };
@@ -307,15 +384,16 @@ extern "C" {
 int vs_op_content_mask(const void* d_src, size_t stride, int w, int h, int cn, void* d_mask, size_t mask_stride,
                        void* stream) {
     VS_TRY(ensure_device());
-    return launch_content_mask((const uint8_t*)d_src, stride, w, h, cn, (uint8_t*)d_mask, mask_stride, (hipStream_t)stream);
+    return launch_content_mask((const uint8_t*)d_src, stride, w, h, cn, (uint8_t*)d_mask, mask_stride, nullptr, 0,
+                               (hipStream_t)stream);
 }
 
 // Host logic only (no device needed): :141-228 on a host mask.
 int vs_azc_crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, int32_t* info, uint8_t* filled_out) {
     if (!mask || !info || w <= 0 || h <= 0 || stride < (size_t)w) return VS_ERR_INVALID_ARG;
-    CropScratch S;
+    static thread_local CropScratch S;       // kept between calls, as the vs_azc object keeps its own
     std::vector<uint8_t> filled;
-    crop_from_mask(mask, w, h, stride, S, info, filled_out ? &filled : nullptr);
+    crop_from_mask(pack_mask(mask, w, h, stride, S), S, info, filled_out ? &filled : nullptr);
     if (filled_out) {
         if (filled.empty()) memset(filled_out, 0, (size_t)w * h);
         else memcpy(filled_out, filled.data(), (size_t)w * h);
@@ -366,19 +444,23 @@ int vs_azc_sync(vs_azc* a) {
 
 // Mask on the device, contour logic on the host: fills a->info (:111-228).
 static int azc_plan(vs_azc* a, const void* d_data, int w, int h, size_t stride, int cn) {
-    const size_t mb = (size_t)w * h;
-    if (a->mask_bytes < mb) {
+    const size_t mb = BitFrame::words_for(w, h) * 8;
+    if (a->mask_w != w || a->mask_h != h) {
         if (a->d_mask) (void)hipFree(a->d_mask);
         if (a->h_mask) (void)hipHostFree(a->h_mask);
-        a->d_mask = a->h_mask = nullptr; a->mask_bytes = 0;
+        a->d_mask = a->h_mask = nullptr; a->mask_w = a->mask_h = 0;
         A_HIP(a, hipMalloc((void**)&a->d_mask, mb));
         A_HIP(a, hipHostMalloc((void**)&a->h_mask, mb, hipHostMallocDefault));
-        a->mask_bytes = mb;
+        A_HIP(a, hipMemsetAsync(a->d_mask, 0, mb, a->st));          // the frame; the kernel rewrites the inside
+        a->mask_w = w; a->mask_h = h;
     }
-    A_TRY(a, launch_content_mask((const uint8_t*)d_data, stride, w, h, cn, a->d_mask, w, a->st));      // :111-139
+    BitFrame bf;
+    bf.w = w; bf.h = h; bf.pitch = BitFrame::pitch_for(w); bf.F = (const uint64_t*)a->h_mask;
+    A_TRY(a, launch_content_mask((const uint8_t*)d_data, stride, w, h, cn, nullptr, 0, (unsigned long long*)a->d_mask,
+                                 bf.pitch, a->st));                                                   // :111-139
     A_HIP(a, hipMemcpyAsync(a->h_mask, a->d_mask, mb, hipMemcpyDeviceToHost, a->st));                 // :142-143
     A_HIP(a, hipStreamSynchronize(a->st));
-    crop_from_mask(a->h_mask, w, h, w, a->scratch, a->info, nullptr);                                 // :146-228
+    crop_from_mask(bf, a->scratch, a->info, nullptr);                                                 // :146-228
     return VS_OK;
 }
 

@@ -7,10 +7,11 @@
 //   resize x0.25 + BGR2GRAY (fused, k_gray.hip)
 //   sobel_kernel      3x3 Sobel, BORDER_REPLICATE -> dx,dy (int16) and L1 magnitude
 //   canny_nms_kernel  non-maximum suppression with the tan(22.5) fixed-point sectors,
-//                     double threshold -> map {0 maybe, 1 no, 2 edge}
-//   canny_hyst_tile_kernel  growth of the edge set through the "maybe" pixels: every 64x32 tile is iterated
-//                     to its own fixed point in LDS; passes over the image repeat until a pass changes
-//                     nothing (chains that cross tile borders; the host reads one flag word per group
+//                     double threshold -> bit planes E ("edge") and C ("maybe"), 64 pixels per word
+//   canny_hyst_band_kernel  growth of the edge set through the "maybe" pixels on the bit planes: a band
+//                     of 62 rows x up to 1024 pixels is iterated to its own fixed point in registers
+//                     (wave = word, lane = row); passes over the image repeat until a pass changes
+//                     nothing (chains that cross band borders; the host reads one flag word per group
 //                     of passes)
 //   hough_accum_kernel  votes of every (edge pixel, angle) pair, float rho as cv::HoughLines
 //   hough_peaks_kernel  local maxima above the threshold -> (votes, index) keys
@@ -51,93 +52,157 @@ __global__ __launch_bounds__(NT) void sobel_kernel(const uint8_t* __restrict__ g
     mag[(size_t)(y + 1) * mw + x + 1] = abs(dx) + abs(dy);
 }
 
-// map/mag are framed with one pixel (map frame = 1, mag frame = 0), row pitch mw = w + 2
+// mag is framed with one pixel of zeros, row pitch mw = w + 2.  The result goes out as two bit planes: word k of
+// row y holds pixels 64k .. 64k+63 (bit b = pixel 64k + b); E = "edge" (above the high threshold), C = "maybe"
+// (local maximum between the thresholds).  One wave covers 64 consecutive pixels, so a ballot is the word.
+typedef unsigned long long u64;
+
 __global__ __launch_bounds__(NT) void canny_nms_kernel(const short2* __restrict__ dxy, const int* __restrict__ mag,
-                                                       int w, int h, int mw, int low, int high, int* __restrict__ map) {
+                                                       int w, int h, int mw, int low, int high, u64* __restrict__ E,
+                                                       u64* __restrict__ C, int wpr) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w || y >= h) return;
-    const int p = (y + 1) * mw + x + 1;
-    const int m = mag[p];
     int out = 1;
-    if (m > low) {
-        const short2 d = dxy[(size_t)y * w + x];
-        const int xs = d.x, ys = d.y;
-        const int ax = abs(xs), ay = abs(ys) << 15;
-        const int tg22x = ax * 13573;
-        bool is_max;
-        if (ay < tg22x) {
-            is_max = m > mag[p - 1] && m >= mag[p + 1];
-        } else {
-            const int tg67x = tg22x + (ax << 16);
-            if (ay > tg67x) {
-                is_max = m > mag[p - mw] && m >= mag[p + mw];
+    if (x < w) {
+        const int p = (y + 1) * mw + x + 1;
+        const int m = mag[p];
+        if (m > low) {
+            const short2 d = dxy[(size_t)y * w + x];
+            const int xs = d.x, ys = d.y;
+            const int ax = abs(xs), ay = abs(ys) << 15;
+            const int tg22x = ax * 13573;
+            bool is_max;
+            if (ay < tg22x) {
+                is_max = m > mag[p - 1] && m >= mag[p + 1];
             } else {
-                const int s = (xs ^ ys) < 0 ? 1 : -1;
-                is_max = m > mag[p - mw - s] && m > mag[p + mw + s];
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) {
+                    is_max = m > mag[p - mw] && m >= mag[p + mw];
+                } else {
+                    const int s = (xs ^ ys) < 0 ? 1 : -1;
+                    is_max = m > mag[p - mw - s] && m > mag[p + mw + s];
+                }
+            }
+            if (is_max) {
+                out = m > high ? 2 : 0;
             }
         }
-        if (is_max) {
-            out = m > high ? 2 : 0;
-        }
     }
-    map[p] = out;
+    const u64 be = __ballot(out == 2), bc = __ballot(out == 0);
+    if ((threadIdx.x & 63) == 0 && x < w) {
+        E[(size_t)y * wpr + (x >> 6)] = be;
+        C[(size_t)y * wpr + (x >> 6)] = bc;
+    }
 }
 
-constexpr int HT_W = 64, HT_H = 32;      // hysteresis tile
+constexpr int HB_ROWS = 62;      // rows a hysteresis band owns (lanes 1..62; lanes 0 and 63 hold the rows next to it)
+constexpr int HB_WORDS = 16;     // words (of 64 pixels) one workgroup spans: one wave per word
 
-// One pass: each tile grows its edges (2) through its candidates (0) until nothing changes inside the tile; the
-// halo is read as the neighbours left it.  Growth is monotone, so concurrent tiles can only help each other.
-__global__ __launch_bounds__(NT) void canny_hyst_tile_kernel(int* __restrict__ map, int mw, int w, int h,
-                                                             int* __restrict__ changed) {
-    __shared__ int8_t t[HT_H + 2][HT_W + 2 + 2];
-    __shared__ int s_flag;
-    const int x0 = blockIdx.x * HT_W, y0 = blockIdx.y * HT_H, tid = threadIdx.x;
-    for (int i = tid; i < (HT_H + 2) * (HT_W + 2); i += NT) {
-        const int ly = i / (HT_W + 2), lx = i - ly * (HT_W + 2);
-        const int x = x0 + lx - 1, y = y0 + ly - 1;           // image coordinates; the map has a frame of 1s
-        int8_t v = 1;
-        if (x >= -1 && x <= w && y >= -1 && y <= h) v = (int8_t)map[(y + 1) * mw + x + 1];
-        t[ly][lx] = v;
+// all candidate bits of `c` that a run of candidates links to a bit of `g` along the row (Kogge-Stone fill)
+__device__ __forceinline__ u64 fill_row(u64 g, u64 c) {
+    u64 a = g, p = c;
+    a |= p & (a << 1);  p &= p << 1;
+    a |= p & (a << 2);  p &= p << 2;
+    a |= p & (a << 4);  p &= p << 4;
+    a |= p & (a << 8);  p &= p << 8;
+    a |= p & (a << 16); p &= p << 16;
+    a |= p & (a << 32);
+    u64 b = g; p = c;
+    b |= p & (b >> 1);  p &= p >> 1;
+    b |= p & (b >> 2);  p &= p >> 2;
+    b |= p & (b >> 4);  p &= p >> 4;
+    b |= p & (b >> 8);  p &= p >> 8;
+    b |= p & (b >> 16); p &= p >> 16;
+    b |= p & (b >> 32);
+    return a | b;
+}
+
+// the same along the columns (lane = row): all candidate bits a vertical run of candidates links to a bit of `g`
+__device__ __forceinline__ u64 fill_col(u64 g, u64 c, int lane) {
+    u64 a = g, p = c;
+#pragma unroll
+    for (int n = 1; n < 64; n *= 2) {
+        const u64 ta = __shfl_up(a, n), tp = __shfl_up(p, n);
+        if (lane >= n) { a |= p & ta; p &= tp; } else { p = 0; }
     }
-    bool mine = false;
+    u64 b = g; p = c;
+#pragma unroll
+    for (int n = 1; n < 64; n *= 2) {
+        const u64 tb = __shfl_down(b, n), tp = __shfl_down(p, n);
+        if (lane + n < 64) { b |= p & tb; p &= tp; } else { p = 0; }
+    }
+    return a | b;
+}
+
+// One pass of the growth of the edge set through the "maybe" pixels.  A workgroup owns a band of 62 rows by up to
+// 16 words: wave = word, lane = row, so a row of 64 pixels is one register and the 8-neighbourhood is shifts plus
+// a lane shuffle.  The band is iterated to its own fixed point (the waves trade their border columns through LDS);
+// the rows and words around it are read as the neighbours left them.  Growth is monotone and its fixed point
+// unique, so concurrent bands can only help each other; passes repeat until one changes nothing.
+__global__ __launch_bounds__(64 * HB_WORDS) void canny_hyst_band_kernel(u64* __restrict__ E, const u64* __restrict__ C,
+                                                                        int wpr, int h, int* __restrict__ changed,
+                                                                        const int* __restrict__ before) {
+    if (before && *before == 0) return;      // the pass before this one changed nothing: neither will this one
+    __shared__ uint8_t s_lo[HB_WORDS][64], s_hi[HB_WORDS][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const int k = blockIdx.x * nwv + wv, y = blockIdx.y * HB_ROWS - 1 + lane;
+    const bool in_img = k < wpr && y >= 0 && y < h;
+    const bool own = in_img && lane >= 1 && lane <= HB_ROWS;
+    const size_t at = in_img ? (size_t)y * wpr + k : 0;
+    u64 e = in_img ? E[at] : 0;
+    const u64 c = own ? C[at] : 0;
+    const u64 e0 = e;
+    // columns next to the workgroup's span: fixed for this pass
+    u64 gl = 0, gr = 0;
+    if (in_img && wv == 0 && k > 0) gl = E[at - 1] >> 63;
+    if (in_img && wv == nwv - 1 && k + 1 < wpr) gr = (E[at + 1] & 1) << 63;
+    // a wave whose own rows and whose neighbours' columns stood still in the last round has nothing to do in
+    // this one: the tail of a pass, when one chain is still growing, costs one wave and not sixteen
+    bool active = true;
+    u64 pl = ~0ull, pr = ~0ull;
     for (;;) {
+        s_lo[wv][lane] = (uint8_t)(e & 1);
+        s_hi[wv][lane] = (uint8_t)(e >> 63);
         __syncthreads();
-        if (tid == 0) s_flag = 0;
-        __syncthreads();
+        const u64 l = wv > 0 ? (u64)s_hi[wv - 1][lane] : gl;
+        const u64 r = wv < nwv - 1 ? (u64)s_lo[wv + 1][lane] << 63 : gr;
+        const bool moved = __ballot(l != pl || r != pr) != 0;
+        pl = l; pr = r;
         bool grew = false;
-        for (int i = tid; i < HT_H * HT_W; i += NT) {
-            const int ly = i / HT_W + 1, lx = i % HT_W + 1;
-            if (t[ly][lx] != 0) continue;
-            const bool near = t[ly - 1][lx - 1] == 2 || t[ly - 1][lx] == 2 || t[ly - 1][lx + 1] == 2 || t[ly][lx - 1] == 2 ||
-                              t[ly][lx + 1] == 2 || t[ly + 1][lx - 1] == 2 || t[ly + 1][lx] == 2 || t[ly + 1][lx + 1] == 2;
-            if (near) { t[ly][lx] = 2; grew = true; }
+        if (active || moved) {
+            const u64 hd = e | (e << 1) | (e >> 1) | l | r;       // the row, spread by one pixel to both sides
+            u64 up = __shfl_up(hd, 1), dn = __shfl_down(hd, 1);
+            if (lane == 0) up = 0;
+            if (lane == 63) dn = 0;
+            const u64 ne = fill_col(fill_row(e | (c & (hd | up | dn)), c), c, lane);
+            grew = ne != e;
+            e = ne;
+            active = __ballot(grew) != 0;
         }
-        if (grew) { s_flag = 1; mine = true; }
-        __syncthreads();
-        if (!s_flag) break;
+        if (!__syncthreads_or(grew)) break;
     }
-    if (__syncthreads_or(mine)) {
-        for (int i = tid; i < HT_H * HT_W; i += NT) {
-            const int ly = i / HT_W + 1, lx = i % HT_W + 1;
-            const int x = x0 + lx - 1, y = y0 + ly - 1;
-            if (x < w && y < h && t[ly][lx] == 2) map[(y + 1) * mw + x + 1] = 2;
-        }
-        if (tid == 0) *changed = 1;
-    }
+    const bool mine = own && e != e0;
+    if (mine) E[at] = e;
+    if (__syncthreads_or(mine) && threadIdx.x == 0) *changed = 1;
 }
 
-__global__ __launch_bounds__(NT) void canny_out_kernel(const int* __restrict__ map, int w, int h, int mw,
+__global__ __launch_bounds__(NT) void canny_out_kernel(const u64* __restrict__ E, int wpr, int w, int h,
                                                        uint8_t* __restrict__ edges, size_t estride) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w || y >= h) return;
-    edges[(size_t)y * estride + x] = map[(y + 1) * mw + x + 1] == 2 ? 255 : 0;
+    edges[(size_t)y * estride + x] = (E[(size_t)y * wpr + (x >> 6)] >> (x & 63)) & 1 ? 255 : 0;
 }
 
 __global__ __launch_bounds__(NT) void edge_list_kernel(const uint8_t* __restrict__ edges, size_t stride, int w, int h,
                                                        int* __restrict__ list, int* __restrict__ counters) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w || y >= h) return;
-    if (edges[(size_t)y * stride + x] != 0) list[atomicAdd(&counters[1], 1)] = y * w + x;
+    const bool on = x < w && y < h && edges[(size_t)y * stride + x] != 0;
+    const u64 m = __ballot(on);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&counters[1], __popcll(m));
+    base = __shfl(base, 0);
+    if (on) list[base + __popcll(m & ((1ull << lane) - 1))] = y * w + x;
 }
 
 __global__ __launch_bounds__(NT) void hough_accum_kernel(const int* __restrict__ list, const int* __restrict__ counters,
@@ -256,7 +321,9 @@ struct RollWork {
     uint8_t* edges = nullptr;
     short2* dxy = nullptr;
     int* mag = nullptr;
-    int* map = nullptr;
+    unsigned long long* E = nullptr;     // Canny bit planes, wpr words per row
+    unsigned long long* C = nullptr;
+    int wpr = 0;
     int* queue = nullptr;
     int* list = nullptr;
     int* accum = nullptr;
@@ -278,13 +345,14 @@ static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hi
     if (k.base && k.w == w && k.h == h && k.rho == rho && k.theta == theta) return VS_OK;
     roll_work_free(k);
     if (!(rho > 0) || !(theta > 0)) { set_last_error("hough: rho and theta must be positive"); return VS_ERR_INVALID_ARG; }
-    k.w = w; k.h = h; k.mw = w + 2; k.rho = rho; k.theta = theta;
+    k.w = w; k.h = h; k.mw = w + 2; k.wpr = (w + 63) / 64; k.rho = rho; k.theta = theta;
     k.geom = hough_geom(w, h, rho, theta);
     const size_t npx = (size_t)w * h, nfr = (size_t)(w + 2) * (h + 2);
     k.accum_bytes = (size_t)(k.geom.numangle + 2) * (k.geom.numrho + 2) * 4;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; };
-    const size_t o_gray = take(npx), o_edges = take(npx), o_dxy = take(npx * 4), o_mag = take(nfr * 4), o_map = take(nfr * 4);
+    const size_t o_gray = take(npx), o_edges = take(npx), o_dxy = take(npx * 4), o_mag = take(nfr * 4);
+    const size_t o_E = take((size_t)k.wpr * h * 8), o_C = take((size_t)k.wpr * h * 8);
     const size_t o_queue = take(npx * 4 + 64), o_list = take(npx * 4 + 64), o_accum = take(k.accum_bytes);
     const size_t o_sin = take((size_t)k.geom.numangle * 4), o_cos = take((size_t)k.geom.numangle * 4);
     const size_t o_keys = take((size_t)HOUGH_CAP * 8), o_lines = take((size_t)HOUGH_CAP * 8), o_cnt = take(64), o_res = take(64);
@@ -292,12 +360,10 @@ static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hi
     VS_HIP_TRY(hipMemsetAsync(k.base, 0, off, st));
     uint8_t* b = k.base;
     k.gray = b + o_gray; k.edges = b + o_edges; k.dxy = (short2*)(b + o_dxy); k.mag = (int*)(b + o_mag);
-    k.map = (int*)(b + o_map); k.queue = (int*)(b + o_queue); k.list = (int*)(b + o_list); k.accum = (int*)(b + o_accum);
+    k.E = (unsigned long long*)(b + o_E); k.C = (unsigned long long*)(b + o_C); k.queue = (int*)(b + o_queue); k.list = (int*)(b + o_list); k.accum = (int*)(b + o_accum);
     k.tabSin = (float*)(b + o_sin); k.tabCos = (float*)(b + o_cos); k.keys = (unsigned long long*)(b + o_keys);
     k.lines = (float*)(b + o_lines); k.counters = (int*)(b + o_cnt); k.res = (RollResult*)(b + o_res);
-    // map frame = 1 ("not an edge"); interior is rewritten every frame.  mag frame stays 0.
-    std::vector<int> frame(nfr, 1);
-    VS_HIP_TRY(hipMemcpyAsync(k.map, frame.data(), nfr * 4, hipMemcpyHostToDevice, st));
+    // the frame of mag stays 0; its interior and the bit planes are rewritten every frame
     // createTrigTable: float angle accumulation, sin/cos in double (host libm, as the oracle)
     std::vector<float> ts(k.geom.numangle), tc(k.geom.numangle);
     const float irho = 1 / rho;
@@ -320,24 +386,26 @@ static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double l
     const int w = k.w, h = k.h;
     dim3 grid((w + NT - 1) / NT, h);
     hipLaunchKernelGGL(sobel_kernel, grid, dim3(NT), 0, st, d_gray, stride, w, h, k.dxy, k.mag, k.mw);
-    hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.map);
+    hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.E, k.C, k.wpr);
     VS_HIP_TRY(hipGetLastError());
-    // hysteresis: passes in groups of 2, 4, 8, 16, 16, ...; one flag word per pass, read back per group.  A pass
-    // that changed nothing ends the growth (later passes of its group were no-ops).
+    // hysteresis: passes in groups of 4, 8, 16, 16, ...; one flag word per pass, read back per group.  A pass
+    // that changed nothing ends the growth: the later passes of its group see its flag and return at once.
     {
-        dim3 hg((w + HT_W - 1) / HT_W, (h + HT_H - 1) / HT_H);
+        const int nwv = k.wpr < HB_WORDS ? k.wpr : HB_WORDS;
+        dim3 hg((k.wpr + nwv - 1) / nwv, (h + HB_ROWS - 1) / HB_ROWS);
         int32_t flags[16];
-        for (int group = 2;; group = group < 16 ? group * 2 : 16) {
+        for (int group = 4;; group = group < 16 ? group * 2 : 16) {
             VS_HIP_TRY(hipMemsetAsync(k.counters, 0, 64, st));
             for (int p = 0; p < group; p++)
-                hipLaunchKernelGGL(canny_hyst_tile_kernel, hg, dim3(NT), 0, st, k.map, k.mw, w, h, k.counters + p);
+                hipLaunchKernelGGL(canny_hyst_band_kernel, hg, dim3(64 * nwv), 0, st, k.E, k.C, k.wpr, h, k.counters + p,
+                                   p ? k.counters + p - 1 : (int*)nullptr);
             VS_HIP_TRY(hipGetLastError());
             VS_HIP_TRY(hipMemcpyAsync(flags, k.counters, 64, hipMemcpyDeviceToHost, st));
             VS_HIP_TRY(hipStreamSynchronize(st));
             if (!flags[group - 1]) break;
         }
     }
-    hipLaunchKernelGGL(canny_out_kernel, grid, dim3(NT), 0, st, k.map, w, h, k.mw, d_edges, estride);
+    hipLaunchKernelGGL(canny_out_kernel, grid, dim3(NT), 0, st, k.E, k.wpr, w, h, d_edges, estride);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
