@@ -4,12 +4,12 @@
 // Split of the work (the reference has the same split, AutoZoomCrop.cpp:141-147: the mask is
 // downloaded for cv::findContours on the CPU):
 //   device  content_mask_kernel : BGR2GRAY + threshold(>1) + MORPH_CLOSE(5x5 ellipse) fused in one
-//                                 pass over the frame (tile + halo in LDS), 3 B/px read, 1 B/px written
-//   host    crop_from_mask      : border following of the 1 B/px mask (pointer chasing along one
+//                                 pass over the frame (tile + halo in LDS), 3 B/px read, 1 bit/px written
+//   host    crop_from_mask      : border following on the bit mask (pointer chasing along one
 //                                 contour: serial by nature), filled interior as row spans, the
-//                                 shrink loop of :189-205 on per-row/column prefix counts
+//                                 shrink loop of :189-205 on the spans
 //   device  warp_affine_kernel  : crop + scale to 640x360 (cv::warpAffine semantics, k_warp.hip)
-// Only the mask (w*h bytes) crosses PCIe between the two device stages; the frame stays in HBM.
+// Only the mask (one bit per pixel) crosses PCIe between the two device stages; the frame stays in HBM.
 #include <algorithm>
 #include <climits>
 #include <cstring>

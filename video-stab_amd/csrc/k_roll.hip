@@ -192,21 +192,71 @@ __global__ __launch_bounds__(NT) void canny_out_kernel(const u64* __restrict__ E
     edges[(size_t)y * estride + x] = (E[(size_t)y * wpr + (x >> 6)] >> (x & 63)) & 1 ? 255 : 0;
 }
 
+// Edge pixels as packed (y << 16 | x), in no particular order (the votes do not depend on it).  A thread looks at
+// eight pixels, a wave reserves its share of the list with one atomic.
+constexpr int EL_PX = 8;
+
 __global__ __launch_bounds__(NT) void edge_list_kernel(const uint8_t* __restrict__ edges, size_t stride, int w, int h,
                                                        int* __restrict__ list, int* __restrict__ counters) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    const bool on = x < w && y < h && edges[(size_t)y * stride + x] != 0;
-    const u64 m = __ballot(on);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * EL_PX, y = blockIdx.y;
+    const uint8_t* row = edges + (size_t)y * stride;
+    unsigned on = 0;
+    if (x0 + EL_PX <= w && (((uintptr_t)(row + x0)) & 7) == 0) {
+        const uint2 v = *(const uint2*)(row + x0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            on |= ((v.x >> (8 * k)) & 255u ? 1u : 0u) << k;
+            on |= ((v.y >> (8 * k)) & 255u ? 1u : 0u) << (4 + k);
+        }
+    } else {
+        for (int k = 0; k < EL_PX; k++)
+            if (x0 + k < w && row[x0 + k] != 0) on |= 1u << k;
+    }
+    const int mine = __popc(on), lane = threadIdx.x & 63;
+    if (__ballot(mine != 0) == 0) return;
+    int incl = mine;                             // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d *= 2) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
     int base = 0;
-    if (lane == 0) base = atomicAdd(&counters[1], __popcll(m));
-    base = __shfl(base, 0);
-    if (on) list[base + __popcll(m & ((1ull << lane) - 1))] = y * w + x;
+    if (lane == 63) base = atomicAdd(&counters[1], incl);
+    base = __shfl(base, 63) + incl - mine;
+    while (on) {
+        const int k = __builtin_ctz(on);
+        on &= on - 1;
+        list[base++] = (y << 16) | (x0 + k);
+    }
 }
 
+// Votes of every (edge pixel, angle) pair.  One workgroup per angle keeps that angle's row of the accumulator in
+// LDS, runs over the edge list and stores the row: no atomics on HBM and no clearing of the accumulator between
+// frames (rows are stored whole; the frame of zeros around them is never written).
+__global__ __launch_bounds__(1024) void hough_accum_lds_kernel(const int* __restrict__ list, const int* __restrict__ counters,
+                                                               const float* __restrict__ tabSin,
+                                                               const float* __restrict__ tabCos, int numrho,
+                                                               int* __restrict__ accum) {
+    extern __shared__ int s_row[];
+    const int n = blockIdx.x, n_edges = counters[1];
+    for (int r = threadIdx.x; r < numrho; r += blockDim.x) s_row[r] = 0;
+    __syncthreads();
+    const float cs = tabCos[n], sn = tabSin[n];
+    const int shift = (numrho - 1) / 2;
+    for (int e = threadIdx.x; e < n_edges; e += blockDim.x) {
+        const int idx = list[e];
+        const int i = idx >> 16, j = idx & 0xFFFF;
+        const int r = f_round((float)j * cs + (float)i * sn) + shift;
+        atomicAdd(&s_row[r], 1);
+    }
+    __syncthreads();
+    int* out = accum + (size_t)(n + 1) * (numrho + 2) + 1;
+    for (int r = threadIdx.x; r < numrho; r += blockDim.x) out[r] = s_row[r];
+}
+
+// The same with atomics on a zeroed accumulator in HBM, for accumulator rows that do not fit LDS.
 __global__ __launch_bounds__(NT) void hough_accum_kernel(const int* __restrict__ list, const int* __restrict__ counters,
-                                                         int w, const float* __restrict__ tabSin,
+                                                         const float* __restrict__ tabSin,
                                                          const float* __restrict__ tabCos, int numangle, int numrho,
                                                          int* __restrict__ accum) {
     const int n_edges = counters[1];
@@ -214,7 +264,7 @@ __global__ __launch_bounds__(NT) void hough_accum_kernel(const int* __restrict__
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int e = (int)(t / numangle), n = (int)(t - (long long)e * numangle);
         const int idx = list[e];
-        const int i = idx / w, j = idx - i * w;
+        const int i = idx >> 16, j = idx & 0xFFFF;
         int r = f_round((float)j * tabCos[n] + (float)i * tabSin[n]);
         r += (numrho - 1) / 2;
         atomicAdd(&accum[(size_t)(n + 1) * (numrho + 2) + r + 1], 1);
@@ -414,12 +464,19 @@ static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double l
 static int run_hough(RollWork& k, const uint8_t* d_edges, size_t estride, int threshold, double amin, double amax,
                      hipStream_t st) {
     const int w = k.w, h = k.h;
-    dim3 grid((w + NT - 1) / NT, h);
+    if (w > 65535 || h > 32767) { set_last_error("hough: image too large"); return VS_ERR_INVALID_ARG; }
     VS_HIP_TRY(hipMemsetAsync(k.counters + 1, 0, 60, st));
-    VS_HIP_TRY(hipMemsetAsync(k.accum, 0, k.accum_bytes, st));
-    hipLaunchKernelGGL(edge_list_kernel, grid, dim3(NT), 0, st, d_edges, estride, w, h, k.list, k.counters);
-    hipLaunchKernelGGL(hough_accum_kernel, dim3(2048), dim3(NT), 0, st, k.list, k.counters, w, k.tabSin, k.tabCos,
-                       k.geom.numangle, k.geom.numrho, k.accum);
+    dim3 lgrid((w + NT * EL_PX - 1) / (NT * EL_PX), h);
+    hipLaunchKernelGGL(edge_list_kernel, lgrid, dim3(NT), 0, st, d_edges, estride, w, h, k.list, k.counters);
+    const size_t row_bytes = (size_t)k.geom.numrho * 4;
+    if (row_bytes <= 60 * 1024) {
+        hipLaunchKernelGGL(hough_accum_lds_kernel, dim3(k.geom.numangle), dim3(1024), row_bytes, st, k.list, k.counters,
+                           k.tabSin, k.tabCos, k.geom.numrho, k.accum);
+    } else {
+        VS_HIP_TRY(hipMemsetAsync(k.accum, 0, k.accum_bytes, st));
+        hipLaunchKernelGGL(hough_accum_kernel, dim3(2048), dim3(NT), 0, st, k.list, k.counters, k.tabSin, k.tabCos,
+                           k.geom.numangle, k.geom.numrho, k.accum);
+    }
     dim3 g2((k.geom.numrho + NT - 1) / NT, k.geom.numangle);
     hipLaunchKernelGGL(hough_peaks_kernel, g2, dim3(NT), 0, st, k.accum, k.geom.numangle, k.geom.numrho, threshold, k.keys, k.counters);
     hipLaunchKernelGGL(hough_select_kernel, dim3(1), dim3(1024), 0, st, k.keys, k.counters, k.geom.numrho, k.rho, k.theta,
