@@ -447,6 +447,45 @@ int vs_enh_cvt_color(vs_enh* e, int code, const void* d_src, void* d_dst, size_t
 int vs_enh_gaussian_blur(vs_enh* e, const void* d_src, size_t stride, int w, int h, double sigma,
                          void* d_dst, size_t dstride);
 
+/* ------------------------------------------------------------------ config layer (host only, no device)
+ * The YAML the reference's example mains read through cv::FileStorage and the key -> parameter mapping each of
+ * them repeats (examples/config.yaml:1-159; examples/vs.cpp:50-168; examples/vsg.cpp:1007-1112), plus the
+ * st_mtime test of their hot reload (vs.cpp:199-200,381-394).  Scalars and `>>` conversions follow OpenCV's YAML
+ * reader (see csrc/config.cpp for the rules restated).  Key paths are section names joined by '.',
+ * e.g. "stabilizer.smoothing_radius". */
+typedef struct vs_config vs_config;
+
+typedef enum vs_config_kind_e {
+    VS_CFG_NONE = 0,      /* absent, or an empty value */
+    VS_CFG_INT = 1,
+    VS_CFG_REAL = 2,
+    VS_CFG_STRING = 3,
+    VS_CFG_MAP = 4,
+    VS_CFG_SEQ = 5
+} vs_config_kind_e;
+
+/* VS_ERR_INVALID_ARG when the file cannot be read or is malformed (vs_last_error names the line). */
+int vs_config_open(const char* path, vs_config** out);
+int vs_config_parse(const char* text, size_t len, vs_config** out);
+void vs_config_close(vs_config* c);
+int vs_config_kind(const vs_config* c, const char* key_path);
+int vs_config_size(const vs_config* c, const char* key_path);      /* entries of a map / sequence, 1 for a scalar */
+/* `node >> value` of cv::FileNode: an absent key gives 0 / 0.0 / "", a value of the wrong kind INT_MAX / DBL_MAX /
+ * FLT_MAX / "", a real read as int is rounded half to even. */
+int vs_config_get_int(const vs_config* c, const char* key_path, int32_t* v);
+int vs_config_get_double(const vs_config* c, const char* key_path, double* v);
+int vs_config_get_float(const vs_config* c, const char* key_path, float* v);
+int vs_config_get_string(const vs_config* c, const char* key_path, char* buf, size_t cap);
+int vs_config_seq_get_double(const vs_config* c, const char* key_path, int index, double* v);
+/* The sections of config.yaml into the flat parameter structs (struct_size must be set; start from
+ * vs_*_params_default).  An absent section leaves *p alone and reports *present = 0 (the mains test
+ * `!node.empty()`).  zero_missing = 1 is the reference to the letter: every key the mains read is assigned, an
+ * absent one as 0 / "" (that is what `node["k"] >> field` does); 0 keeps the field's value for absent keys. */
+int vs_config_read_stab(const vs_config* c, const char* section, int zero_missing, vs_params_c* p, int* present);
+int vs_config_read_roll(const vs_config* c, const char* section, int zero_missing, vs_roll_params_c* p, int* present);
+int vs_config_read_enh(const vs_config* c, const char* section, int zero_missing, vs_enh_params_c* p, int* present);
+int vs_config_mtime(const char* path, int64_t* mtime);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,6 +214,22 @@ class VsLib:
         L.vs_azc_get_info.argtypes = [vp, i32p]
         L.vs_op_content_mask.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.vs_azc_crop_from_mask.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i32p, u8p]
+        cp = C.c_char_p
+        L.vs_config_open.argtypes = [cp, C.POINTER(vp)]
+        L.vs_config_parse.argtypes = [cp, C.c_size_t, C.POINTER(vp)]
+        L.vs_config_close.argtypes = [vp]
+        L.vs_config_close.restype = None
+        L.vs_config_kind.argtypes = [vp, cp]
+        L.vs_config_size.argtypes = [vp, cp]
+        L.vs_config_get_int.argtypes = [vp, cp, i32p]
+        L.vs_config_get_double.argtypes = [vp, cp, f64p]
+        L.vs_config_get_float.argtypes = [vp, cp, C.POINTER(C.c_float)]
+        L.vs_config_get_string.argtypes = [vp, cp, C.c_char_p, C.c_size_t]
+        L.vs_config_seq_get_double.argtypes = [vp, cp, C.c_int, f64p]
+        L.vs_config_read_stab.argtypes = [vp, cp, C.c_int, C.POINTER(VsParams), i32p]
+        L.vs_config_read_roll.argtypes = [vp, cp, C.c_int, C.POINTER(VsRollParams), i32p]
+        L.vs_config_read_enh.argtypes = [vp, cp, C.c_int, C.POINTER(VsEnhParams), i32p]
+        L.vs_config_mtime.argtypes = [cp, C.POINTER(C.c_int64)]
         ep = C.POINTER(VsEnhParams)
         L.vs_enh_params_default.argtypes = [ep]
         L.vs_enh_params_default.restype = None
@@ -487,6 +503,92 @@ class AutoZoomCrop:
         info = np.zeros(8, np.int32)
         self._check(self.lib.vs_azc_get_info(self.h, _p(info, i32p)))
         return info
+
+
+class Config:
+    """The config layer of the C ABI (vs_config_*): config.yaml of the reference's example mains, read with the
+    conversions of cv::FileNode (examples/vs.cpp:50-168, examples/vsg.cpp:1007-1112).  Host only."""
+
+    KINDS = ("none", "int", "real", "string", "map", "seq")
+
+    def __init__(self, vs, path=None, text=None):
+        self.vs = vs
+        self.lib = vs.lib
+        h = C.c_void_p()
+        if path is not None:
+            vs.check(self.lib.vs_config_open(os.fsencode(path), C.byref(h)))
+        else:
+            raw = text.encode() if isinstance(text, str) else bytes(text)
+            vs.check(self.lib.vs_config_parse(raw, len(raw), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.vs_config_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def kind(self, key):
+        return self.KINDS[self.lib.vs_config_kind(self.h, key.encode())]
+
+    def size(self, key):
+        return self.lib.vs_config_size(self.h, key.encode())
+
+    def get_int(self, key):
+        v = C.c_int32()
+        self.vs.check(self.lib.vs_config_get_int(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def get_bool(self, key):
+        return self.get_int(key) != 0
+
+    def get_double(self, key):
+        v = C.c_double()
+        self.vs.check(self.lib.vs_config_get_double(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def get_float(self, key):
+        v = C.c_float()
+        self.vs.check(self.lib.vs_config_get_float(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def get_string(self, key):
+        buf = C.create_string_buffer(4096)
+        self.vs.check(self.lib.vs_config_get_string(self.h, key.encode(), buf, len(buf)))
+        return buf.value.decode()
+
+    def get_seq(self, key):
+        out = []
+        for i in range(self.size(key) if self.kind(key) == "seq" else 0):
+            v = C.c_double()
+            self.vs.check(self.lib.vs_config_seq_get_double(self.h, key.encode(), i, C.byref(v)))
+            out.append(v.value)
+        return out
+
+    def _read(self, fn, p, section, zero_missing):
+        present = C.c_int32()
+        self.vs.check(fn(self.h, section.encode(), int(zero_missing), C.byref(p), C.byref(present)))
+        return p, bool(present.value)
+
+    def stab_params(self, section="stabilizer", zero_missing=False, base=None):
+        return self._read(self.lib.vs_config_read_stab, base or self.vs.params(), section, zero_missing)
+
+    def roll_params(self, section="roll_correction", zero_missing=False, base=None):
+        return self._read(self.lib.vs_config_read_roll, base or self.vs.roll_params(), section, zero_missing)
+
+    def enh_params(self, section="enhancer", zero_missing=False, base=None):
+        return self._read(self.lib.vs_config_read_enh, base or Enhancer.default_params(self.vs), section, zero_missing)
+
+    @staticmethod
+    def mtime(vs, path):
+        v = C.c_int64()
+        vs.check(vs.lib.vs_config_mtime(os.fsencode(path), C.byref(v)))
+        return v.value
 
 
 class Enhancer:
