@@ -6,6 +6,8 @@
 // here (everything off, 1080p), which the reference leaves uninitialised.
 #pragma once
 
+#include <string>
+
 namespace vs {
 
 class Mode {
@@ -22,6 +24,28 @@ public:
 
         /// Stages of this library that are switched on.
         int enabledStages() const { return (int)enhancerEnabled + (int)rollCorrectionEnabled + (int)stabilizationEnabled; }
+
+        /// One line for a log, e.g. "1920x1080 enhance+stabilize".
+        std::string describe() const {
+            std::string chain;
+            auto add = [&chain](bool on, const char* name) {
+                if (!on) return;
+                if (!chain.empty()) chain += '+';
+                chain += name;
+            };
+            add(enhancerEnabled, "enhance");
+            add(rollCorrectionEnabled, "roll");
+            add(stabilizationEnabled, "stabilize");
+            add(trackerEnabled, "track");
+            return std::to_string(width) + "x" + std::to_string(height) + " " + (chain.empty() ? "passthrough" : chain);
+        }
+
+        bool operator==(const Parameters& o) const {
+            return width == o.width && height == o.height && optimizeFps == o.optimizeFps && useCuda == o.useCuda &&
+                   enhancerEnabled == o.enhancerEnabled && rollCorrectionEnabled == o.rollCorrectionEnabled &&
+                   stabilizationEnabled == o.stabilizationEnabled && trackerEnabled == o.trackerEnabled;
+        }
+        bool operator!=(const Parameters& o) const { return !(*this == o); }
     };
 };
 
