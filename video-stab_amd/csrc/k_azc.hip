@@ -3,8 +3,8 @@
 //
 // Split of the work (the reference has the same split, AutoZoomCrop.cpp:141-147: the mask is
 // downloaded for cv::findContours on the CPU):
-//   device  content_mask_kernel : BGR2GRAY + threshold(>1) + MORPH_CLOSE(5x5 ellipse) fused in one
-//                                 pass over the frame (tile + halo in LDS), 3 B/px read, 1 bit/px written
+//   device  threshold_bits_kernel: BGR2GRAY + threshold(>1) as a bit plane (3 B/px read, 1 bit/px written)
+//           close5_bits_kernel   : MORPH_CLOSE(5x5 ellipse) on the bit plane, 64 pixels per register
 //   host    crop_from_mask      : border following on the bit mask (pointer chasing along one
 //                                 contour: serial by nature), filled interior as row spans, the
 //                                 shrink loop of :189-205 on the spans
@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -25,76 +26,122 @@ int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh,
 
 namespace {
 
-constexpr int TW = 64, TH = 16;                 // output tile
-constexpr int W0 = TW + 8, H0 = TH + 8;         // thresholded mask, halo 4
-constexpr int W1 = TW + 4, H1 = TH + 4;         // dilated mask, halo 2
+typedef unsigned long long u64;
 
-// 5x5 MORPH_ELLIPSE: rows -1..1 are full, rows -2 and +2 hold the centre only
+struct __attribute__((aligned(4))) U3 { uint32_t a, b, c; };
+
+// gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15 (BGR2GRAY); threshold(gray, 1, 255, BINARY) keeps gray >= 2
+__device__ __forceinline__ unsigned content_bgr(uint32_t b, uint32_t g, uint32_t r) {
+    return b * 3735u + g * 19235u + r * 9798u + (1u << 14) >= (2u << 15) ? 1u : 0u;
+}
+
+// Pass 1: BGR2GRAY + threshold as a bit plane T (64 pixels per word, wpr words per row, bits past the width 0).
+// A lane takes 4 pixels (12 bytes, three dword loads when the rows allow), a workgroup 1024 pixels of one row;
+// the 4-bit results go through LDS and 16 lanes pack them into the 16 words.
 template <int CN>
-__global__ __launch_bounds__(256) void content_mask_kernel(const uint8_t* __restrict__ src, size_t stride, int w, int h,
-                                                           uint8_t* __restrict__ mask, size_t mstride,
-                                                           unsigned long long* __restrict__ bits, int bpitch) {
-    __shared__ uint8_t m0[H0][W0 + 4];
-    __shared__ uint8_t m1[H1][W1 + 4];
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
-    for (int i = tid; i < W0 * H0; i += 256) {
-        const int ly = i / W0, lx = i - ly * W0;
-        const int x = x0 + lx - 4, y = y0 + ly - 4;
-        uint8_t v = 0;                           // outside pixels never win a max
-        if ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) {
-            const uint8_t* p = src + (size_t)y * stride + (size_t)x * CN;
-            uint32_t g;
-            if (CN == 3) g = (p[0] * 3735u + p[1] * 19235u + p[2] * 9798u + (1u << 14)) >> 15;   // BGR2GRAY
-            else g = p[0];
-            v = g > 1 ? 1 : 0;                   // threshold(gray, 1, 255, THRESH_BINARY)
+__global__ __launch_bounds__(256) void threshold_bits_kernel(const uint8_t* __restrict__ src, size_t stride, int w,
+                                                             int aligned, u64* __restrict__ T, int wpr) {
+    __shared__ __attribute__((aligned(16))) uint8_t nib[256];
+    const int tid = threadIdx.x, x = (blockIdx.x * 256 + tid) * 4, y = blockIdx.y;
+    const uint8_t* row = src + (size_t)y * stride;
+    unsigned n = 0;
+    if (x + 3 < w && aligned) {
+        if (CN == 3) {
+            const U3 d = *reinterpret_cast<const U3*>(row + (size_t)x * 3);
+            n = content_bgr(d.a & 255u, (d.a >> 8) & 255u, (d.a >> 16) & 255u) |
+                content_bgr(d.a >> 24, d.b & 255u, (d.b >> 8) & 255u) << 1 |
+                content_bgr((d.b >> 16) & 255u, d.b >> 24, d.c & 255u) << 2 |
+                content_bgr((d.c >> 8) & 255u, (d.c >> 16) & 255u, d.c >> 24) << 3;
+        } else {
+            const uint32_t d = *reinterpret_cast<const uint32_t*>(row + x);
+            n = ((d & 255u) > 1u) | (((d >> 8) & 255u) > 1u) << 1 | (((d >> 16) & 255u) > 1u) << 2 | ((d >> 24) > 1u) << 3;
         }
-        m0[ly][lx] = v;
+    } else {
+        for (int i = 0; i < 4; i++) {
+            if (x + i >= w) break;
+            const uint8_t* p = row + (size_t)(x + i) * CN;
+            n |= (CN == 3 ? content_bgr(p[0], p[1], p[2]) : (p[0] > 1 ? 1u : 0u)) << i;
+        }
     }
+    nib[tid] = (uint8_t)n;
     __syncthreads();
-    for (int i = tid; i < W1 * H1; i += 256) {   // dilate
-        const int ly = i / W1, lx = i - ly * W1;
-        const int x = x0 + lx - 2, y = y0 + ly - 2;
-        uint8_t v = 1;                           // outside pixels never win a min
-        if ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) {
-            const int cy = ly + 2, cx = lx + 2;
-            v = m0[cy - 2][cx] | m0[cy + 2][cx];
-#pragma unroll
-            for (int ky = -1; ky <= 1; ky++)
-#pragma unroll
-                for (int kx = -2; kx <= 2; kx++) v |= m0[cy + ky][cx + kx];
-        }
-        m1[ly][lx] = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < TW * TH; i += 256) {   // erode; a wave is one row of the tile (TW = 64)
-        const int ly = i / TW, lx = i - ly * TW;
-        const int x = x0 + lx, y = y0 + ly;
-        const bool in = x < w && y < h;
-        const int cy = ly + 2, cx = lx + 2;
-        uint8_t v = m1[cy - 2][cx] & m1[cy + 2][cx];
-#pragma unroll
-        for (int ky = -1; ky <= 1; ky++)
-#pragma unroll
-            for (int kx = -2; kx <= 2; kx++) v &= m1[cy + ky][cx + kx];
-        if (bits) {                              // BitFrame layout (host side below): 64 pixels per word
-            const unsigned long long word = __ballot(in && v);
-            if (lx == 0 && in) bits[(size_t)(y + 1) * bpitch + (x0 >> 6) + 1] = word;
-        } else if (in) {
-            mask[(size_t)y * mstride + x] = v ? 255 : 0;
-        }
+    const int word = blockIdx.x * 16 + tid;
+    if (tid < 16 && word < wpr) {
+        const uint4 q = reinterpret_cast<const uint4*>(nib)[tid];
+        auto squeeze = [](uint32_t d) {          // four nibbles, one per byte -> 16 bits
+            return (d & 0xFu) | ((d >> 4) & 0xF0u) | ((d >> 8) & 0xF00u) | ((d >> 12) & 0xF000u);
+        };
+        const u64 lo = squeeze(q.x) | (squeeze(q.y) << 16), hi = squeeze(q.z) | (squeeze(q.w) << 16);
+        T[(size_t)y * wpr + word] = lo | (hi << 32);
     }
 }
 
-static_assert(TW == 64, "one wave per tile row");
+constexpr int MC_ROWS = 56;      // rows a wave of the morphology pass owns (lanes 4..59; halo 4 above and below)
 
-// Either d_mask (0 / 255 bytes) or d_bits (a zero-framed BitFrame of pitch bpitch words) receives the result.
-int launch_content_mask(const uint8_t* d_src, size_t stride, int w, int h, int cn, uint8_t* d_mask, size_t mstride,
-                        unsigned long long* d_bits, int bpitch, hipStream_t st) {
-    if (!d_src || (!d_mask && !d_bits) || w <= 0 || h <= 0 || (cn != 1 && cn != 3)) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
-    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH);
-    if (grid.y > 65535) { set_last_error("content_mask: image too tall"); return VS_ERR_INVALID_ARG; }
-    if (cn == 3) hipLaunchKernelGGL(content_mask_kernel<3>, grid, dim3(256), 0, st, d_src, stride, w, h, d_mask, mstride, d_bits, bpitch);
-    else hipLaunchKernelGGL(content_mask_kernel<1>, grid, dim3(256), 0, st, d_src, stride, w, h, d_mask, mstride, d_bits, bpitch);
+// OR / AND of a row with itself moved by -2..2 pixels; l, r: the words left and right of it
+__device__ __forceinline__ u64 spread5(u64 l, u64 t, u64 r) {
+    return t | (t << 1) | (l >> 63) | (t << 2) | (l >> 62) | (t >> 1) | (r << 63) | (t >> 2) | (r << 62);
+}
+__device__ __forceinline__ u64 shrink5(u64 l, u64 t, u64 r) {
+    return t & ((t << 1) | (l >> 63)) & ((t << 2) | (l >> 62)) & ((t >> 1) | (r << 63)) & ((t >> 2) | (r << 62));
+}
+__device__ __forceinline__ u64 row_from(u64 v, int d, int lane) {     // value of lane + d, zero past the wave
+    const u64 t = __shfl(v, lane + d);
+    return (unsigned)(lane + d) < 64u ? t : 0;
+}
+
+// Pass 2: MORPH_CLOSE with the 5x5 ellipse (rows -1..1 five wide, rows -2 and +2 the centre only) on the bit
+// plane: wave = one word column, lane = row, a row of 64 pixels one register.  Dilation sees zeros outside the
+// image, erosion ones (cv::morphologyEx border value).  The result goes out as a zero-framed BitFrame (host
+// side below) or, for vs_op_content_mask, as a plain bit plane that expand_bits_kernel turns into bytes.
+__global__ __launch_bounds__(64) void close5_bits_kernel(const u64* __restrict__ T, int wpr, int w, int h,
+                                                         u64* __restrict__ out, int opitch, int oframe) {
+    const int lane = threadIdx.x, k = blockIdx.x, y = blockIdx.y * MC_ROWS - 4 + lane;
+    const bool row_in = y >= 0 && y < h;
+    auto word_in = [&](int kk) { return kk >= 0 && kk < wpr; };
+    auto ones_outside = [&](int kk) -> u64 {        // bits of word kk that lie outside the image
+        if (!row_in || !word_in(kk)) return ~0ull;
+        const int left = w - 64 * kk;                // pixels of this word inside the image
+        return left >= 64 ? 0ull : ~0ull << left;
+    };
+    u64 t[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) t[j] = (row_in && word_in(k - 2 + j)) ? T[(size_t)y * wpr + k - 2 + j] : 0ull;
+    u64 d[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {                    // dilated words k-1, k, k+1
+        const u64 hrow = spread5(t[j], t[j + 1], t[j + 2]);
+        d[j] = row_from(hrow, -1, lane) | hrow | row_from(hrow, 1, lane) | row_from(t[j + 1], -2, lane) |
+               row_from(t[j + 1], 2, lane);
+        d[j] |= ones_outside(k - 1 + j);
+    }
+    // rows past the wave count as outside for the lanes that look at them; those lanes' results are not stored
+    const u64 erow = shrink5(d[0], d[1], d[2]);
+    auto and_from = [&](u64 v, int dd) { const u64 tv = __shfl(v, lane + dd); return (unsigned)(lane + dd) < 64u ? tv : ~0ull; };
+    u64 f = and_from(erow, -1) & erow & and_from(erow, 1) & and_from(d[1], -2) & and_from(d[1], 2);
+    f &= ~ones_outside(k);
+    if (row_in && lane >= 4 && lane < 4 + MC_ROWS) out[(size_t)(y + oframe) * opitch + k + oframe] = f;
+}
+
+__global__ __launch_bounds__(256) void expand_bits_kernel(const u64* __restrict__ F, int wpr, int w, int h,
+                                                          uint8_t* __restrict__ mask, size_t mstride) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < w && y < h) mask[(size_t)y * mstride + x] = (F[(size_t)y * wpr + (x >> 6)] >> (x & 63)) & 1 ? 255 : 0;
+}
+
+// d_T: scratch of ceil(w/64)*h words.  The closed mask goes to d_out with row pitch opitch words, shifted by
+// oframe rows and words (1 for a BitFrame whose frame is already zero, 0 for a plain bit plane).
+int launch_content_bits(const uint8_t* d_src, size_t stride, int w, int h, int cn, u64* d_T, u64* d_out, int opitch,
+                        int oframe, hipStream_t st) {
+    if (!d_src || !d_T || !d_out || w <= 0 || h <= 0 || (cn != 1 && cn != 3)) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
+    if (h > 65535) { set_last_error("content_mask: image too tall"); return VS_ERR_INVALID_ARG; }
+    const int wpr = (w + 63) / 64;
+    const int aligned = (((uintptr_t)d_src | stride) & 3) == 0;
+    dim3 g1((w + 1023) / 1024, h);
+    if (cn == 3) hipLaunchKernelGGL(threshold_bits_kernel<3>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr);
+    else hipLaunchKernelGGL(threshold_bits_kernel<1>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr);
+    dim3 g2(wpr, (h + MC_ROWS - 1) / MC_ROWS);
+    hipLaunchKernelGGL(close5_bits_kernel, g2, dim3(64), 0, st, d_T, wpr, w, h, d_out, opitch, oframe);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -135,7 +182,7 @@ struct BitFrame {
 // scan is inside a component already followed: a hole, or something within a hole).  Returns the number of
 // contours.
 int trace_largest(const BitFrame& bf, CropScratch& S) {
-    const int w = bf.w, h = bf.h, P = bf.pitch, W = w + 2;
+    const int h = bf.h, P = bf.pitch;
     const uint64_t* F = bf.F;
     // the mark planes start from zero: only the words the last call marked need wiping
     const size_t n_words = (size_t)P * (h + 2);
@@ -144,52 +191,59 @@ int trace_largest(const BitFrame& bf, CropScratch& S) {
     S.touched.clear();
     uint64_t* ML = S.ml.data();
     uint64_t* MR = S.mr.data();
-    auto word_of = [P](int x, int y) { return (size_t)(y + 1) * P + ((x + 64) >> 6); };
-    auto fg = [&](int x, int y) { return (F[word_of(x, y)] >> ((x + 64) & 63)) & 1; };
     // 8 directions counter-clockwise from east, image y pointing down (twice, so that a turn needs no wrap)
     static const int DX[16] = {1, 1, 0, -1, -1, -1, 0, 1, 1, 1, 0, -1, -1, -1, 0, 1};
     static const int DY[16] = {0, -1, -1, -1, 0, 1, 1, 1, 0, -1, -1, -1, 0, 1, 1, 1};
     S.best.clear(); S.chain_best.clear();
     int n_contours = 0;
 
+    // A pixel as one number: pos = (y + 1) * 64 P + x + 64, so that pos >> 6 is its word and pos & 63 its bit, and a
+    // step in direction d adds STEP[d].
+    const long long P64 = (long long)P * 64;
+    long long STEP[16];
+    for (int d = 0; d < 16; d++) STEP[d] = DY[d] * P64 + DX[d];
+    auto fg_at = [F](long long pos) { return (F[pos >> 6] >> (pos & 63)) & 1; };
+
     auto follow = [&](int sx, int sy) {
         S.cur.clear(); S.chain_cur.clear();
-        auto mark_right = [&](int x, int y) {
-            const size_t i = word_of(x, y); const uint64_t bit = 1ull << (x & 63);
+        auto mark_right = [&](long long pos) {
+            const size_t i = (size_t)(pos >> 6); const uint64_t bit = 1ull << (pos & 63);
             MR[i] |= bit; ML[i] &= ~bit;
             S.touched.push_back(i);
         };
-        auto mark_left_if_new = [&](int x, int y) {
-            const size_t i = word_of(x, y); const uint64_t bit = 1ull << (x & 63);
+        auto mark_left_if_new = [&](long long pos) {
+            const size_t i = (size_t)(pos >> 6); const uint64_t bit = 1ull << (pos & 63);
             if (!((ML[i] | MR[i]) & bit)) { ML[i] |= bit; S.touched.push_back(i); }
         };
+        const long long start = (sy + 1) * P64 + sx + 64;
         // first neighbour clockwise from west
         int dir = 4;
         bool alone = true;
         for (int k = 0; k < 7; k++) {
             dir = (dir + 7) & 7;
-            if (fg(sx + DX[dir], sy + DY[dir])) { alone = false; break; }
+            if (fg_at(start + STEP[dir])) { alone = false; break; }
         }
         if (alone) {
-            mark_right(sx, sy);
+            mark_right(start);
             S.cur.push_back({sx, sy});
-            S.chain_cur.push_back((sy + 1) * W + sx + 1);
+            S.chain_cur.push_back((sy << 16) | sx);
             return;
         }
-        const int x2 = sx + DX[dir], y2 = sy + DY[dir];
+        const long long second = start + STEP[dir];
+        long long at = start;
         int ax = sx, ay = sy, last_dir = dir ^ 4;
         while (true) {
             const int from = dir;
-            int nx, ny;
-            do { ++dir; nx = ax + DX[dir]; ny = ay + DY[dir]; } while (!fg(nx, ny));
-            dir &= 7;
-            const bool passed_east = (unsigned)(dir - 1) < (unsigned)from;
-            if (passed_east) mark_right(ax, ay);
-            else mark_left_if_new(ax, ay);
-            S.chain_cur.push_back((ay + 1) * W + ax + 1);
-            if (dir != last_dir) { S.cur.push_back({ax, ay}); last_dir = dir; }
-            if (nx == sx && ny == sy && ax == x2 && ay == y2) break;
-            ax = nx; ay = ny;
+            long long next;
+            do { next = at + STEP[++dir]; } while (!fg_at(next));
+            const bool passed_east = (unsigned)((dir & 7) - 1) < (unsigned)from;
+            if (passed_east) mark_right(at);
+            else mark_left_if_new(at);
+            S.chain_cur.push_back((ay << 16) | ax);
+            if ((dir & 7) != last_dir) { S.cur.push_back({ax, ay}); last_dir = dir & 7; }
+            if (next == start && at == second) break;
+            ax += DX[dir]; ay += DY[dir];
+            at = next;
             dir = (dir + 4) & 7;
         }
     };
@@ -197,20 +251,27 @@ int trace_largest(const BitFrame& bf, CropScratch& S) {
     const int wpr = P - 2;
     for (int y = 0; y < h; y++) {
         const size_t r = (size_t)(y + 1) * P + 1;
-        int last_mark = 0;                       // kind of the last mark met on this row: 0 none, 1 ML, 2 MR
+        // kind of the last mark on this row before the scan position (0 none, 1 ML, 2 MR), brought up to date only
+        // when a candidate asks for it: most rows have none, and then the mark planes are not read at all
+        int last_mark = 0, marks_upto = 0;           // words [0, marks_upto) are accounted for in last_mark
         uint64_t west = 0;                       // the pixel left of the word (bit 0)
         for (int k = 0; k < wpr; k++) {
             const uint64_t f = F[r + k];
             if (f == 0) { west = 0; continue; }          // no pixels, hence no marks
-            uint64_t begins = f & ~((f << 1) | west);    // mask pixels with background to their west
+            const uint64_t begins = f & ~((f << 1) | west);    // mask pixels with background to their west
             west = f >> 63;
+            if (begins == 0) continue;
             uint64_t cand = begins & ~(ML[r + k] | MR[r + k]);
             while (cand) {
+                for (; marks_upto < k; marks_upto++) {
+                    const uint64_t ml = ML[r + marks_upto], mr = MR[r + marks_upto];
+                    if (ml | mr) last_mark = ml > mr ? 1 : 2;     // the higher bit is the later pixel
+                }
                 const int b = __builtin_ctzll(cand);
                 const uint64_t below = (1ull << b) - 1;
                 const uint64_t ml = ML[r + k] & below, mr = MR[r + k] & below;
                 int kind = last_mark;
-                if (ml | mr) kind = ml > mr ? 1 : 2;     // the higher bit is the later pixel
+                if (ml | mr) kind = ml > mr ? 1 : 2;
                 if (kind != 1) {
                     ++n_contours;
                     follow(k * 64 + b, y);
@@ -220,8 +281,6 @@ int trace_largest(const BitFrame& bf, CropScratch& S) {
                 const uint64_t above = b == 63 ? 0 : ~((2ull << b) - 1);
                 cand = begins & ~(ML[r + k] | MR[r + k]) & above;
             }
-            const uint64_t ml = ML[r + k], mr = MR[r + k];
-            if (ml | mr) last_mark = ml > mr ? 1 : 2;
         }
     }
     return n_contours;
@@ -246,14 +305,13 @@ BitFrame pack_mask(const uint8_t* mask, int w, int h, size_t stride, CropScratch
 // themselves.  Nothing of the size of the image is written: the shrink loop below only asks how many pixels
 // of a row / column segment are NOT filled.
 void fill_spans(int w, int h, CropScratch& S, std::vector<uint8_t>* dump) {
-    const int W = w + 2;
     typedef CropScratch::Span Span;
     S.rows.resize(h); S.spans.resize(h);
     for (int y = 0; y < h; y++) { S.rows[y].clear(); S.spans[y].clear(); }
     const size_t n = S.chain_best.size();
     for (size_t i = 0; i < n; i++) {
-        const int a = S.chain_best[i], b = S.chain_best[(i + 1) % n];
-        const int ay = a / W - 1, ax = a % W - 1, by = b / W - 1, bx = b % W - 1;
+        const int a = S.chain_best[i], b = S.chain_best[i + 1 < n ? i + 1 : 0];
+        const int ay = a >> 16, ax = a & 0xFFFF, by = b >> 16, bx = b & 0xFFFF;
         S.spans[ay].push_back(Span{ax, ax});
         if (ay == by) continue;
         if (ay < by) S.rows[ay].push_back(ax); else S.rows[by].push_back(bx);
@@ -363,6 +421,7 @@ struct vs_azc {
     std::string err;
     uint8_t* d_mask = nullptr;
     uint8_t* h_mask = nullptr;        // pinned; both hold the mask as a BitFrame
+    u64* d_tbits = nullptr;           // thresholded bit plane, before the closing
     uint8_t* d_in = nullptr;
     uint8_t* d_out = nullptr;
     int mask_w = 0, mask_h = 0;       // the size d_mask / h_mask (a BitFrame) are laid out for
@@ -381,16 +440,35 @@ struct vs_azc {
 
 extern "C" {
 
+// The mask as 0 / 255 bytes (the form cv::threshold / cv::morphologyEx hand on); scratch for the two bit planes is
+// kept between calls.
 int vs_op_content_mask(const void* d_src, size_t stride, int w, int h, int cn, void* d_mask, size_t mask_stride,
                        void* stream) {
     VS_TRY(ensure_device());
-    return launch_content_mask((const uint8_t*)d_src, stride, w, h, cn, (uint8_t*)d_mask, mask_stride, nullptr, 0,
-                               (hipStream_t)stream);
+    if (!d_mask || w <= 0 || h <= 0 || mask_stride < (size_t)w) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
+    static std::mutex mu;
+    static u64* planes = nullptr;
+    static size_t plane_words = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    const int wpr = (w + 63) / 64;
+    const size_t words = (size_t)wpr * h;
+    hipStream_t st = (hipStream_t)stream;
+    if (plane_words < words) {
+        if (planes) { VS_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(planes); planes = nullptr; plane_words = 0; }
+        VS_HIP_TRY(hipMalloc((void**)&planes, 2 * words * 8));
+        plane_words = words;
+    }
+    VS_TRY(launch_content_bits((const uint8_t*)d_src, stride, w, h, cn, planes, planes + plane_words, wpr, 0, st));
+    dim3 grid((w + 255) / 256, h);
+    hipLaunchKernelGGL(expand_bits_kernel, grid, dim3(256), 0, st, planes + plane_words, wpr, w, h, (uint8_t*)d_mask, mask_stride);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
 }
 
 // Host logic only (no device needed): :141-228 on a host mask.
 int vs_azc_crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, int32_t* info, uint8_t* filled_out) {
     if (!mask || !info || w <= 0 || h <= 0 || stride < (size_t)w) return VS_ERR_INVALID_ARG;
+    if (w > 65535 || h > 32767) { set_last_error("auto zoom/crop: image too large"); return VS_ERR_INVALID_ARG; }
     static thread_local CropScratch S;       // kept between calls, as the vs_azc object keeps its own
     std::vector<uint8_t> filled;
     crop_from_mask(pack_mask(mask, w, h, stride, S), S, info, filled_out ? &filled : nullptr);
@@ -421,6 +499,7 @@ void vs_azc_destroy(vs_azc* a) {
     if (a->st) (void)hipStreamSynchronize(a->st);
     if (a->d_mask) (void)hipFree(a->d_mask);
     if (a->h_mask) (void)hipHostFree(a->h_mask);
+    if (a->d_tbits) (void)hipFree(a->d_tbits);
     if (a->d_in) (void)hipFree(a->d_in);
     if (a->d_out) (void)hipFree(a->d_out);
     if (a->st) (void)hipStreamDestroy(a->st);
@@ -444,20 +523,22 @@ int vs_azc_sync(vs_azc* a) {
 
 // Mask on the device, contour logic on the host: fills a->info (:111-228).
 static int azc_plan(vs_azc* a, const void* d_data, int w, int h, size_t stride, int cn) {
+    if (w > 65535 || h > 32767) { a->err = "auto zoom/crop: image too large"; set_last_error(a->err); return VS_ERR_INVALID_ARG; }
     const size_t mb = BitFrame::words_for(w, h) * 8;
     if (a->mask_w != w || a->mask_h != h) {
         if (a->d_mask) (void)hipFree(a->d_mask);
         if (a->h_mask) (void)hipHostFree(a->h_mask);
-        a->d_mask = a->h_mask = nullptr; a->mask_w = a->mask_h = 0;
+        if (a->d_tbits) (void)hipFree(a->d_tbits);
+        a->d_mask = a->h_mask = nullptr; a->d_tbits = nullptr; a->mask_w = a->mask_h = 0;
         A_HIP(a, hipMalloc((void**)&a->d_mask, mb));
+        A_HIP(a, hipMalloc((void**)&a->d_tbits, (size_t)((w + 63) / 64) * h * 8));
         A_HIP(a, hipHostMalloc((void**)&a->h_mask, mb, hipHostMallocDefault));
         A_HIP(a, hipMemsetAsync(a->d_mask, 0, mb, a->st));          // the frame; the kernel rewrites the inside
         a->mask_w = w; a->mask_h = h;
     }
     BitFrame bf;
     bf.w = w; bf.h = h; bf.pitch = BitFrame::pitch_for(w); bf.F = (const uint64_t*)a->h_mask;
-    A_TRY(a, launch_content_mask((const uint8_t*)d_data, stride, w, h, cn, nullptr, 0, (unsigned long long*)a->d_mask,
-                                 bf.pitch, a->st));                                                   // :111-139
+    A_TRY(a, launch_content_bits((const uint8_t*)d_data, stride, w, h, cn, a->d_tbits, (u64*)a->d_mask, bf.pitch, 1, a->st));   // :111-139
     A_HIP(a, hipMemcpyAsync(a->h_mask, a->d_mask, mb, hipMemcpyDeviceToHost, a->st));                 // :142-143
     A_HIP(a, hipStreamSynchronize(a->st));
     crop_from_mask(bf, a->scratch, a->info, nullptr);                                                 // :146-228
