@@ -204,6 +204,13 @@ def test_host_crop_logic_matches_oracle(oracle, vs):
         blobs[rng.random(blobs.shape) < 0.03] ^= 255
         masks.append(blobs)
     masks.append(np.full((5, 192), 255, np.uint8))
+    for w, bw in ((300, 40), (517, 70), (700, 130)):        # long straight edges: the word-at-a-time stretch of the follower
+        blobs = np.kron((rng.random((6, (w + bw - 1) // bw)) < 0.6).astype(np.uint8), np.ones((12, bw), np.uint8))[:, :w] * 255
+        masks.append(blobs.copy())
+        blobs[rng.random(blobs.shape) < 0.004] ^= 255
+        masks.append(blobs)
+        masks.append(np.pad(np.full((20, w - 2), 255, np.uint8), 1))
+    masks.append(np.full((40, 400), 255, np.uint8))
     for m in masks:
         ref = oracle.azc_crop_rect(m)
         got, filled = vs.azc_crop_from_mask(m, want_filled=True)
