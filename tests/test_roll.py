@@ -215,6 +215,34 @@ def test_roll_correct_matches_oracle(gpu, oracle, size, slope):
 
 
 @pytest.mark.gpu
+def test_roll_correct_when_the_edge_growth_needs_many_passes(gpu, oracle):
+    """The roll stage builds its line search on the edge map of the first four hysteresis passes and redoes it
+    when the growth had not ended by then: a weak serpentine with one strong spot needs dozens of passes."""
+    h, w = 400, 300
+    g = np.full((h, w), 100, np.uint8)
+    xs = list(range(10, w - 20, 24))
+    for i, x in enumerate(xs):
+        g[20:h - 20, x:x + 6] = 112
+        if i + 1 < len(xs):
+            y = h - 26 if i % 2 == 0 else 20
+            g[y:y + 6, x:x + 30] = 112
+    g[20:26, 10:16] = 230
+    f = np.repeat(g[:, :, None], 3, axis=2)
+    kw = dict(scale_factor=1.0, canny_threshold_low=20, canny_threshold_high=100, hough_threshold=60,
+              angle_filter_min=-100.0, angle_filter_max=100.0)
+    ro, rg = oracle.roll_correction(oracle.roll_params(**kw)), gpu.roll_correction(gpu.roll_params(**kw))
+    for _ in range(2):
+        a, b = ro.correct(f), rg.correct(f)
+        assert ro.state() == rg.state()
+        assert np.array_equal(a, b)
+    assert ro.state()[2] > 4                                   # the long bars were found as lines: the full edge map was used
+    weak = f.copy()
+    weak[20:26, 10:16] = 112
+    ro2, rg2 = oracle.roll_correction(oracle.roll_params(**kw)), gpu.roll_correction(gpu.roll_params(**kw))
+    assert np.array_equal(ro2.correct(weak), rg2.correct(weak)) and ro2.state() == rg2.state() and ro2.state()[2] == 0
+
+
+@pytest.mark.gpu
 def test_roll_device_entry_point(gpu, oracle):
     from vsamd.capi import DevBuf
     f = roll_scene.horizon_frame(640, 360, 45, seed=2)

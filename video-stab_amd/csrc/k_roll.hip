@@ -11,15 +11,17 @@
 //   canny_hyst_band_kernel  growth of the edge set through the "maybe" pixels on the bit planes: a band
 //                     of 62 rows x up to 1024 pixels is iterated to its own fixed point in registers
 //                     (wave = word, lane = row); passes over the image repeat until a pass changes
-//                     nothing (chains that cross band borders; the host reads one flag word per group
-//                     of passes)
-//   hough_accum_kernel  votes of every (edge pixel, angle) pair, float rho as cv::HoughLines
+//                     nothing (chains that cross band borders)
+//   edge_list_kernel  edge pixels as a packed list, one atomic per wave
+//   hough_accum_lds_kernel  one workgroup per angle, that angle's accumulator row in LDS; float rho as
+//                     cv::HoughLines
 //   hough_peaks_kernel  local maxima above the threshold -> (votes, index) keys
 //   hough_select_kernel ONE workgroup: bitonic sort (votes desc, index asc) and the
 //                     sequential angle filter / mean of RollCorrection.cpp:109-125
 //   warp_affine_kernel<3> with BORDER_REPLICATE (k_warp.hip) for the rotation.
-// The smoothed angle (EMA, clamp, decay) is host state of the vs_roll object; it needs
-// one 24-byte read-back per frame (the reference synchronises several times per frame).
+// The smoothed angle (EMA, clamp, decay) is host state of the vs_roll object; a frame needs ONE wait of the host:
+// the 24-byte result comes back together with the flag that says whether four hysteresis passes were enough
+// (if not, the growth is finished and the line search redone; the reference synchronises several times per frame).
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -382,6 +384,7 @@ struct RollWork {
     unsigned long long* keys = nullptr;
     float* lines = nullptr;
     int* counters = nullptr;
+    int* hflags = nullptr;               // hysteresis pass flags (16 words after the counters)
     RollResult* res = nullptr;
     size_t accum_bytes = 0;
 };
@@ -405,14 +408,14 @@ static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hi
     const size_t o_E = take((size_t)k.wpr * h * 8), o_C = take((size_t)k.wpr * h * 8);
     const size_t o_queue = take(npx * 4 + 64), o_list = take(npx * 4 + 64), o_accum = take(k.accum_bytes);
     const size_t o_sin = take((size_t)k.geom.numangle * 4), o_cos = take((size_t)k.geom.numangle * 4);
-    const size_t o_keys = take((size_t)HOUGH_CAP * 8), o_lines = take((size_t)HOUGH_CAP * 8), o_cnt = take(64), o_res = take(64);
+    const size_t o_keys = take((size_t)HOUGH_CAP * 8), o_lines = take((size_t)HOUGH_CAP * 8), o_cnt = take(128), o_res = take(64);
     VS_HIP_TRY(hipMalloc((void**)&k.base, off));
     VS_HIP_TRY(hipMemsetAsync(k.base, 0, off, st));
     uint8_t* b = k.base;
     k.gray = b + o_gray; k.edges = b + o_edges; k.dxy = (short2*)(b + o_dxy); k.mag = (int*)(b + o_mag);
     k.E = (unsigned long long*)(b + o_E); k.C = (unsigned long long*)(b + o_C); k.queue = (int*)(b + o_queue); k.list = (int*)(b + o_list); k.accum = (int*)(b + o_accum);
     k.tabSin = (float*)(b + o_sin); k.tabCos = (float*)(b + o_cos); k.keys = (unsigned long long*)(b + o_keys);
-    k.lines = (float*)(b + o_lines); k.counters = (int*)(b + o_cnt); k.res = (RollResult*)(b + o_res);
+    k.lines = (float*)(b + o_lines); k.counters = (int*)(b + o_cnt); k.hflags = k.counters + 16; k.res = (RollResult*)(b + o_res);
     // the frame of mag stays 0; its interior and the bit planes are rewritten every frame
     // createTrigTable: float angle accumulation, sin/cos in double (host libm, as the oracle)
     std::vector<float> ts(k.geom.numangle), tc(k.geom.numangle);
@@ -428,9 +431,45 @@ static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hi
     return VS_OK;
 }
 
-// cv::Canny(gray, edges, low, high, 3, false) on device buffers
+// One group of hysteresis passes: one flag word per pass (k.hflags), the first pass of a group runs always, a later
+// one returns at once when the pass before it changed nothing.
+static int hyst_group(RollWork& k, int group, hipStream_t st) {
+    const int nwv = k.wpr < HB_WORDS ? k.wpr : HB_WORDS;
+    dim3 hg((k.wpr + nwv - 1) / nwv, (k.h + HB_ROWS - 1) / HB_ROWS);
+    VS_HIP_TRY(hipMemsetAsync(k.hflags, 0, 64, st));
+    for (int p = 0; p < group; p++)
+        hipLaunchKernelGGL(canny_hyst_band_kernel, hg, dim3(64 * nwv), 0, st, k.E, k.C, k.wpr, k.h, k.hflags + p,
+                           p ? k.hflags + p - 1 : (int*)nullptr);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// Passes in groups of 8, 16, 16, ... after a first group of 4 whose last pass still changed something; the flags are
+// read back per group.
+static int hyst_finish(RollWork& k, hipStream_t st) {
+    int32_t flags[16];
+    for (int group = 8;; group = 16) {
+        VS_TRY(hyst_group(k, group, st));
+        VS_HIP_TRY(hipMemcpyAsync(flags, k.hflags, 64, hipMemcpyDeviceToHost, st));
+        VS_HIP_TRY(hipStreamSynchronize(st));
+        if (!flags[group - 1]) return VS_OK;
+    }
+}
+
+// cv::Canny(gray, edges, low, high, 3, false) on device buffers.  With `unchecked` the edge map is written after
+// the first group of four hysteresis passes without asking whether the growth had ended: the caller reads
+// k.hflags[3] together with its own results and, if it is set, calls hyst_finish and canny_emit and redoes what it
+// built on the edge map (the roll stage does; four passes are enough for nearly every frame, and this saves a round
+// trip to the host per frame).
+static int canny_emit(RollWork& k, uint8_t* d_edges, size_t estride, hipStream_t st) {
+    dim3 grid((k.w + NT - 1) / NT, k.h);
+    hipLaunchKernelGGL(canny_out_kernel, grid, dim3(NT), 0, st, k.E, k.wpr, k.w, k.h, d_edges, estride);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
 static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double low_t, double high_t, uint8_t* d_edges,
-                     size_t estride, hipStream_t st) {
+                     size_t estride, hipStream_t st, bool unchecked = false) {
     if (low_t > high_t) std::swap(low_t, high_t);
     const int low = (int)std::floor(low_t), high = (int)std::floor(high_t);
     const int w = k.w, h = k.h;
@@ -438,26 +477,14 @@ static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double l
     hipLaunchKernelGGL(sobel_kernel, grid, dim3(NT), 0, st, d_gray, stride, w, h, k.dxy, k.mag, k.mw);
     hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.E, k.C, k.wpr);
     VS_HIP_TRY(hipGetLastError());
-    // hysteresis: passes in groups of 4, 8, 16, 16, ...; one flag word per pass, read back per group.  A pass
-    // that changed nothing ends the growth: the later passes of its group see its flag and return at once.
-    {
-        const int nwv = k.wpr < HB_WORDS ? k.wpr : HB_WORDS;
-        dim3 hg((k.wpr + nwv - 1) / nwv, (h + HB_ROWS - 1) / HB_ROWS);
-        int32_t flags[16];
-        for (int group = 4;; group = group < 16 ? group * 2 : 16) {
-            VS_HIP_TRY(hipMemsetAsync(k.counters, 0, 64, st));
-            for (int p = 0; p < group; p++)
-                hipLaunchKernelGGL(canny_hyst_band_kernel, hg, dim3(64 * nwv), 0, st, k.E, k.C, k.wpr, h, k.counters + p,
-                                   p ? k.counters + p - 1 : (int*)nullptr);
-            VS_HIP_TRY(hipGetLastError());
-            VS_HIP_TRY(hipMemcpyAsync(flags, k.counters, 64, hipMemcpyDeviceToHost, st));
-            VS_HIP_TRY(hipStreamSynchronize(st));
-            if (!flags[group - 1]) break;
-        }
+    VS_TRY(hyst_group(k, 4, st));
+    if (!unchecked) {
+        int32_t flag = 0;
+        VS_HIP_TRY(hipMemcpyAsync(&flag, k.hflags + 3, 4, hipMemcpyDeviceToHost, st));
+        VS_HIP_TRY(hipStreamSynchronize(st));
+        if (flag) VS_TRY(hyst_finish(k, st));
     }
-    hipLaunchKernelGGL(canny_out_kernel, grid, dim3(NT), 0, st, k.E, k.wpr, w, h, d_edges, estride);
-    VS_HIP_TRY(hipGetLastError());
-    return VS_OK;
+    return canny_emit(k, d_edges, estride, st);
 }
 
 // cv::HoughLines(edges, lines, rho, theta, threshold) + the angle statistics of the roll stage
@@ -641,11 +668,20 @@ int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t str
     RollWork& k = r->wk;
     // resize + BGR2GRAY (:41,:51), Canny (:54-61), HoughLines (:66-73), angle statistics (:106-119)
     R_TRY(r, launch_resize_gray((const uint8_t*)d_data, stride, w, h, VS_FMT_BGR8, k.gray, sw, sw, sh, r->st));
-    R_TRY(r, run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, k.edges, sw, r->st));
+    R_TRY(r, run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, k.edges, sw, r->st, /*unchecked=*/true));
     R_TRY(r, run_hough(k, k.edges, sw, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, r->st));
     RollResult res;
+    int32_t growing = 0;
     R_HIP(r, hipMemcpyAsync(&res, k.res, sizeof res, hipMemcpyDeviceToHost, r->st));
+    R_HIP(r, hipMemcpyAsync(&growing, k.hflags + 3, 4, hipMemcpyDeviceToHost, r->st));
     R_HIP(r, hipStreamSynchronize(r->st));
+    if (growing) {          // the edge set was still growing after four passes: finish it and redo the line search
+        R_TRY(r, hyst_finish(k, r->st));
+        R_TRY(r, canny_emit(k, k.edges, sw, r->st));
+        R_TRY(r, run_hough(k, k.edges, sw, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, r->st));
+        R_HIP(r, hipMemcpyAsync(&res, k.res, sizeof res, hipMemcpyDeviceToHost, r->st));
+        R_HIP(r, hipStreamSynchronize(r->st));
+    }
     r->last_lines = res.n_lines; r->last_used = res.count; r->last_detected = 0.0;
     if (res.n_lines == 0 || res.count == 0) {
         r->smoothed *= p.angle_decay;                                                             // :76-77,:122-123
