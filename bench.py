@@ -30,11 +30,18 @@ from vsamd import capi, dist as vsdist, synth  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
 
 
-def make_params(vs):
+def make_params(vs, config=None):
     # BASELINE.json configs[1]: 200 corners, 3-level LK (maxLevel 2) with a 21x21 window;
     # everything else is the reference's live default (Stabilizer.h:76-175, Stabilizer.cpp:611-649).
-    return vs.params(max_corners=200, lk_win_size=21, lk_max_level=2, lk_max_iters=20, lk_epsilon=0.03,
-                     smoothing_radius=30)
+    p = vs.params(max_corners=200, lk_win_size=21, lk_max_level=2, lk_max_iters=20, lk_epsilon=0.03,
+                  smoothing_radius=30)
+    if config:
+        # the "stabilizer" section of a config.yaml of the reference's apps on top of that (vs_config_read_stab;
+        # keys the file does not name keep the values above)
+        p, present = capi.Config(vs, path=config).stab_params(base=p)
+        if not present:
+            raise SystemExit("bench.py: %s has no 'stabilizer' section" % config)
+    return p
 
 
 def clip_order(n_frames, n_steps):
@@ -101,6 +108,9 @@ def main():
                     help="batch mode: analysis stages of this many consecutive pushes run as one launch each (1 = per-frame pipeline)")
     ap.add_argument("--warp-batch", type=int, default=8,
                     help="deferred output: results of this many consecutive pushes are warped by one launch (1 = one launch per push)")
+    ap.add_argument("--config", default=None,
+                    help="a config.yaml of the reference's apps: its 'stabilizer' section replaces the configs[1] "
+                         "parameters (not the headline workload any more: no cpu_baseline, the workload string says so)")
     ap.add_argument("--fanout", action="store_true",
                     help="N > 1 only: rank 0 owns ingest - it generates the clips of ALL streams and scatters them to the "
                          "owning ranks (RCCL send/recv over xGMI) before the timed region; timed separately, reported as `fanout`")
@@ -167,7 +177,7 @@ def main():
     WB = max(1, min(32, args.warp_batch if BT == 1 else BT))
     NOUT = max(2 * WB, 3 * BT)        # a result stays untouched until its batch and the next one have been issued
     d_out = [[capi.DevBuf(vs, fb) for _ in range(NOUT)] for _ in range(S)]
-    stabs = [vs.stabilizer(make_params(vs), device=local_rank) for _ in range(S)]
+    stabs = [vs.stabilizer(make_params(vs, args.config), device=local_rank) for _ in range(S)]
     for s in stabs:
         s.set_batch(BT)
         s.set_zero_copy(bool(args.zero_copy))
@@ -252,8 +262,11 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d stream(s)/GPU %dx%d BGR8, 200 corners, 3-level LK 21x21, "
-                                   "RANSAC partial affine, warpAffine; frames resident in HBM" % (S, W, H),
+            "config": {"workload": ("configs[1]: %d stream(s)/GPU %dx%d BGR8, 200 corners, 3-level LK 21x21, "
+                                    "RANSAC partial affine, warpAffine; frames resident in HBM" % (S, W, H))
+                       if not args.config else
+                       ("custom: %d stream(s)/GPU %dx%d BGR8, stabilizer parameters from %s; frames resident in HBM"
+                        % (S, W, H, os.path.basename(args.config))),
                        "streams_per_gpu": S, "batch": BT, "warp_batch": WB, "zero_copy": bool(args.zero_copy),
                        "timed_frames_per_rank": [int(r[1]) for r in per_rank]},
             "roofline": {"bound": "hbm", "kernel": "warp_affine_kernel<3>", "achieved": round(achieved, 1),
@@ -268,7 +281,7 @@ def main():
             names = ["copy_in", "gray", "pyramid", "lk", "ransac", "traj", "gftt", "warp"]
             out["stage_us_per_launch"] = {names[k]: round(stage_ms[k] / max(stage_n[k], 1) * 1e3, 2) for k in range(8)}
             out["stage_launches"] = {names[k]: stage_n[k] for k in range(8)}
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and not args.config:
             out["cpu_baseline"] = cpu_baseline(W, H, clips[0], clip_order)
         print(json.dumps(out), flush=True)
 

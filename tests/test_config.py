@@ -233,3 +233,20 @@ def test_cpp_face_compiles_and_reads_like_the_mains(vs, tmp_path):
     path.write_text(CONFIG)
     r = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "config ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_example_config_and_bench_option(vs):
+    """The shipped example parses and gives the library defaults; bench.py takes a config file for its parameters."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = capi.Config(vs, path=os.path.join(root, "video-stab_amd", "config.example.yaml"))
+    p, present = c.stab_params()
+    d = vs.params()
+    assert present and (p.smoothing_radius, p.max_corners, p.min_distance, p.block_size) == \
+        (d.smoothing_radius, d.max_corners, d.min_distance, d.block_size)
+    assert c.roll_params()[0].hough_threshold == vs.roll_params().hough_threshold and c.get_int("mode.stabilizer_enabled") == 1
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    q = bench.make_params(vs, os.path.join(root, "video-stab_amd", "config.example.yaml"))
+    assert (q.max_corners, q.lk_win_size, q.smoothing_radius) == (200, 21, 30)
