@@ -227,7 +227,8 @@ def test_host_crop_logic_full_hd(oracle, vs):
 
 # ------------------------------------------------------------------ HIP parity (GPU)
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,cn", [((270, 480), 3), ((101, 67), 3), ((64, 64), 1), ((5, 7), 3), ((1080, 1920), 3)])
+@pytest.mark.parametrize("shape,cn", [((270, 480), 3), ((101, 67), 3), ((64, 64), 1), ((5, 7), 3), ((1080, 1920), 3),
+                                      ((33, 70), 1), ((40, 1030), 3), ((9, 1025), 1), ((120, 129), 3), ((57, 64), 3)])
 def test_content_mask_bit_exact(gpu, oracle, shape, cn):
     rng = np.random.default_rng(shape[0] * 7 + cn)
     h, w = shape
