@@ -219,6 +219,14 @@ void crop_from_mask(const BitFrame& bf, CropScratch& S, int32_t info[8], std::ve
         }
         return zeros;
     };
+    // The rectangle only shrinks: while a side keeps its column, its count changes by the rows that left the range.
+    struct ColCache { int x = -1, ya = 0, yb = 0, zeros = 0; } lcache, rcache;
+    auto col_cached = [&](ColCache& c, int x, int ya, int yb) {
+        if (c.x == x && ya >= c.ya && yb <= c.yb && ya <= yb) c.zeros -= col_zeros(x, c.ya, ya) + col_zeros(x, yb, c.yb);
+        else c.zeros = col_zeros(x, ya, yb);
+        c.x = x; c.ya = ya; c.yb = yb;
+        return c.zeros;
+    };
     size_t lo_x = 0, hi_x = S.sx.size() - 1, lo_y = 0, hi_y = S.sy.size() - 1;
     int bx = 0, by = 0, bw = 0, bh = 0, iters = 0;
     while (lo_x < hi_x && lo_y < hi_y) {
@@ -226,7 +234,7 @@ void crop_from_mask(const BitFrame& bf, CropScratch& S, int32_t info[8], std::ve
         ++iters;
         if (bw <= 0 || bh <= 0) break;              // degenerate rectangle: nothing to test
         const int top = row_zeros(by, bx, bx + bw), bottom = row_zeros(by + bh - 1, bx, bx + bw);
-        const int left = col_zeros(bx, by, by + bh), right = col_zeros(bx + bw - 1, by, by + bh);
+        const int left = col_cached(lcache, bx, by, by + bh), right = col_cached(rcache, bx + bw - 1, by, by + bh);
         if (!(top | bottom | left | right)) break;
         // which side gives way (AutoZoomCrop.cpp:57-77)
         bool mv_top = false, mv_bottom = false, mv_left = false, mv_right = false;
