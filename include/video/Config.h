@@ -50,10 +50,12 @@ public:
     operator double() const { double v = 0; if (c_) vs_config_get_double(c_.get(), path_.c_str(), &v); return v; }
     operator std::string() const { return string(); }
     std::string string() const {
-        char buf[4096];
-        buf[0] = 0;
-        if (c_) vs_config_get_string(c_.get(), path_.c_str(), buf, sizeof buf);
-        return buf;
+        if (!c_) return std::string();
+        std::string buf(256, '\0');
+        // the C entry point refuses a buffer that is too small: grow until the value fits
+        while (vs_config_get_string(c_.get(), path_.c_str(), &buf[0], buf.size()) != VS_OK && buf.size() < (1u << 24))
+            buf.assign(buf.size() * 4, '\0');
+        return std::string(buf.c_str());
     }
     /// Element of a sequence of numbers, e.g. node["roi"].at(2).
     double at(int index) const { double v = 0; if (c_) vs_config_seq_get_double(c_.get(), path_.c_str(), index, &v); return v; }

@@ -37,6 +37,16 @@ int main(int argc, char** argv) {
     CHECK(stabParams.smoothingRadius == 15 && stabParams.borderType == "reflect_101" && !stabParams.cropNZoom);
     CHECK(fs["nothing"].empty() && fs["nothing"]["deeper"].empty());
 
+    // strings longer than any fixed buffer
+    {
+        vs::ConfigFile big;
+        const std::string longpath(9000, 'p');
+        CHECK(big.parse("model_path: \"" + longpath + "\"\n"));
+        std::string got;
+        big["model_path"] >> got;
+        CHECK(got == longpath);
+    }
+
     // the bundled loader
     vs::AppConfig cfg;
     cfg.stabilizer.stageOneRadius = 77;                           // not in the file: must survive
