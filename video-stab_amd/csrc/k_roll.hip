@@ -12,7 +12,8 @@
 //                     of 62 rows x up to 1024 pixels is iterated to its own fixed point in registers
 //                     (wave = word, lane = row); passes over the image repeat until a pass changes
 //                     nothing (chains that cross band borders)
-//   edge_list_kernel  edge pixels as a packed list, one atomic per wave
+//   edge_list_bits_kernel  edge pixels as a packed list straight from the bit plane, one atomic per wave
+//                     (edge_list_kernel: the same from a byte edge map, for vs_op_hough_lines)
 //   hough_accum_lds_kernel  one workgroup per angle, that angle's accumulator row in LDS; float rho as
 //                     cv::HoughLines
 //   hough_peaks_kernel  local maxima above the threshold -> (votes, index) keys
@@ -229,6 +230,31 @@ __global__ __launch_bounds__(NT) void edge_list_kernel(const uint8_t* __restrict
         const int k = __builtin_ctz(on);
         on &= on - 1;
         list[base++] = (y << 16) | (x0 + k);
+    }
+}
+
+// The same list straight from the Canny bit plane E (the roll stage never needs the edge map as bytes): a lane
+// takes one word of 64 pixels.
+__global__ __launch_bounds__(NT) void edge_list_bits_kernel(const u64* __restrict__ E, int wpr, int h,
+                                                            int* __restrict__ list, int* __restrict__ counters) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    u64 m = idx < wpr * h ? E[idx] : 0ull;
+    const int mine = __popcll(m);
+    if (__ballot(mine != 0) == 0) return;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d *= 2) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    int base = 0;
+    if (lane == 63) base = atomicAdd(&counters[1], incl);
+    base = __shfl(base, 63) + incl - mine;
+    const int y = idx / wpr, x0 = (idx - y * wpr) * 64;
+    while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        list[base++] = (y << 16) | (x0 + b);
     }
 }
 
@@ -484,7 +510,7 @@ static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double l
         VS_HIP_TRY(hipStreamSynchronize(st));
         if (flag) VS_TRY(hyst_finish(k, st));
     }
-    return canny_emit(k, d_edges, estride, st);
+    return d_edges ? canny_emit(k, d_edges, estride, st) : VS_OK;
 }
 
 // cv::HoughLines(edges, lines, rho, theta, threshold) + the angle statistics of the roll stage
@@ -493,8 +519,13 @@ static int run_hough(RollWork& k, const uint8_t* d_edges, size_t estride, int th
     const int w = k.w, h = k.h;
     if (w > 65535 || h > 32767) { set_last_error("hough: image too large"); return VS_ERR_INVALID_ARG; }
     VS_HIP_TRY(hipMemsetAsync(k.counters + 1, 0, 60, st));
-    dim3 lgrid((w + NT * EL_PX - 1) / (NT * EL_PX), h);
-    hipLaunchKernelGGL(edge_list_kernel, lgrid, dim3(NT), 0, st, d_edges, estride, w, h, k.list, k.counters);
+    if (d_edges) {
+        dim3 lgrid((w + NT * EL_PX - 1) / (NT * EL_PX), h);
+        hipLaunchKernelGGL(edge_list_kernel, lgrid, dim3(NT), 0, st, d_edges, estride, w, h, k.list, k.counters);
+    } else {        // the edge set of the last run_canny on this work area, as it stands in k.E
+        hipLaunchKernelGGL(edge_list_bits_kernel, dim3((k.wpr * h + NT - 1) / NT), dim3(NT), 0, st, k.E, k.wpr, h, k.list,
+                           k.counters);
+    }
     const size_t row_bytes = (size_t)k.geom.numrho * 4;
     if (row_bytes <= 60 * 1024) {
         hipLaunchKernelGGL(hough_accum_lds_kernel, dim3(k.geom.numangle), dim3(1024), row_bytes, st, k.list, k.counters,
@@ -668,8 +699,8 @@ int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t str
     RollWork& k = r->wk;
     // resize + BGR2GRAY (:41,:51), Canny (:54-61), HoughLines (:66-73), angle statistics (:106-119)
     R_TRY(r, launch_resize_gray((const uint8_t*)d_data, stride, w, h, VS_FMT_BGR8, k.gray, sw, sw, sh, r->st));
-    R_TRY(r, run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, k.edges, sw, r->st, /*unchecked=*/true));
-    R_TRY(r, run_hough(k, k.edges, sw, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, r->st));
+    R_TRY(r, run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, r->st, /*unchecked=*/true));
+    R_TRY(r, run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, r->st));
     RollResult res;
     int32_t growing = 0;
     R_HIP(r, hipMemcpyAsync(&res, k.res, sizeof res, hipMemcpyDeviceToHost, r->st));
@@ -677,8 +708,7 @@ int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t str
     R_HIP(r, hipStreamSynchronize(r->st));
     if (growing) {          // the edge set was still growing after four passes: finish it and redo the line search
         R_TRY(r, hyst_finish(k, r->st));
-        R_TRY(r, canny_emit(k, k.edges, sw, r->st));
-        R_TRY(r, run_hough(k, k.edges, sw, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, r->st));
+        R_TRY(r, run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, r->st));
         R_HIP(r, hipMemcpyAsync(&res, k.res, sizeof res, hipMemcpyDeviceToHost, r->st));
         R_HIP(r, hipStreamSynchronize(r->st));
     }
