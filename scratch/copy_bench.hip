@@ -1,6 +1,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 struct __attribute__((aligned(4))) U3 { unsigned a, b, c; };
 __global__ void copy16(const uint4* __restrict__ s, uint4* __restrict__ d, size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -38,8 +39,8 @@ __global__ void copy_tile_wide(const unsigned char* __restrict__ s, unsigned cha
         }
     }
 }
-int main() {
-    const int W = 1920, H = 1080, B = 16; size_t fb = (size_t)W * H * 3, total = fb * B;
+int main(int argc, char** argv) {
+    const int W = 1920, H = 1080, B = argc > 1 ? atoi(argv[1]) : 16; size_t fb = (size_t)W * H * 3, total = fb * B;
     unsigned char *s, *d; hipMalloc(&s, total); hipMalloc(&d, total); hipMemset(s, 1, total);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto timeit = [&](const char* name, auto fn) {

@@ -40,11 +40,12 @@ constexpr int MAXB = 32;     // frames per launch (frame pointers and, for host 
 // fast path (near-identity maps): the source box of a tile is staged with a FIXED row pitch, so
 // the lower taps sit at an immediate offset and the tap address is one multiply-add
 constexpr int FPITCH = 136;  // staged row pitch in pixels (128 + tap + shear + 12-byte alignment slack)
-constexpr int FROWS = 28;    // staged rows
-constexpr int LDS_PX = FPITCH * FROWS;   // 14.9 KiB of staged pixels per workgroup
+constexpr int FROWS = 26;    // staged rows (rotations up to ~4 degrees at scale ~1)
+constexpr int LDS_PX = FPITCH * FROWS;   // 13.8 KiB of staged pixels per workgroup
 constexpr int SG = FPITCH / 4;           // 34 four-pixel groups per staged row
 constexpr int SR = 7;                    // rows per staging pass (34 x 7 = 238 lanes)
-constexpr int SPASS = FROWS / SR;        // 4 staging passes held in registers
+constexpr int SPASS = (FROWS + SR - 1) / SR;   // 4 staging passes held in registers (the last one is partial)
+constexpr int LUT_STRIDE = 32;           // bytes between the entries of the weight table (index = coordinate & 0x3E0)
 constexpr int OBUF = (NT / 64) * 2 * TW; // per wave: two output rows, one dword per pixel
 
 struct WarpArgs {
@@ -58,6 +59,8 @@ struct WarpArgs {
     int border;                  // VS_BORDER_BLACK (constant 0) or VS_BORDER_REPLICATE
     int minv_stride;             // doubles between the maps of consecutive frames in Minv_dev
     int use_list;                // frames given one by one (srcs/dsts) instead of base + k*frame
+    int32_t* tabs;               // coordinate tables of the frames of this launch (warp_tables_kernel), or nullptr
+    int tab_stride;              // ints between the tables of consecutive frames (>= 2*dw + 2*dh)
     const uint8_t* srcs[MAXB];
     uint8_t* dsts[MAXB];
 };
@@ -111,6 +114,7 @@ __device__ __forceinline__ uint32_t blend(uint32_t p00, uint32_t p01, uint32_t p
 }
 
 struct __attribute__((aligned(4))) U3 { uint32_t a, b, c; };
+struct __attribute__((aligned(4))) U4 { uint32_t a, b, c, d; };
 
 template <int CN>
 __device__ __forceinline__ uint4 stage_group(const WarpArgs& a, const uint8_t* __restrict__ src, int sx, int sy) {
@@ -207,47 +211,53 @@ __device__ __forceinline__ void emit_rows(const WarpArgs& a, const uint8_t* __re
     }
 }
 
-// a*b + c as ONE v_mad_u32_u24.  The empty asm pins the accumulator, so the two multiply-adds of
-// a vertical lerp are not re-associated into mul, mul, add3.  (A real asm mad must not be used
-// here: its source is a v_dot4 result and gfx950 needs wait states between the two that only
-// the compiler's hazard recogniser inserts.)
-__device__ __forceinline__ uint32_t mad24u(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t d = __umul24(a, b) + c;
-    asm("" : "+v"(d));
-    return d;
+// ---- fast path (BGR8, near-identity maps) ------------------------------------------------------------------
+// Staged layout: one dword per source pixel x, E(x) = [B(x), B(x+1), G(x), R(x)].  The horizontal lerp of the B
+// channel is then ONE byte dot product on the staged dword itself, and one byte permute of (E(x), E(x+1)) gives
+// [G(x), G(x+1), R(x), R(x+1)] for the other two (two permutes per tap pair with a plain [B,G,R,-] layout).
+//
+// Weight table in LDS, 32 entries (one per 1/32-px fraction f) of 32 bytes: {wlo, whi, W0, W1}:
+//   wlo = (32-f) | f << 8, whi = wlo << 16   byte weights of the horizontal lerp (against bytes 0,1 / 2,3)
+//   W0 = (32-f) * 2^121, W1 = f * 2^121      float weights of the vertical lerp
+// indexed with (coordinate & 0x3E0) - the fraction bits in place - so a pixel's weights cost two 2-cycle ANDs and
+// two LDS reads instead of a bit-field extract, two multiply-adds, a shift and a subtraction.
+//
+// Vertical lerp in fp32.  gfx950 issues v_fma_f32 / v_add_f32 at twice the rate of the integer multiply-adds.  The
+// horizontal sums t, b <= 8160 are used as they are: an integer bit pattern read as a float is the denormal
+// t * 2^-149 (denormals run at full rate), so
+//   u = fma(t, W0, 2^-29)       = (t*(32-f)     + 1/2) * 2^-28     exact (< 2^20 units of 2^-29)
+//   v = fma(b, W1, u)           = (S            + 1/2) * 2^-28     S = t*(32-f) + b*f, exact
+//   m = v + 32.0f               rounds to multiples of 2^-18 = 1024 * 2^-28: RNE((S + 1/2) / 1024), never a tie,
+//                               = floor((S + 512) / 1024) = cv::warpAffine's (sum + 2^14) >> 15 of the 4-tap form
+// and the 8-bit result is the low byte of m's bit pattern (checked exhaustively: scratch/denorm_probe.hip).
+struct __attribute__((aligned(8))) LutX { uint32_t wlo, whi; };
+struct __attribute__((aligned(8))) LutY { float w0, w1; };
+
+__device__ __forceinline__ float vlerp(uint32_t t, uint32_t b, LutY w) {
+    const float u = __builtin_fmaf(__uint_as_float(t), w.w0, 0x1p-29f);
+    const float v = __builtin_fmaf(__uint_as_float(b), w.w1, u);
+    return v + 32.0f;
 }
 
-// Fast-path blend.  SX, SY: source coordinates in 1/1024 px.  The horizontal weights carry a
-// factor 2 and the vertical ones a factor 32 (= the bits of SY that hold the fraction, taken in
-// place), so that the rounded 8-bit result of a channel is byte 2 of its accumulator:
-//   (t*wy0 + b*wy1 + 512) >> 10  ==  ((2t)*(32 wy0) + (2b)*(32 wy1) + 32768) >> 16
-// and the three channels are gathered with two byte permutes instead of shifts and ors.
-__device__ __forceinline__ uint32_t blend3_fast(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, int SX, int SY) {
-    const uint32_t fx = ((uint32_t)SX >> 5) & 31u;
-    const uint32_t wlo = mad24u(fx, 510u, 64u);           // (64-2fx) | 2fx<<8
-    const uint32_t whi = wlo << 16;
-    const uint32_t wy1 = (uint32_t)SY & 0x3E0u, wy0 = 1024u - wy1;
-    const uint32_t x0 = __builtin_amdgcn_perm(p01, p00, 0x05010400u);
-    const uint32_t x1 = __builtin_amdgcn_perm(p11, p10, 0x05010400u);
-    const uint32_t y0 = __builtin_amdgcn_perm(p01, p00, 0x0C0C0602u);
-    const uint32_t y1 = __builtin_amdgcn_perm(p11, p10, 0x0C0C0602u);
-    uint32_t c0 = mad24u(__builtin_amdgcn_udot4(x0, wlo, 0u, false), wy0, 32768u);
-    c0 = mad24u(__builtin_amdgcn_udot4(x1, wlo, 0u, false), wy1, c0);
-    uint32_t c1 = mad24u(__builtin_amdgcn_udot4(x0, whi, 0u, false), wy0, 32768u);
-    c1 = mad24u(__builtin_amdgcn_udot4(x1, whi, 0u, false), wy1, c1);
-    uint32_t c2 = mad24u(__builtin_amdgcn_udot4(y0, wlo, 0u, false), wy0, 32768u);
-    c2 = mad24u(__builtin_amdgcn_udot4(y1, wlo, 0u, false), wy1, c2);
-    const uint32_t bg = __builtin_amdgcn_perm(c1, c0, 0x0C0C0602u);      // (c0.b2, c1.b2, 0, 0)
-    return __builtin_amdgcn_perm(c2, bg, 0x0C060100u);                     // (B, G, R, 0)
+__device__ __forceinline__ uint32_t blend3_fast(uint32_t e00, uint32_t e01, uint32_t e10, uint32_t e11, LutX wx, LutY wy) {
+    const uint32_t q0 = __builtin_amdgcn_perm(e01, e00, 0x07030602u);   // [G00 G01 R00 R01]
+    const uint32_t q1 = __builtin_amdgcn_perm(e11, e10, 0x07030602u);
+    const float mb = vlerp(__builtin_amdgcn_udot4(e00, wx.wlo, 0u, false), __builtin_amdgcn_udot4(e10, wx.wlo, 0u, false), wy);
+    const float mg = vlerp(__builtin_amdgcn_udot4(q0, wx.wlo, 0u, false), __builtin_amdgcn_udot4(q1, wx.wlo, 0u, false), wy);
+    const float mr = vlerp(__builtin_amdgcn_udot4(q0, wx.whi, 0u, false), __builtin_amdgcn_udot4(q1, wx.whi, 0u, false), wy);
+    const uint32_t bg = __builtin_amdgcn_perm(__float_as_uint(mg), __float_as_uint(mb), 0x0C0C0400u);   // (B, G, 0, 0)
+    return __builtin_amdgcn_perm(__float_as_uint(mr), bg, 0x0C040100u);                                  // (B, G, R, 0)
 }
 
-// Fast-path output (BGR8).  Lane L of a 32-lane row handles the pixels L, L+32, L+64, L+96 of its
-// row, so that neighbouring lanes read neighbouring LDS dwords (no bank conflicts; with 4
-// consecutive pixels per lane the taps of a wave fall on 8 of the 32 banks).  The results are
-// transposed through a small per-wave LDS buffer so that every lane still stores 4 consecutive
-// pixels = 12 contiguous bytes.  `base` = -(by0*FPITCH + bx0a).
+// Staged dword of pixel x from the pixel itself and its right neighbour, both as [B, G, R, -].
+__device__ __forceinline__ uint32_t pair_b(uint32_t cur, uint32_t next) { return __builtin_amdgcn_perm(next, cur, 0x02010400u); }
+
+// Fast-path output (BGR8).  Lane L of a 32-lane row handles the pixels L, L+32, L+64, L+96 of its row, so that
+// neighbouring lanes read neighbouring LDS dwords (no bank conflicts; with 4 consecutive pixels per lane the taps of a
+// wave fall on 8 of the 32 banks).  The results are transposed through a small per-wave LDS buffer so that every lane
+// still stores 4 consecutive pixels = 12 contiguous bytes.  `base` = -(by0*FPITCH + bx0a).
 __device__ __forceinline__ void emit_fast(const WarpArgs& a, uint8_t* __restrict__ dst, const uint32_t* tile,
-                                          uint32_t* obuf, const int* s_ad, const int* s_bd, const int* s_x0,
+                                          uint32_t* obuf, const uint8_t* lut, const int* s_ad, const int* s_bd, const int* s_x0,
                                           const int* s_y0, int x0, int y0, int x1, int y1, int base) {
     const int tid = threadIdx.x;
     const int L = tid & 31, ty = tid >> 5;
@@ -255,32 +265,47 @@ __device__ __forceinline__ void emit_fast(const WarpArgs& a, uint8_t* __restrict
     int ad[4], bd[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { ad[i] = s_ad[L + 32 * i]; bd[i] = s_bd[L + 32 * i]; }
+    // full tile, aligned rows: the stores need no per-lane checks (tile-uniform)
+    const bool whole = a.dst_aligned && x1 - x0 == TW - 1 && y1 - y0 == TH - 1;
+    const uint32_t dstride32 = (uint32_t)a.dstride;
+    uint8_t* const dtile = dst + (size_t)y0 * a.dstride + (size_t)x0 * 3;      // wave-uniform base, 32-bit lane offsets
 #pragma unroll
     for (int r = 0; r < TH / TYN; r++) {
         const int yl = ty + TYN * r;
         const int X0 = s_x0[yl], Y0 = s_y0[yl];
-        uint32_t p00[4], p01[4], p10[4], p11[4];
-        int SX[4], SY[4];
+        uint32_t e00[4], e01[4], e10[4], e11[4];
+        LutX wx[4];
+        LutY wy[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            SX[i] = X0 + ad[i]; SY[i] = Y0 + bd[i];              // 1/1024 px
+            const int SX = X0 + ad[i], SY = Y0 + bd[i];              // 1/1024 px
             // byte address of the upper-left tap: one multiply-add and one shift-add
-            int rowb = __mul24(SY[i] >> 10, FPITCH * 4) + 4 * base;
+            int rowb = __mul24(SY >> 10, FPITCH * 4) + 4 * base;
             asm("" : "+v"(rowb));
-            int sxi = SX[i] >> 10;
+            int sxi = SX >> 10;
             asm("" : "+v"(sxi));
             const uint32_t* t = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile) + ((sxi << 2) + rowb));
-            p00[i] = t[0]; p01[i] = t[1];
-            p10[i] = t[FPITCH]; p11[i] = t[FPITCH + 1];
+            e00[i] = t[0]; e01[i] = t[1];
+            e10[i] = t[FPITCH]; e11[i] = t[FPITCH + 1];
+            wx[i] = *reinterpret_cast<const LutX*>(lut + (SX & 0x3E0));
+            wy[i] = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) wb[L + 32 * i] = blend3_fast(p00[i], p01[i], p10[i], p11[i], SX[i], SY[i]);
+        for (int i = 0; i < 4; i++) wb[L + 32 * i] = blend3_fast(e00[i], e01[i], e10[i], e11[i], wx[i], wy[i]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint4 q = *reinterpret_cast<const uint4*>(&wb[4 * L]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (whole) {
+            U3 v;
+            v.a = __builtin_amdgcn_perm(q.y, q.x, 0x04020100u);
+            v.b = __builtin_amdgcn_perm(q.z, q.y, 0x05040201u);
+            v.c = __builtin_amdgcn_perm(q.w, q.z, 0x06050402u);
+            *reinterpret_cast<U3*>(dtile + (__umul24((uint32_t)yl, dstride32) + 12u * L)) = v;
+            continue;
+        }
         const int y = y0 + yl, x = x0 + 4 * L;
         if (y <= y1 && x <= x1) {
             uint8_t* d = dst + (size_t)y * a.dstride + (size_t)x * 3;
@@ -306,15 +331,8 @@ __device__ __forceinline__ void emit_fast(const WarpArgs& a, uint8_t* __restrict
 // (columns: adelta = round(M0*x*1024) with q = 0; rows: round((M1*y + M2)*1024) + round_delta).
 __device__ __forceinline__ int coord_term(double p, double q, double v) { return d_round((p * v + q) * 1024); }
 
-template <int CN>
-__global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_PX];
-    __shared__ __attribute__((aligned(16))) uint32_t obuf[OBUF];
-    __shared__ int s_ad[TW], s_bd[TW], s_x0[TH], s_y0[TH];
-    const int bz = blockIdx.z;
-    const uint8_t* __restrict__ src = a.use_list ? a.srcs[bz] : a.src + (size_t)bz * a.sframe;
-    uint8_t* __restrict__ dst = a.use_list ? a.dsts[bz] : a.dst + (size_t)bz * a.dframe;
-    double m[6];   // inverse map of this frame (wave-uniform, scalar loads)
+// The inverse map of frame bz (wave-uniform: scalar loads or kernel arguments).
+__device__ __forceinline__ void load_map(const WarpArgs& a, int bz, double* m) {
     if (a.Minv_dev) {
         const __attribute__((address_space(4))) double* mp =
             (const __attribute__((address_space(4))) double*)(a.Minv_dev + a.minv_stride * bz);
@@ -324,33 +342,93 @@ __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; i++) m[i] = a.Minv_val[6 * bz + i];
     }
+}
+
+// Coordinate tables of a frame, once per frame instead of once per tile: [adelta(x), x < dw | bdelta(x) | X0(y), y < dh |
+// Y0(y)] as WarpAffineInvoker builds them (double arithmetic, one rounding each).  ~6000 terms per 1080p frame; the
+// warp kernel then holds no double-precision arithmetic at all (it was 15 % of its vector instructions).
+__global__ __launch_bounds__(NT) void warp_tables_kernel(WarpArgs a) {
+    const int bz = blockIdx.y;
+    double m[6];
+    load_map(a, bz, m);
+    int32_t* T = a.tabs + (size_t)bz * a.tab_stride;
+    const int j = blockIdx.x * NT + threadIdx.x;
+    if (j < a.dw) {
+        const double dv = (double)j;
+        T[j] = coord_term(m[0], 0.0, dv);
+        T[a.dw + j] = coord_term(m[3], 0.0, dv);
+    } else if (j < a.dw + a.dh) {
+        const int y = j - a.dw;
+        const double dv = (double)y;
+        T[2 * a.dw + y] = coord_term(m[1], m[2], dv) + 16;
+        T[2 * a.dw + a.dh + y] = coord_term(m[4], m[5], dv) + 16;
+    }
+}
+
+template <int CN, bool TABS>
+__global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_PX];
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[OBUF];
+    __shared__ int s_ad[TW], s_bd[TW], s_x0[TH], s_y0[TH];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[CN == 3 ? 32 * LUT_STRIDE : 16];
+    const int bz = blockIdx.z;
+    const uint8_t* __restrict__ src = a.use_list ? a.srcs[bz] : a.src + (size_t)bz * a.sframe;
+    uint8_t* __restrict__ dst = a.use_list ? a.dsts[bz] : a.dst + (size_t)bz * a.dframe;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int x1 = min(x0 + TW, a.dw) - 1, y1 = min(y0 + TH, a.dh) - 1;
-
-    // ---- 1. coordinate terms of the tile, once per workgroup: waves 0 and 1 the 128 columns
-    // (adelta, bdelta), 16 lanes of wave 2 the rows (X0, Y0).  Columns and rows past the image repeat
-    // the last one, so every lane of a partial tile stays inside the box.
-    if (wave < 2) {
-        const double dv = (double)min(x0 + tid, x1);
-        s_ad[tid] = coord_term(m[0], 0.0, dv);
-        s_bd[tid] = coord_term(m[3], 0.0, dv);
-    } else if (tid < 2 * 64 + TH) {
-        const double dv = (double)min(y0 + (tid - 128), y1);
-        s_x0[tid - 128] = coord_term(m[1], m[2], dv) + 16;
-        s_y0[tid - 128] = coord_term(m[4], m[5], dv) + 16;
+    if (CN == 3 && tid >= NT - 32) {      // weight table of the fast path (see blend3_fast): the last 32 lanes of wave 3
+        const uint32_t f = tid - (NT - 32);
+        const uint32_t wlo = (32u - f) | (f << 8);
+        *reinterpret_cast<uint4*>(lut + f * LUT_STRIDE) =
+            make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
     }
-    __syncthreads();
-    // The maps are monotone in x and in y separately, so the source bounding box of the tile follows
-    // from the terms of its first/last column and row (scalar arithmetic on broadcast LDS reads).
+
+    // ---- 1. coordinate terms of the tile (128 columns: adelta, bdelta; 16 rows: X0, Y0) -> LDS.  Columns and rows
+    // past the image repeat the last one, so every lane of a partial tile stays inside the box.  The maps are
+    // monotone in x and in y separately, so the source bounding box of the tile follows from the terms of its
+    // first/last column and row.
+    int ad0, ad1, bd0, bd1, Xa, Xb, Ya, Yb;
+    int tv0 = 0, tv1 = 0;
+    if (TABS) {
+        // from the frame's tables: the corner terms with scalar loads, the tile's share with one vector load per
+        // lane; they travel together with the staging loads of step 2 and reach LDS in front of the one barrier
+        const size_t tb = (size_t)bz * a.tab_stride;
+        const __attribute__((address_space(4))) int32_t* Ts = (const __attribute__((address_space(4))) int32_t*)(a.tabs + tb);
+        ad0 = Ts[x0]; ad1 = Ts[x1]; bd0 = Ts[a.dw + x0]; bd1 = Ts[a.dw + x1];
+        Xa = Ts[2 * a.dw + y0]; Xb = Ts[2 * a.dw + y1]; Ya = Ts[2 * a.dw + a.dh + y0]; Yb = Ts[2 * a.dw + a.dh + y1];
+        const int32_t* Tg = a.tabs + tb;
+        if (wave < 2) {
+            const int c = min(x0 + tid, x1);
+            tv0 = Tg[c]; tv1 = Tg[a.dw + c];
+        } else if (tid < 2 * 64 + TH) {
+            const int r = min(y0 + (tid - 128), y1);
+            tv0 = Tg[2 * a.dw + r]; tv1 = Tg[2 * a.dw + a.dh + r];
+        }
+    } else {
+        // no tables (single launches of the image operators): waves 0 and 1 evaluate the columns, 16 lanes of
+        // wave 2 the rows, in double; the corner terms come back through LDS
+        double m[6];
+        load_map(a, bz, m);
+        if (wave < 2) {
+            const double dv = (double)min(x0 + tid, x1);
+            s_ad[tid] = coord_term(m[0], 0.0, dv);
+            s_bd[tid] = coord_term(m[3], 0.0, dv);
+        } else if (tid < 2 * 64 + TH) {
+            const double dv = (double)min(y0 + (tid - 128), y1);
+            s_x0[tid - 128] = coord_term(m[1], m[2], dv) + 16;
+            s_y0[tid - 128] = coord_term(m[4], m[5], dv) + 16;
+        }
+        __syncthreads();
+        const int cl = x1 - x0, rl = y1 - y0;
+        ad0 = __builtin_amdgcn_readfirstlane(s_ad[0]); ad1 = __builtin_amdgcn_readfirstlane(s_ad[cl]);
+        bd0 = __builtin_amdgcn_readfirstlane(s_bd[0]); bd1 = __builtin_amdgcn_readfirstlane(s_bd[cl]);
+        Xa = __builtin_amdgcn_readfirstlane(s_x0[0]); Xb = __builtin_amdgcn_readfirstlane(s_x0[rl]);
+        Ya = __builtin_amdgcn_readfirstlane(s_y0[0]); Yb = __builtin_amdgcn_readfirstlane(s_y0[rl]);
+    }
     int bx0, bx1, by0, by1;
     bool saturated;
     {
-        const int cl = x1 - x0, rl = y1 - y0;
-        const int ad0 = __builtin_amdgcn_readfirstlane(s_ad[0]), ad1 = __builtin_amdgcn_readfirstlane(s_ad[cl]);
-        const int bd0 = __builtin_amdgcn_readfirstlane(s_bd[0]), bd1 = __builtin_amdgcn_readfirstlane(s_bd[cl]);
-        const int Xa = __builtin_amdgcn_readfirstlane(s_x0[0]), Xb = __builtin_amdgcn_readfirstlane(s_x0[rl]);
-        const int Ya = __builtin_amdgcn_readfirstlane(s_y0[0]), Yb = __builtin_amdgcn_readfirstlane(s_y0[rl]);
         const int sx00 = (Xa + ad0) >> 10, sx01 = (Xa + ad1) >> 10, sx10 = (Xb + ad0) >> 10, sx11 = (Xb + ad1) >> 10;
         const int sy00 = (Ya + bd0) >> 10, sy01 = (Ya + bd1) >> 10, sy10 = (Yb + bd0) >> 10, sy11 = (Yb + bd1) >> 10;
         const int rx0 = min(min(sx00, sx01), min(sx10, sx11)), rx1 = max(max(sx00, sx01), max(sx10, sx11));
@@ -364,28 +442,32 @@ __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
     const int bh = by1 - by0 + 1;
     const bool fast = CN == 3 && !saturated && bw <= FPITCH && bh <= FROWS;
     const bool use_lds = fast || (!saturated && (long long)bw * bh <= LDS_PX);
-    const bool interior = fast && a.src_aligned && bx0a >= 0 && bx0a + bw <= a.sw && by0 >= 0 && by0 + bh <= a.sh;
+    // (the last group of a row loads 4 bytes past the box: inside the frame unless the box ends with the frame)
+    const bool interior = fast && a.src_aligned && bx0a >= 0 && bx0a + bw <= a.sw && by0 >= 0 && by0 + bh <= a.sh &&
+                          (bx0a + bw + 2 <= a.sw || by0 + bh < a.sh);
 
     // ---- 2. staging
     if (interior) {
-        // branch-free: 4 passes of 7 rows x 34 groups; rows past the box repeat its last row
+        // branch-free: 4 passes of 7 rows x 34 groups; rows past the box repeat its last row.  A lane loads 16 bytes
+        // = its 4 pixels and the B of the next one (the staged dword of a pixel carries its right neighbour's B)
         const int ly = tid / SG, lx = tid - ly * SG;
         if (tid < SG * SR && 4 * lx < bw) {
             // wave-uniform base + 32-bit lane offset (the box spans < 2^24 bytes of rows)
             const uint8_t* box = src + (size_t)bx0a * 3 + (size_t)by0 * a.sstride;
             const uint32_t stride32 = (uint32_t)a.sstride, col = 12u * lx;
-            U3 d[SPASS];
+            U4 d[SPASS];
 #pragma unroll
             for (int k = 0; k < SPASS; k++)
                 if (SR * k < bh)       // tile-uniform: small rotations need 3 passes (21 rows)
-                    d[k] = *reinterpret_cast<const U3*>(box + (__umul24((uint32_t)min(ly + SR * k, bh - 1), stride32) + col));
+                    d[k] = *reinterpret_cast<const U4*>(box + (__umul24((uint32_t)min(ly + SR * k, bh - 1), stride32) + col));
 #pragma unroll
             for (int k = 0; k < SPASS; k++) {
-                // byte 3 of a staged pixel is never read by the blend, so it may hold the next pixel's B
-                if (SR * k < bh)
+                if (SR * k < bh && (SR * (k + 1) <= FROWS || ly + SR * k < FROWS))
                     *reinterpret_cast<uint4*>(&tile[(ly + SR * k) * FPITCH + 4 * lx]) =
-                        make_uint4(d[k].a, __builtin_amdgcn_alignbit(d[k].b, d[k].a, 24),
-                                   __builtin_amdgcn_alignbit(d[k].c, d[k].b, 16), d[k].c >> 8);
+                        make_uint4(__builtin_amdgcn_perm(d[k].a, d[k].a, 0x02010300u),      // bytes 0,3,1,2
+                                   __builtin_amdgcn_perm(d[k].b, d[k].a, 0x05040603u),      // bytes 3,6,4,5
+                                   __builtin_amdgcn_perm(d[k].c, d[k].b, 0x04030502u),      // bytes 6,9,7,8
+                                   __builtin_amdgcn_perm(d[k].d, d[k].c, 0x03020401u));     // bytes 9,12,10,11
             }
         }
     } else if (use_lds) {
@@ -394,21 +476,45 @@ __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
         const int total = gpr * bh;
         for (int g = tid; g < total; g += NT) {
             const int row = g / gpr, gx = g - row * gpr;
-            const uint4 px = stage_group<CN>(a, src, bx0a + 4 * gx, by0 + row);
+            uint4 px = stage_group<CN>(a, src, bx0a + 4 * gx, by0 + row);
+            if (CN == 3 && fast) {     // the fast path's layout (tiles at the image border)
+                const uint32_t nx = load_px_checked<CN>(src, a.sstride, a.sw, a.sh, bx0a + 4 * gx + 4, by0 + row, a.border);
+                px = make_uint4(pair_b(px.x, px.y), pair_b(px.y, px.z), pair_b(px.z, px.w), pair_b(px.w, nx));
+            }
             *reinterpret_cast<uint4*>(&tile[row * pitch + 4 * gx]) = px;
         }
+    }
+    if (TABS) {
+        if (wave < 2) { s_ad[tid] = tv0; s_bd[tid] = tv1; }
+        else if (tid < 2 * 64 + TH) { s_x0[tid - 128] = tv0; s_y0[tid - 128] = tv1; }
     }
     __syncthreads();
 
     // ---- 3. output (the choice is tile-uniform)
-    if (CN == 3 && fast) emit_fast(a, dst, tile, obuf, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, -(by0 * FPITCH + bx0a));
+    if (CN == 3 && fast) emit_fast(a, dst, tile, obuf, lut, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, -(by0 * FPITCH + bx0a));
     else if (use_lds) emit_rows<CN, true>(a, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw);
     else emit_rows<CN, false>(a, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw);
 }
 
+// Ints of table workspace for `frames` frames of dw x dh (see warp_tables_kernel).
+inline int tab_stride_of(int dw, int dh) { return (2 * dw + 2 * dh + 3) & ~3; }
+
 template <int CN>
-void launch_one(const WarpArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL(warp_affine_kernel<CN>, grid, dim3(NT), 0, st, a);
+void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, hipStream_t st) {
+    a.tabs = d_tabs;
+    a.tab_stride = tab_stride_of(a.dw, a.dh);
+    if (d_tabs) {
+        hipLaunchKernelGGL(warp_tables_kernel, dim3((a.dw + a.dh + NT - 1) / NT, grid.z), dim3(NT), 0, st, a);
+        hipLaunchKernelGGL((warp_affine_kernel<CN, true>), grid, dim3(NT), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((warp_affine_kernel<CN, false>), grid, dim3(NT), 0, st, a);
+    }
+}
+
+void launch_cn(WarpArgs& a, dim3 grid, int cn, int32_t* d_tabs, hipStream_t st) {
+    if (cn == 3) launch_one<3>(a, grid, d_tabs, st);
+    else if (cn == 1) launch_one<1>(a, grid, d_tabs, st);
+    else launch_one<2>(a, grid, d_tabs, st);
 }
 
 void fill_common(WarpArgs& a, const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh, uint8_t* d_dst,
@@ -419,6 +525,7 @@ void fill_common(WarpArgs& a, const uint8_t* d_src, size_t sstride, size_t sfram
     a.border = VS_BORDER_BLACK;
     a.minv_stride = 6;
     a.use_list = 0;
+    a.tabs = nullptr; a.tab_stride = 0;
     for (int i = 0; i < MAXB; i++) { a.srcs[i] = nullptr; a.dsts[i] = nullptr; }
     const int galign = cn == 2 ? 8 : 4;
     a.src_aligned = ((uintptr_t)d_src % galign == 0) && (sstride % galign == 0) && (sframe % galign == 0);
@@ -434,9 +541,12 @@ bool bad_args(const void* d_src, const void* d_dst, const void* M, size_t sstrid
 
 }  // namespace
 
+// Ints of workspace the table form of a launch over `frames` frames of dw x dh needs (d_tabs of the launchers).
+size_t warp_tabs_ints(int dw, int dh, int frames) { return (size_t)tab_stride_of(dw, dh) * (size_t)(frames > 0 ? frames : 1); }
+
 int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                        uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
-                       const double* d_Minv, int batch, hipStream_t st) {
+                       const double* d_Minv, int batch, int32_t* d_tabs, hipStream_t st) {
     if (bad_args(d_src, d_dst, d_Minv, sstride, sw, sh, dstride, dw, dh, cn, batch) || batch > 65535) {
         set_last_error("warp_affine: invalid argument");
         return VS_ERR_INVALID_ARG;
@@ -445,9 +555,7 @@ int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int 
     fill_common(a, d_src, sstride, sframe, sw, sh, d_dst, dstride, dframe, dw, dh, cn);
     a.Minv_dev = d_Minv;
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, batch);
-    if (cn == 3) launch_one<3>(a, grid, st);
-    else if (cn == 1) launch_one<1>(a, grid, st);
-    else launch_one<2>(a, grid, st);
+    launch_cn(a, grid, cn, d_tabs, st);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -455,7 +563,8 @@ int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int 
 // Frames given one by one (deferred output of a stream: each result goes to its caller's buffer);
 // all share one geometry.  d_Minv: inverse maps on the device, minv_stride doubles apart.
 int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
-                            size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, hipStream_t st) {
+                            size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, int32_t* d_tabs,
+                            hipStream_t st) {
     if (n < 1 || n > MAXB || !srcs || !dsts || bad_args(srcs[0], dsts[0], d_Minv, sstride, sw, sh, dstride, dw, dh, cn, n)) {
         set_last_error("warp_affine_list: invalid argument");
         return VS_ERR_INVALID_ARG;
@@ -473,9 +582,7 @@ int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, in
     a.Minv_dev = d_Minv;
     a.minv_stride = minv_stride;
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, n);
-    if (cn == 3) launch_one<3>(a, grid, st);
-    else if (cn == 1) launch_one<1>(a, grid, st);
-    else launch_one<2>(a, grid, st);
+    launch_cn(a, grid, cn, d_tabs, st);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -489,6 +596,10 @@ int launch_warp_affine_hostM(const uint8_t* d_src, size_t sstride, size_t sframe
         set_last_error("warp_affine: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
+    // coordinate tables for launches of several frames: stream-ordered scratch, released behind the last launch
+    int32_t* d_tabs = nullptr;
+    if (batch >= 4)
+        VS_HIP_TRY(hipMallocAsync((void**)&d_tabs, warp_tabs_ints(dw, dh, batch < MAXB ? batch : MAXB) * sizeof(int32_t), st));
     for (int b0 = 0; b0 < batch; b0 += MAXB) {
         const int nb = batch - b0 < MAXB ? batch - b0 : MAXB;
         WarpArgs a;
@@ -500,11 +611,10 @@ int launch_warp_affine_hostM(const uint8_t* d_src, size_t sstride, size_t sframe
             else for (int i = 0; i < 6; i++) a.Minv_val[6 * b + i] = 0.;
         }
         dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, nb);
-        if (cn == 3) launch_one<3>(a, grid, st);
-        else if (cn == 1) launch_one<1>(a, grid, st);
-        else launch_one<2>(a, grid, st);
+        launch_cn(a, grid, cn, d_tabs, st);
         VS_HIP_TRY(hipGetLastError());
     }
+    if (d_tabs) VS_HIP_TRY(hipFreeAsync(d_tabs, st));
     return VS_OK;
 }
 
@@ -523,9 +633,7 @@ int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh,
     a.border = border;
     for (int i = 0; i < MAXB * 6; i++) a.Minv_val[i] = i < 6 ? h_Minv[i] : 0.;
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, 1);
-    if (cn == 3) launch_one<3>(a, grid, st);
-    else if (cn == 1) launch_one<1>(a, grid, st);
-    else launch_one<2>(a, grid, st);
+    launch_cn(a, grid, cn, nullptr, st);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

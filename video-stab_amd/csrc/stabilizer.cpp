@@ -174,6 +174,7 @@ struct vs_stab {
     std::vector<PendWarp> pend;
     size_t pend_stride = 0;
     double* d_MinvB[2] = {nullptr, nullptr};   // inverse maps of the pending frames, 12 doubles each; two sets
+    int32_t* d_tabs[2] = {nullptr, nullptr};   // coordinate tables of a batched warp launch: [0] launches on `main`, [1] on the warp stream
     int pend_set = 0;
     hipEvent_t ev_emit = nullptr, ev_warp[2] = {nullptr, nullptr};
     bool warp_valid[2] = {false, false};
@@ -383,6 +384,8 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     const size_t o_pairs = take(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
     size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
     size_t o_MinvB[2] = {take((size_t)BATCH_MAX * 96), take((size_t)BATCH_MAX * 96)};
+    const size_t tab_bytes = warp_tabs_ints(w, h, WARP_BATCH_MAX) * sizeof(int32_t);
+    size_t o_tabs[2] = {take(tab_bytes), take(tab_bytes)};
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
     S_HIP(s, hipMemsetAsync(s->d_all, 0, off, s->st));
     uint8_t* b = s->d_all;
@@ -413,6 +416,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->d_traj = (TrajState*)(b + o_traj);
     s->d_M = (float*)(b + o_M); s->d_Minv = (double*)(b + o_Minv); s->d_dbg = (vs_debug_frame*)(b + o_dbg);
     s->d_MinvB[0] = (double*)(b + o_MinvB[0]); s->d_MinvB[1] = (double*)(b + o_MinvB[1]);
+    s->d_tabs[0] = (int32_t*)(b + o_tabs[0]); s->d_tabs[1] = (int32_t*)(b + o_tabs[1]);
     s->pend.clear(); s->pend_set = 0; s->warp_valid[0] = s->warp_valid[1] = false;
     // GFTT scratch sized for the larger of the two detection images
     const int gmaxw = std::max(s->aw, 480), gmaxh = std::max(s->ah, 270);
@@ -604,7 +608,7 @@ int flush_warps(vs_stab* s, bool on_main) {
     {
         StageScope t(s, VS_STAGE_WARP, ws);
         rc = launch_warp_affine_list(srcs, dsts, n, s->src_pitch, s->w, s->h, s->pend_stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[set], 12, ws);
+                                     s->d_MinvB[set], 12, n >= 4 ? s->d_tabs[on_main ? 0 : 1] : nullptr, ws);
     }
     if (hipEventRecord(s->ev_warp[set], ws) == hipSuccess) s->warp_valid[set] = true;
     for (int i = 0; i < n; i++) {
@@ -649,7 +653,7 @@ int launch_ready(vs_stab* s) {
         const int m = std::min(WARP_BATCH_MAX, R.n - i0);
         StageScope t(s, VS_STAGE_WARP, st);
         rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->src_pitch, s->w, s->h, R.stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[R.set] + 12 * i0, 12, st);
+                                     s->d_MinvB[R.set] + 12 * i0, 12, m >= 4 ? s->d_tabs[0] : nullptr, st);
         if (rc == VS_OK && s->fmt == VS_FMT_NV12) {
             // interleaved chroma plane: half size, two channels, the map with the halved translation
             const uint8_t* us[WARP_BATCH_MAX];
@@ -659,7 +663,7 @@ int launch_ready(vs_stab* s) {
                 ud[i] = R.dsts[i0 + i] + dst_uv(s, R.dsts[i0 + i], R.stride);
             }
             rc = launch_warp_affine_list(us, ud, m, s->src_pitch, s->w / 2, s->h / 2, R.stride, s->w / 2, s->h / 2, 2,
-                                         s->d_MinvB[R.set] + 12 * i0 + 6, 12, st);
+                                         s->d_MinvB[R.set] + 12 * i0 + 6, 12, m >= 4 ? s->d_tabs[0] : nullptr, st);
         }
     }
     if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
@@ -707,27 +711,27 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
         s->last_out_w = s->w; s->last_out_h = s->h;
     } else if (s->fmt == VS_FMT_NV12) {
         StageScope t(s, VS_STAGE_WARP, st);
-        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_Minv, 1, st);
+        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_Minv, 1, nullptr, st);
         if (rc == VS_OK)
             rc = launch_warp_affine(frame + src_uv(s), s->src_pitch, 0, s->w / 2, s->h / 2,
                                     d_out + dst_uv(s, d_out, out_stride), out_stride, 0, s->w / 2, s->h / 2, 2,
-                                    s->d_Minv + 6, 1, st);
+                                    s->d_Minv + 6, 1, nullptr, st);
     } else if (p.border_size > 0 && !p.crop_n_zoom) {                                 // :981-990
         const int b = p.border_size, bw = s->w + 2 * b, bh = s->h + 2 * b;
         rc = launch_make_border(frame, s->src_pitch, s->w, s->h, s->cn, s->d_tmp, (size_t)bw * s->cn, b, p.border_type, st);
         StageScope t(s, VS_STAGE_WARP, st);
         if (rc == VS_OK)
-            rc = launch_warp_affine(s->d_tmp, (size_t)bw * s->cn, 0, bw, bh, d_out, out_stride, 0, bw, bh, s->cn, s->d_Minv, 1, st);
+            rc = launch_warp_affine(s->d_tmp, (size_t)bw * s->cn, 0, bw, bh, d_out, out_stride, 0, bw, bh, s->cn, s->d_Minv, 1, nullptr, st);
     } else if (p.crop_n_zoom && p.border_size > 0 && s->w - 2 * p.border_size > 0 && s->h - 2 * p.border_size > 0) {  // :1108-1124
         const int b = p.border_size;
         StageScope t(s, VS_STAGE_WARP, st);
-        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, s->d_tmp, s->row_bytes, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
+        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, s->d_tmp, s->row_bytes, 0, s->w, s->h, s->cn, s->d_Minv, 1, nullptr, st);
         if (rc == VS_OK)
             rc = launch_resize_linear(s->d_tmp + ((size_t)b * s->w + b) * s->cn, s->row_bytes, s->w - 2 * b, s->h - 2 * b,
                                       s->cn, d_out, out_stride, s->orig_w, s->orig_h, st);
     } else {                                                                          // :1056-1060
         StageScope t(s, VS_STAGE_WARP, st);
-        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, s->cn, s->d_Minv, 1, st);
+        rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, s->cn, s->d_Minv, 1, nullptr, st);
     }
     // the slot may be overwritten once this warp has read it
     if (slot >= 0) {

@@ -75,11 +75,16 @@ inline void warp_invert(const float* Mf, double* inv) {
 
 // ---- stage launchers (device pointers, asynchronous on `st`) -----------------
 // d_Minv: batch*6 doubles on the DEVICE: the INVERSE maps (warp_invert of the forward matrices).
+// d_tabs: nullptr, or warp_tabs_ints(dw, dh, frames of the launch) ints of device scratch: the coordinate terms are
+// then built once per frame by a small launch in front of the warp instead of once per tile inside it.  The scratch
+// is read by the warp launch only (stream order), so one buffer per stream and caller is enough.
+size_t warp_tabs_ints(int dw, int dh, int frames);
 int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                        uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
-                       const double* d_Minv, int batch, hipStream_t st);
+                       const double* d_Minv, int batch, int32_t* d_tabs, hipStream_t st);
 int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
-                            size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, hipStream_t st);
+                            size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, int32_t* d_tabs,
+                            hipStream_t st);
 int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
                        uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st);
 // Batched forms (batch mode): the images of `items` frames in one launch; d_pairs = device table of
