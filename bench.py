@@ -11,8 +11,13 @@ warpAffine); streams never exchange data, so scaling is weak and there is no
 data-path collective - torch.distributed only provides the barrier and the
 max-over-ranks of the timed region.
 
-A step = one stabilize() (vs_stab_push_dev) per stream on a frame that is
-already resident in HBM.  Prints ONE JSON line on rank 0.
+A STEP = one pass of the hot path over one batch of synthetic input: `--batch`
+(32) consecutive stabilize() calls (vs_stab_push_dev) per stream on frames that
+are already resident in HBM - the unit the batch mode issues its launches in, so
+that any K is a whole number of steady-state batches.  `value` is frames/s.
+Prints ONE JSON line on rank 0; at N = 1 it also carries the PCIe-inclusive rate
+of the host-pointer entry point, BASELINE configs[2] (3840x2160) and the CPU
+baseline.
 """
 import argparse
 import json
@@ -30,11 +35,12 @@ from vsamd import capi, dist as vsdist, synth  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
 
 
-def make_params(vs, config=None):
+def make_params(vs, config=None, **over):
     # BASELINE.json configs[1]: 200 corners, 3-level LK (maxLevel 2) with a 21x21 window;
     # everything else is the reference's live default (Stabilizer.h:76-175, Stabilizer.cpp:611-649).
-    p = vs.params(max_corners=200, lk_win_size=21, lk_max_level=2, lk_max_iters=20, lk_epsilon=0.03,
-                  smoothing_radius=30)
+    kw = dict(max_corners=200, lk_win_size=21, lk_max_level=2, lk_max_iters=20, lk_epsilon=0.03, smoothing_radius=30)
+    kw.update(over)
+    p = vs.params(**kw)
     if config:
         # the "stabilizer" section of a config.yaml of the reference's apps on top of that (vs_config_read_stab;
         # keys the file does not name keep the values above)
@@ -71,9 +77,10 @@ def cpu_baseline(width, height, frames, order_fn):
             n_out += 1
     dt = time.perf_counter() - t0
     s.close()
-    # all-core variant of the same port (point-parallel LK, row-parallel warp)
+    # all-core variant of the same port (resize / corner response / LK points / warp rows spread over threads)
     ncores = os.cpu_count() or 1
-    o.lib.vso_set_threads(ncores)
+    nthr = min(ncores, 64)
+    o.lib.vso_set_threads(nthr)
     s = o.stabilizer(p)
     for i in order[:warm]:
         s.push(frames[i])
@@ -86,28 +93,196 @@ def cpu_baseline(width, height, frames, order_fn):
     return {
         "value": round(timed / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": "%d steady-state stabilize() calls on the same %dx%d clip, oracle/ single thread" % (timed, width, height),
-        "all_cores": {"value": round(60 / dt_mt, 3), "cores": ncores,
-                      "note": "same port, LK points and warp rows spread over threads"},
+        "all_cores": {"value": round(60 / dt_mt, 3), "cores": nthr, "host_cores": ncores,
+                      "note": "same port, threaded stages spread over %d threads" % nthr},
     }
+
+
+class StreamSet:
+    """S stabilizer instances in batch mode on one GPU, each with a resident clip and a ring of output frames."""
+
+    def __init__(self, vs, device, params, frames_per_stream, w, h, fmt, batch, warp_batch, zero_copy):
+        self.vs, self.w, self.h, self.fmt = vs, w, h, fmt
+        self.fb = frames_per_stream[0][0].nbytes
+        self.stride = w * 3 if fmt == capi.FMT_BGR8 else w
+        self.clip_frames = len(frames_per_stream[0])
+        self.d_in = []
+        for frames in frames_per_stream:
+            buf = capi.DevBuf(vs, self.fb * len(frames))
+            for i, f in enumerate(frames):
+                buf.upload(f, i * self.fb)
+            self.d_in.append(buf)
+        self.BT = max(1, min(32, batch))
+        self.WB = max(1, min(32, warp_batch if self.BT == 1 else self.BT))
+        self.NOUT = max(2 * self.WB, 3 * self.BT)    # a result stays untouched until its batch and the next one have been issued
+        self.d_out = [[capi.DevBuf(vs, self.fb) for _ in range(self.NOUT)] for _ in frames_per_stream]
+        self.stabs = [vs.stabilizer(params, device=device) for _ in frames_per_stream]
+        for s in self.stabs:
+            s.set_batch(self.BT)
+            s.set_zero_copy(bool(zero_copy))
+            s.set_warp_batch(self.WB)
+        self.i = 0
+        self.order = clip_order(self.clip_frames, 1 << 17)
+
+    def push(self, n):
+        """n consecutive pushes per stream."""
+        for _ in range(n):
+            fi = self.order[self.i % len(self.order)]
+            for j, s in enumerate(self.stabs):
+                s.push_dev(self.d_in[j].ptr + fi * self.fb, self.w, self.h, self.stride, self.fmt,
+                           self.d_out[j][self.i % self.NOUT].ptr, self.stride)
+            self.i += 1
+
+    def sync(self):
+        for s in self.stabs:
+            s.sync()
+
+    def frames_out(self):
+        return sum(s.counters().frames_out for s in self.stabs)
+
+    def close(self):
+        for s in self.stabs:
+            s.close()
+        for b in self.d_in:
+            b.free()
+        for bs in self.d_out:
+            for b in bs:
+                b.free()
+
+
+def warp_roofline(ss, alg_bytes_per_frame, frames_out_timed, kernel):
+    """Warp stage of the timed region: HIP-event time of its launches on the stream they run on."""
+    stage_ms = [0.0] * 8
+    stage_n = [0] * 8
+    for s in ss.stabs:
+        ms, n = s.stage_times()
+        for k in range(8):
+            stage_ms[k] += ms[k]
+            stage_n[k] += n[k]
+    launches = max(stage_n[7], 1)
+    frames_per_launch = frames_out_timed / launches
+    avg_ms = stage_ms[7] / launches
+    byts = alg_bytes_per_frame * frames_per_launch
+    achieved = byts / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": byts,
+            "frames_per_launch": round(frames_per_launch, 3), "avg_launch_us": round(avg_ms * 1e3, 3), "launches": stage_n[7]}
+    return roof, stage_ms, stage_n
+
+
+def traffic_from_counters(vs, roof, frame_bytes):
+    """HBM bytes per launch from the PMC passes kept in profiles/warp_traffic.json - only when that file was measured on
+    THIS build of the kernels (vs_build_tag); otherwise the field stays null and says why."""
+    pmc = os.path.join(ROOT, "profiles", "warp_traffic.json")
+    try:
+        t = json.load(open(pmc))
+    except Exception:
+        roof["traffic_note"] = "no counter file"
+        return
+    tag = vs.lib.vs_build_tag().decode()
+    if t.get("build_tag") != tag:
+        roof["traffic_note"] = "stale: profiles/warp_traffic.json was measured on build %s, this is %s" % (t.get("build_tag"), tag)
+        return
+    per_frame = t["hbm_bytes_per_launch"] / t["frames_per_launch"] * (frame_bytes / (1920 * 1080 * 3.0))
+    roof["traffic"] = round(per_frame * roof["frames_per_launch"])
+    roof["traffic_note"] = "FETCH_SIZE x2 + WRITE_SIZE of %s (%d-frame launches), scaled to this launch" % (t.get("source"), t["frames_per_launch"])
+
+
+def host_api_rate(vs, device, params, frames, n_timed=240):
+    """vs_stab_push: host frame in, host frame out (what vs::Stabilizer::stabilize(cv::Mat) calls) - PCIe both ways."""
+    s = vs.stabilizer(params, device=device)
+    order = clip_order(len(frames), 64 + n_timed)
+    for i in order[:64]:
+        s.push(frames[i])
+    t0 = time.perf_counter()
+    n_out = 0
+    for i in order[64:]:
+        if s.push(frames[i]) is not None:
+            n_out += 1
+    dt = time.perf_counter() - t0
+    s.close()
+    return {"value": round(n_out / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n_out, 1) * 1e3, 4),
+            "what": "vs_stab_push, %d calls: host frame in, stabilized host frame out per call (H2D + D2H inside the call)" % n_timed}
+
+
+def config2(vs, device, args):
+    """BASELINE configs[2]: 3840x2160, 400 corners, RollCorrection + AutoZoomCrop enabled."""
+    W, H = 3840, 2160
+    out = {"workload": "configs[2]: 1 stream 3840x2160, 400 corners, 3-level LK 21x21; frames resident in HBM"}
+    bgr = synth.make_clip(synth.SEED_CONFIG3, W, H, 6)
+    p = make_params(vs, max_corners=400)
+    # (a) the stream as a decoder hands it over: NV12 surfaces, batch mode
+    nv = [synth.bgr_to_nv12(f) for f in bgr]
+    BT = 16
+    ss = StreamSet(vs, device, p, [nv], W, H, capi.FMT_NV12, BT, BT, True)
+    ss.push(64)
+    ss.sync()
+    ss.push(2 * BT)
+    for s in ss.stabs:
+        s.set_profiling(1)
+        s.stage_times()
+    ss.sync()
+    f0 = ss.frames_out()
+    nb = 8
+    t0 = time.perf_counter()
+    ss.push(nb * BT)
+    ss.sync()
+    dt = time.perf_counter() - t0
+    fo = ss.frames_out() - f0
+    roof, _, _ = warp_roofline(ss, 2.0 * nv[0].nbytes, fo, "warp_affine_kernel<1> + <2> (Y and interleaved UV plane)")
+    out["nv12_stabilize"] = {"value": round(fo / dt, 1), "unit": "frames/s", "batch": BT, "timed_frames": fo, "roofline": roof}
+    ss.close()
+    # (b) the reference's order of operators on a 4K BGR frame: roll correction -> stabilize -> auto zoom/crop (each
+    # call finished before the next: the reference's loop is synchronous, examples/roll-correction-file.cpp:58-70)
+    fb = bgr[0].nbytes
+    d_f = capi.DevBuf(vs, fb * len(bgr))
+    for i, f in enumerate(bgr):
+        d_f.upload(f, i * fb)
+    d_r, d_s, d_z = capi.DevBuf(vs, fb), capi.DevBuf(vs, fb), capi.DevBuf(vs, fb)   # (the zoom stage returns the frame as it is when it finds no crop)
+    rc, az = vs.roll_correction(), vs.auto_zoom_crop()
+    st = vs.stabilizer(p, device=device)
+    order = clip_order(len(bgr), 40 + 100)
+
+    def one(i):
+        rc.correct_dev(d_f.ptr + order[i] * fb, W, H, W * 3, d_r.ptr, W * 3)
+        rc.sync()
+        k = st.push_dev(d_r.ptr, W, H, W * 3, capi.FMT_BGR8, d_s.ptr, W * 3)
+        st.sync()
+        if k:
+            az.apply_dev(d_s.ptr, W, H, W * 3, 3, d_z.ptr, W * 3)
+            az.sync()
+        return k
+    for i in range(40):
+        one(i)
+    t0 = time.perf_counter()
+    n = sum(one(i) for i in range(40, 140))
+    dt = time.perf_counter() - t0
+    out["roll_stabilize_zoomcrop_bgr"] = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n, 1) * 1e3, 3),
+                                          "what": "autoCorrectRoll -> stabilize -> autoZoomCrop per 4K BGR frame, one frame at a time"}
+    st.close()
+    for b in (d_f, d_r, d_s, d_z):
+        b.free()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=640)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps; a step = one batch of --batch frames per stream")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed steps in front of them")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU (batch mode)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--clip-frames", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and configs[2] measurements")
     ap.add_argument("--profile-stages", action="store_true", help="time every stage (adds event records)")
     ap.add_argument("--zero-copy", type=int, default=1,
                     help="frames are read where they lie in HBM instead of being copied into the instance's queue")
     ap.add_argument("--batch", type=int, default=32,
-                    help="batch mode: analysis stages of this many consecutive pushes run as one launch each (1 = per-frame pipeline)")
+                    help="frames per step: the analysis stages of this many consecutive pushes run as one launch each (1 = per-frame pipeline)")
     ap.add_argument("--warp-batch", type=int, default=8,
-                    help="deferred output: results of this many consecutive pushes are warped by one launch (1 = one launch per push)")
+                    help="per-frame pipeline only (--batch 1): results of this many consecutive pushes are warped by one launch")
     ap.add_argument("--config", default=None,
                     help="a config.yaml of the reference's apps: its 'stabilizer' section replaces the configs[1] "
                          "parameters (not the headline workload any more: no cpu_baseline, the workload string says so)")
@@ -133,122 +308,62 @@ def main():
     fb = W * H * 3
     S = args.streams
     # synthetic clips: global stream g (owned by rank g % world) uses seed base + g
-    clips, d_in = [], []
     my_streams = vsdist.streams_of_rank(rank, n_gpus, S * n_gpus)
     assert len(my_streams) == S
     fanout = None
+    clips = [synth.make_clip(synth.SEED_CONFIG2 + g, W, H, args.clip_frames) for g in my_streams]
     if args.fanout and world > 1:
-        # ingest on rank 0: the frame payloads travel to the owning GPUs with one scatter; the received
-        # device memory is what the stabilizers read (zero-copy), so the timed region is unchanged
-        import numpy as np
+        # ingest on rank 0: the frame payloads travel to the owning GPUs with one scatter, timed on its own
         payloads = None
         if rank == 0:
             payloads = [np.concatenate([np.stack(synth.make_clip(synth.SEED_CONFIG2 + g, W, H, args.clip_frames)).reshape(-1)
                                         for g in vsdist.streams_of_rank(r, n_gpus, S * n_gpus)]) for r in range(world)]
         nbytes = fb * args.clip_frames * S
         recv, secs = comm.fan_out(payloads, nbytes)
-
-        class _View:                      # same interface as DevBuf for the step loop; `recv` keeps the memory alive
-            def __init__(self, ptr):
-                self.ptr = ptr
-        if comm.device == "cuda":
-            base = recv.data_ptr()
-        else:                             # gloo rehearsal: the payload arrived in host memory
-            staged = capi.DevBuf.from_array(vs, recv.numpy())
-            base = staged.ptr
-        for j in range(S):
-            d_in.append(_View(base + j * fb * args.clip_frames))
-        if rank == 0:
-            clips.append(list(payloads[0][:fb * args.clip_frames].reshape(args.clip_frames, H, W, 3)))
+        got = (recv.cpu().numpy() if comm.device == "cuda" else recv.numpy()).reshape(S, args.clip_frames, H, W, 3)
+        clips = [list(got[j]) for j in range(S)]
         sent = nbytes * (world - 1)
         fanout = {"bytes": sent, "ms": round(secs * 1e3, 3), "GBps": round(sent / secs / 1e9, 2) if secs > 0 else None,
                   "what": "scatter of %d frames per stream from rank 0 to %d ranks (torch.distributed.scatter, %s)" % (
                       args.clip_frames, world - 1, "RCCL" if comm.device == "cuda" else "gloo, host memory")}
-    else:
-        for g in my_streams:
-            seed = synth.SEED_CONFIG2 + g
-            frames = synth.make_clip(seed, W, H, args.clip_frames)
-            clips.append(frames)
-            buf = capi.DevBuf(vs, fb * len(frames))
-            for i, f in enumerate(frames):
-                buf.upload(f, i * fb)
-            d_in.append(buf)
-    BT = max(1, min(32, args.batch))
-    WB = max(1, min(32, args.warp_batch if BT == 1 else BT))
-    NOUT = max(2 * WB, 3 * BT)        # a result stays untouched until its batch and the next one have been issued
-    d_out = [[capi.DevBuf(vs, fb) for _ in range(NOUT)] for _ in range(S)]
-    stabs = [vs.stabilizer(make_params(vs, args.config), device=local_rank) for _ in range(S)]
-    for s in stabs:
-        s.set_batch(BT)
-        s.set_zero_copy(bool(args.zero_copy))
-        s.set_warp_batch(WB)
 
-    preroll = 64   # past the 29-frame warm-up of smoothingRadius 30: every timed step produces a frame
-    total = preroll + args.warmup + args.steps
-    order = clip_order(args.clip_frames, total)
-
-    def step(i):
-        for j in range(S):
-            stabs[j].push_dev(d_in[j].ptr + order[i] * fb, W, H, W * 3, capi.FMT_BGR8, d_out[j][i % NOUT].ptr, W * 3)
+    params = make_params(vs, args.config)
+    ss = StreamSet(vs, local_rank, params, clips, W, H, capi.FMT_BGR8, args.batch, args.warp_batch, args.zero_copy)
+    BT = ss.BT
+    preroll = 64   # past the 29-frame warm-up of smoothingRadius 30: every timed push produces a frame
 
     def sync_all():
-        for s in stabs:
-            s.sync()
+        ss.sync()
         comm.device_sync()
 
-    barrier = comm.barrier
-
-    for i in range(preroll):
-        step(i)
+    ss.push(preroll)
     sync_all()
-    for i in range(preroll, preroll + args.warmup):
-        step(i)
-    for s in stabs:
+    ss.push(args.warmup * BT)
+    for s in ss.stabs:
         s.set_profiling(2 if args.profile_stages else 1)
         s.stage_times()          # drop anything recorded so far
     sync_all()
-    barrier()
+    comm.barrier()
     sync_all()
-    frames_before = sum(s.counters().frames_out for s in stabs)
+    frames_before = ss.frames_out()
     t0 = time.perf_counter()
-    for i in range(preroll + args.warmup, total):
-        step(i)
+    ss.push(args.steps * BT)
     sync_all()
-    barrier()
+    comm.barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
-
     elapsed = comm.max_over_ranks(elapsed)
 
-    # per-stage device time of the timed region (HIP events on the instance streams)
-    stage_ms = [0.0] * 8
-    stage_n = [0] * 8
-    for s in stabs:
-        ms, n = s.stage_times()
-        for k in range(8):
-            stage_ms[k] += ms[k]
-            stage_n[k] += n[k]
-    frames_out = sum(s.counters().frames_out for s in stabs)
-    frames_out_timed = frames_out - frames_before
-    assert frames_out_timed == args.steps * S, "timed steps did not all produce frames"
+    frames_out_timed = ss.frames_out() - frames_before
+    assert frames_out_timed == args.steps * BT * S, "timed steps did not all produce frames"
+    roof, stage_ms, stage_n = warp_roofline(ss, 2.0 * fb, frames_out_timed,
+                                            "warp_tab_kernel (+ warp_tables_kernel)" if BT >= 4 else "warp_affine_kernel<3>")
     # throughput counters of every rank (the only inter-GPU traffic of the path)
-    per_rank = comm.gather_counters([rank, args.steps * S, frames_out])
+    per_rank = comm.gather_counters([rank, args.steps * BT * S, ss.frames_out()])
 
     if rank == 0:
-        frames_per_launch = frames_out_timed / max(stage_n[7], 1)   # WB when every launch is full
-        warp_bytes = 2.0 * fb * frames_per_launch                # algorithmic bytes per launch (2 x frame bytes per frame)
-        warp_avg_ms = stage_ms[7] / max(stage_n[7], 1)
-        achieved = warp_bytes / (warp_avg_ms * 1e-3) / 1e9 if warp_avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "warp_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                t = json.load(open(pmc))
-                # measured on full launches of t["frames_per_launch"] frames of 1920x1080 BGR8; scale to this run's launch
-                traffic = round(t["hbm_bytes_per_launch"] / t["frames_per_launch"] * frames_per_launch * (fb / (1920 * 1080 * 3.0)))
-            except Exception:
-                traffic = None
-        total_frames = args.steps * S * n_gpus
+        traffic_from_counters(vs, roof, fb)
+        total_frames = args.steps * BT * S * n_gpus
         out = {
             "metric": "stabilized frames/sec @1080p (whole job; warp-stage HBM GB/s in roofline)",
             "value": round(total_frames / elapsed, 2),
@@ -267,13 +382,10 @@ def main():
                        if not args.config else
                        ("custom: %d stream(s)/GPU %dx%d BGR8, stabilizer parameters from %s; frames resident in HBM"
                         % (S, W, H, os.path.basename(args.config))),
-                       "streams_per_gpu": S, "batch": BT, "warp_batch": WB, "zero_copy": bool(args.zero_copy),
-                       "timed_frames_per_rank": [int(r[1]) for r in per_rank]},
-            "roofline": {"bound": "hbm", "kernel": "warp_affine_kernel<3>", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic, "bytes_per_launch": warp_bytes,
-                         "frames_per_launch": round(frames_per_launch, 3),
-                         "avg_launch_us": round(warp_avg_ms * 1e3, 3), "launches": stage_n[7]},
+                       "streams_per_gpu": S, "frames_per_step": BT, "step": "one batch of %d stabilize() calls per stream" % BT,
+                       "warp_batch": ss.WB, "zero_copy": bool(args.zero_copy),
+                       "timed_frames_per_rank": [int(r[1]) for r in per_rank], "build": vs.lib.vs_build_tag().decode()},
+            "roofline": roof,
         }
         if fanout is not None:
             out["fanout"] = fanout
@@ -281,12 +393,14 @@ def main():
             names = ["copy_in", "gray", "pyramid", "lk", "ransac", "traj", "gftt", "warp"]
             out["stage_us_per_launch"] = {names[k]: round(stage_ms[k] / max(stage_n[k], 1) * 1e3, 2) for k in range(8)}
             out["stage_launches"] = {names[k]: stage_n[k] for k in range(8)}
+    ss.close()
+    if rank == 0:
+        if n_gpus == 1 and not args.no_extras and not args.config:
+            out["with_pcie"] = host_api_rate(vs, local_rank, params, clips[0])
+            out["configs"] = {"configs[2]": config2(vs, local_rank, args)}
         if n_gpus == 1 and not args.no_cpu_baseline and not args.config:
             out["cpu_baseline"] = cpu_baseline(W, H, clips[0], clip_order)
         print(json.dumps(out), flush=True)
-
-    for s in stabs:
-        s.close()
     comm.close()
 
 

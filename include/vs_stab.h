@@ -182,6 +182,9 @@ typedef struct vs_enh vs_enh;     /* opaque enhancer scratch (tables, stream)  *
 
 /* ---- library ------------------------------------------------------------- */
 int          vs_abi_version(void);
+/* Short tag of the kernel sources this library was built from (hash of the .hip files): measurements that are kept
+ * in files (profiles/warp_traffic.json) name the build they belong to. */
+const char*  vs_build_tag(void);
 const char*  vs_build_info(void);          /* arch, compiler, feature string  */
 int          vs_device_count(void);        /* 0 when no usable GPU            */
 void         vs_params_default(vs_params_c* p);

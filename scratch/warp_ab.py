@@ -41,11 +41,13 @@ for i, v in enumerate(args.variants):
         os.environ[k] = val
     cp = os.path.join(tmpdir, "v%d.so" % i)       # a copy per variant: dlopen of one path twice gives one library
     shutil.copy(os.path.join(ROOT, path) if not os.path.isabs(path) else path, cp)
-    libs.append((name, capi.VsLib(C.CDLL(cp))))
+    libs.append((name, capi.VsLib(C.CDLL(cp)), [kv.partition("=")[0] for kv in filter(None, envs.split(","))], dict(kv.split("=", 1) for kv in filter(None, envs.split(",")))))
     for kv in filter(None, envs.split(",")):
         os.environ.pop(kv.partition("=")[0], None)
 
 vs0 = libs[0][1]
+_libs_env = libs
+libs = [(n, v) for n, v, _, _ in libs]
 world = synth.make_world(synth.SEED_CONFIG2, W, H)
 rng = np.random.default_rng(1)
 d_in = capi.DevBuf(vs0, fb * B)
@@ -65,9 +67,12 @@ def run(vs, n):
 
 
 ref = None
-for name, vs in libs:
+for (name, vs), (_, _, keys, env) in zip(libs, _libs_env):
     d_out.zero()
+    os.environ.update(env)          # a library reads its VS_WARP_* settings at its first launch
     run(vs, 1)
+    for k in keys:
+        os.environ.pop(k, None)
     vs.sync()
     out = d_out.download((B, H, W, 3), np.uint8)
     if ref is None:

@@ -64,6 +64,44 @@ def test_warp_batch_matches_single(gpu, oracle, clip_small):
         assert np.array_equal(out[i], oracle.warp_affine(imgs[i], Ms[i])), i
 
 
+def test_warp_multi_frame_launch_every_matrix_class(gpu, oracle, clip_small):
+    """Launches of four and more frames take the persistent kernel (coordinate tables, double-buffered tiles, prefetch):
+    every matrix class of the single-frame test in ONE launch, so interior tiles, tiles that leave the image on every
+    side, boxes that do not fit the staging area and frames that are entirely out of view alternate inside the
+    workgroups' runs of tiles."""
+    imgs = np.stack([clip_small[i % len(clip_small)] for i in range(len(MATS))])
+    out = gpu.warp_affine(imgs, np.array(MATS, np.float32))
+    for i, M in enumerate(MATS):
+        assert np.array_equal(out[i], oracle.warp_affine(imgs[i], M)), i
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (17, 129), (240, 321), (33, 130), (270, 482), (16, 128), (48, 515)])
+def test_warp_multi_frame_launch_ragged_sizes(gpu, oracle, shape):
+    """Widths that are no multiple of 4 put groups of staged pixels across the right image edge; heights that are no
+    multiple of 16 leave partial tiles."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    h, w = shape
+    Ms = np.array([[0.9998, 0.02, 1.3, -0.02, 0.9998, -0.6], [1, 0, 0, 0, 1, 0], [1, 0, -2.5, 0, 1, 3.75],
+                   [0.9999, -0.012, -4.0, 0.012, 0.9999, 2.0], [1.0, 0.0, 6.0, 0.0, 1.0, -5.0]], np.float32)
+    imgs = rng.integers(0, 256, (len(Ms), h, w, 3), dtype=np.uint8)
+    out = gpu.warp_affine(imgs, Ms)
+    for i in range(len(Ms)):
+        assert np.array_equal(out[i], oracle.warp_affine(imgs[i], Ms[i])), (shape, i)
+
+
+def test_warp_multi_frame_launch_full_hd(gpu, oracle):
+    """Six 1920x1080 frames (6120 tiles: runs of several tiles per workgroup) with the small rotations of a
+    stabilizer, checked in full."""
+    world = synth.make_world(synth.SEED_CONFIG2, 1920, 1080)
+    rng = np.random.default_rng(5)
+    imgs = np.stack([synth.render_frame(world, 1920, 1080, ((300 + 3 * b) * 256, (280 + 2 * b) * 256, 90 + 5 * b)) for b in range(6)])
+    Ms = np.array([[np.cos(a), -np.sin(a), dx, np.sin(a), np.cos(a), dy]
+                   for a, dx, dy in zip(rng.normal(0, 0.004, 6), rng.normal(0, 6, 6), rng.normal(0, 6, 6))], np.float32)
+    out = gpu.warp_affine(imgs, Ms)
+    for i in range(6):
+        assert np.array_equal(out[i], oracle.warp_affine(imgs[i], Ms[i], threads=8)), i
+
+
 def test_warp_full_hd_properties(gpu, oracle):
     """BASELINE config 2 size: identity = exact copy; integer shift = exact shift;
     a checksum of the rotated frame equals the oracle's."""

@@ -45,6 +45,10 @@ using namespace vsd;
 extern "C" {
 
 int vs_abi_version(void) { return VS_STAB_ABI_VERSION; }
+#ifndef VS_BUILD_TAG
+#define VS_BUILD_TAG "untagged"
+#endif
+const char* vs_build_tag(void) { return VS_BUILD_TAG; }
 
 const char* vs_build_info(void) {
     return "libvideo-stab gfx950 (CDNA4, wave64) hipcc -ffp-contract=off; warp=classic-fixed-point";

@@ -139,6 +139,10 @@ class VsLib:
         L = lib
         vp = C.c_void_p
         L.vs_abi_version.restype = C.c_int
+        try:
+            L.vs_build_tag.restype = C.c_char_p
+        except AttributeError:      # a library of an earlier build (A/B measurements)
+            pass
         L.vs_build_info.restype = C.c_char_p
         L.vs_device_count.restype = C.c_int
         L.vs_params_default.argtypes = [C.POINTER(VsParams)]
