@@ -365,17 +365,17 @@ __device__ __forceinline__ void load_map(const WarpArgs& a, int bz, double* m) {
 // Coordinate tables of a frame, once per frame instead of once per tile (WarpAffineInvoker's adelta / bdelta / X0 / Y0:
 // double arithmetic, one rounding each; ~6000 terms per 1080p frame).  The warp kernels then hold no double-precision
 // arithmetic at all.  Layout of a frame's table (ints):
-//   [0, 4)                     source and destination pointer of the frame
-//   [4, 4 + 4 gx)              per tile column: adelta, bdelta of its first and last column  (ad0, ad1, bd0, bd1)
+//   [0, 8 gx)                  per tile column: source and destination pointer of the frame, adelta and bdelta of its first
+//                              and last column  (src, dst, ad0, ad1, bd0, bd1)
 //   [tab_row, + 4 gy)          per tile row: X0, Y0 of its first and last row                 (Xa, Xb, Ya, Yb)
 //   [tab_ad, + dw) adelta(x); [+dw) bdelta(x); [+dh) X0(y); [+dh) Y0(y)
-// so that a tile's box follows from three 16-byte scalar loads.
-constexpr int TAB_COL = 4;
+// so that everything a tile needs before its staging loads comes with ONE 32-byte and ONE 16-byte scalar load.
+constexpr int TAB_COL = 8;     // ints per tile column record
 struct TabLayout { int row, ad, stride; };
 inline TabLayout tab_layout(int dw, int dh) {
     const int gx = (dw + TW - 1) / TW, gy = (dh + TH - 1) / TH;
     TabLayout t;
-    t.row = TAB_COL + 4 * gx;
+    t.row = TAB_COL * gx;
     t.ad = t.row + 4 * gy;
     t.stride = (t.ad + 2 * dw + 2 * dh + 3) & ~3;
     return t;
@@ -389,12 +389,6 @@ __global__ __launch_bounds__(NT) void warp_tables_kernel(WarpArgs a) {
     const int dw = a.c.dw, dh = a.c.dh;
     const int gx = (dw + TW - 1) / TW, gy = (dh + TH - 1) / TH;
     int j = blockIdx.x * NT + threadIdx.x;
-    if (j == 0) {
-        const uint8_t* src = a.use_list ? a.srcs[bz] : a.src + (size_t)bz * a.sframe;
-        uint8_t* dst = a.use_list ? a.dsts[bz] : a.dst + (size_t)bz * a.dframe;
-        *reinterpret_cast<const uint8_t**>(T) = src;
-        *reinterpret_cast<uint8_t**>(T + 2) = dst;
-    }
     if (j < dw) {
         const double dv = (double)j;
         T[a.tab_ad + j] = coord_term(m[0], 0.0, dv);
@@ -411,9 +405,11 @@ __global__ __launch_bounds__(NT) void warp_tables_kernel(WarpArgs a) {
     j -= dh;
     if (j < gx) {
         const double v0 = (double)(j * TW), v1 = (double)(min(j * TW + TW, dw) - 1);
-        int32_t* C = T + TAB_COL + 4 * j;
-        C[0] = coord_term(m[0], 0.0, v0); C[1] = coord_term(m[0], 0.0, v1);
-        C[2] = coord_term(m[3], 0.0, v0); C[3] = coord_term(m[3], 0.0, v1);
+        int32_t* C = T + TAB_COL * j;
+        *reinterpret_cast<const uint8_t**>(C) = a.use_list ? a.srcs[bz] : a.src + (size_t)bz * a.sframe;
+        *reinterpret_cast<uint8_t**>(C + 2) = a.use_list ? a.dsts[bz] : a.dst + (size_t)bz * a.dframe;
+        C[4] = coord_term(m[0], 0.0, v0); C[5] = coord_term(m[0], 0.0, v1);
+        C[6] = coord_term(m[3], 0.0, v0); C[7] = coord_term(m[3], 0.0, v1);
         return;
     }
     j -= gx;
@@ -455,7 +451,7 @@ __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
         // lane; they travel together with the staging loads of step 2 and reach LDS in front of the one barrier
         const size_t tb = (size_t)bz * a.tab_stride;
         const __attribute__((address_space(4))) int32_t* Ts = (const __attribute__((address_space(4))) int32_t*)(a.tabs + tb);
-        const __attribute__((address_space(4))) int32_t* Cc = Ts + TAB_COL + 4 * blockIdx.x;
+        const __attribute__((address_space(4))) int32_t* Cc = Ts + TAB_COL * blockIdx.x + 4;
         const __attribute__((address_space(4))) int32_t* Cr = Ts + a.tab_row + 4 * blockIdx.y;
         ad0 = Cc[0]; ad1 = Cc[1]; bd0 = Cc[2]; bd1 = Cc[3];
         Xa = Cr[0]; Xb = Cr[1]; Ya = Cr[2]; Yb = Cr[3];
@@ -618,9 +614,11 @@ __device__ __forceinline__ void load_terms(const TabK& k, const TileIn& t, int t
     }
 }
 
-__device__ __forceinline__ void store_terms(int* tab, int tid, int tv0, int tv1) {
+// (subx, suby): the origin of the staged box in 1/1024 px, taken off the row terms of a fast tile so that the blend's tap
+// address is relative to the staged tile.
+__device__ __forceinline__ void store_terms(int* tab, int tid, int tv0, int tv1, int subx = 0, int suby = 0) {
     if (tid < TW) { tab[tid] = tv0; tab[TW + tid] = tv1; }
-    else if (tid < TW + TH) { tab[2 * TW + (tid - TW)] = tv0; tab[2 * TW + TH + (tid - TW)] = tv1; }
+    else if (tid < TW + TH) { tab[2 * TW + (tid - TW)] = tv0 - subx; tab[2 * TW + TH + (tid - TW)] = tv1 - suby; }
 }
 
 // Staging loads of a fast tile.  ONE load instruction per pass for every kind of tile (interior tiles and tiles that
@@ -666,7 +664,6 @@ __device__ __forceinline__ void issue_tile(const TabK& k, const TileIn& t, const
         for (int q = 0; q < SPASS; q++)
             if (SR * q < b.bh) pf.d[q] = *reinterpret_cast<const U4*>(t.src + off[q]);
     }
-    load_terms(k, t, tid, pf.tv0, pf.tv1);
 }
 
 __device__ __forceinline__ void store_tile(const TabK& k, const TileIn& t, const TileBox& b, int tid, const TilePre& pf, uint32_t* tile, int* tab) {
@@ -701,41 +698,46 @@ __device__ __forceinline__ void store_tile(const TabK& k, const TileIn& t, const
             }
         }
     }
-    store_terms(tab, tid, pf.tv0, pf.tv1);
+    store_terms(tab, tid, pf.tv0, pf.tv1, b.bx0a << 10, b.by0 << 10);
 }
 
-// ---- one tile per workgroup, everything the prologue needs in the first 16 dwords of the kernel arguments ------
-// gfx950 preloads the leading kernel arguments into scalar registers when the wave is launched (k_warp.hip is built
-// with -mllvm -amdgpu-kernarg-preload-count=16), so the three scalar loads of the tile's inputs (frame pointers, corner
-// terms) go out with the first instructions: ONE round trip in front of the staging loads instead of two (kernel
-// arguments, then the table).  Staging through issue_tile / store_tile: tiles that leave the image take the same
+// ---- one tile per workgroup, everything the prologue needs in 10 dwords of kernel arguments -------------------
+// gfx950 preloads the leading kernel arguments (up to 14 dwords) into scalar registers when the wave is launched
+// (k_warp.hip is built with -mllvm -amdgpu-kernarg-preload-count=16), so the two scalar loads of the tile's inputs
+// (frame pointers + column terms, row terms) go out with the first instructions: ONE round trip in front of the staging
+// loads.  (Measured with s_memtime stamps: an argument that is not preloaded, or an input that is fetched by a third
+// load later on, each cost another ~1000 cycles of a workgroup's ~9000.)  Staging through issue_tile / store_tile: tiles that leave the image take the same
 // 16-byte loads as interior ones.
-__global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, size_t sstride, size_t dstride,
-                                                      int sw, int sh, int dw, int dh, int src_aligned, int dst_aligned, int border) {
+__global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
+                                                      uint32_t swh, uint32_t dwh, uint32_t flags) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_PX];
     __shared__ __attribute__((aligned(16))) uint32_t obuf[OBUF];
     __shared__ int s_tab[TABN];
     __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
     typedef const __attribute__((address_space(4))) int32_t* cptr;
-    typedef const __attribute__((address_space(4))) unsigned long long* cptr64;
     typedef __attribute__((address_space(1))) uint8_t* gptr;
     const int tid = threadIdx.x;
     TabK k;
-    k.c.sstride = sstride; k.c.dstride = dstride; k.c.sw = sw; k.c.sh = sh; k.c.dw = dw; k.c.dh = dh;
-    k.c.src_aligned = src_aligned; k.c.dst_aligned = dst_aligned; k.c.border = border;
+    k.c.sstride = sstride; k.c.dstride = dstride;
+    k.c.sw = swh & 0xFFFFu; k.c.sh = swh >> 16; k.c.dw = dwh & 0xFFFFu; k.c.dh = dwh >> 16;
+    k.c.src_aligned = flags & 1u; k.c.dst_aligned = (flags >> 1) & 1u; k.c.border = flags >> 2;
     k.tabs = tabs; k.tab_stride = tab_stride; k.tab_row = tab_row; k.tab_ad = tab_ad;
     k.gx = gridDim.x; k.gy = gridDim.y;
     TileIn cur;
     {
         cptr Ts = (cptr)(const int32_t*)(tabs + (size_t)blockIdx.z * tab_stride);
-        cptr64 H = (cptr64)Ts;
-        cptr Cc = Ts + TAB_COL + 4 * blockIdx.x, Cr = Ts + tab_row + 4 * blockIdx.y;
-        cur.src = (const uint8_t*)(gptr)H[0];
-        cur.dst = (uint8_t*)(gptr)H[1];
-        cur.ad0 = Cc[0]; cur.ad1 = Cc[1]; cur.bd0 = Cc[2]; cur.bd1 = Cc[3];
-        cur.Xa = Cr[0]; cur.Xb = Cr[1]; cur.Ya = Cr[2]; cur.Yb = Cr[3];
+        // one 32-byte and one 16-byte scalar load, issued together (as separate loads the compiler moves the frame
+        // pointers down to their first use: a third round trip in front of the staging loads)
+        typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
+        typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+        const i32x8 cc = *(const __attribute__((address_space(4))) i32x8*)(Ts + TAB_COL * blockIdx.x);
+        const i32x4 cr = *(const __attribute__((address_space(4))) i32x4*)(Ts + tab_row + 4 * blockIdx.y);
+        cur.src = (const uint8_t*)(gptr)((unsigned long long)(uint32_t)cc[0] | (unsigned long long)(uint32_t)cc[1] << 32);
+        cur.dst = (uint8_t*)(gptr)((unsigned long long)(uint32_t)cc[2] | (unsigned long long)(uint32_t)cc[3] << 32);
+        cur.ad0 = cc[4]; cur.ad1 = cc[5]; cur.bd0 = cc[6]; cur.bd1 = cc[7];
+        cur.Xa = cr[0]; cur.Xb = cr[1]; cur.Ya = cr[2]; cur.Yb = cr[3];
         cur.bz = blockIdx.z; cur.x0 = blockIdx.x * TW; cur.y0 = blockIdx.y * TH;
-        cur.x1 = min(cur.x0 + TW, dw) - 1; cur.y1 = min(cur.y0 + TH, dh) - 1;
+        cur.x1 = min(cur.x0 + TW, k.c.dw) - 1; cur.y1 = min(cur.y0 + TH, k.c.dh) - 1;
     }
     if (tid >= NT - 32) {      // weight table of the fast path (see blend3_fast)
         const uint32_t f = tid - (NT - 32);
@@ -743,14 +745,16 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
         *reinterpret_cast<uint4*>(lut + f * LUT_STRIDE) =
             make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
     }
+    // this lane's share of the tile's coordinate terms does not depend on the box: requested while the scalar loads travel
+    TilePre pf;
+    pf.tv0 = 0; pf.tv1 = 0;
+    load_terms(k, cur, tid, pf.tv0, pf.tv1);
     const TileBox cb = tile_box(k.c, cur);
     if (cb.pre) {
-        TilePre pf;
         issue_tile(k, cur, cb, tid, pf);
         store_tile(k, cur, cb, tid, pf, tile, s_tab);
     } else {
-        int tv0 = 0, tv1 = 0;
-        load_terms(k, cur, tid, tv0, tv1);
+        const int tv0 = pf.tv0, tv1 = pf.tv1;
         if (cb.use_lds) {
             const int pitch = cb.fast ? FPITCH : cb.bw;
             const int gpr = cb.bw >> 2;
@@ -765,11 +769,10 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
                 *reinterpret_cast<uint4*>(&tile[row * pitch + 4 * gxx]) = px;
             }
         }
-        store_terms(s_tab, tid, tv0, tv1);
+        store_terms(s_tab, tid, tv0, tv1, cb.fast ? cb.bx0a << 10 : 0, cb.fast ? cb.by0 << 10 : 0);
     }
     __syncthreads();
-    if (cb.fast) emit_fast(k.c, cur.dst, tile, obuf, lut, s_tab, s_tab + TW, s_tab + 2 * TW, s_tab + 2 * TW + TH, cur.x0, cur.y0, cur.x1, cur.y1,
-                           -(cb.by0 * FPITCH + cb.bx0a), tid);
+    if (cb.fast) emit_fast(k.c, cur.dst, tile, obuf, lut, s_tab, s_tab + TW, s_tab + 2 * TW, s_tab + 2 * TW + TH, cur.x0, cur.y0, cur.x1, cur.y1, 0, tid);
     else if (cb.use_lds) emit_rows<3, true>(k.c, cur.src, cur.dst, tile, s_tab, s_tab + TW, s_tab + 2 * TW, s_tab + 2 * TW + TH, cur.x0, cur.y0, cur.x1,
                                             cur.y1, cb.bx0a, cb.by0, cb.bw, tid);
     else emit_rows<3, false>(k.c, cur.src, cur.dst, tile, s_tab, s_tab + TW, s_tab + 2 * TW, s_tab + 2 * TW + TH, cur.x0, cur.y0, cur.x1, cur.y1,
@@ -785,16 +788,23 @@ bool tab_kernel_setting() {
     return v;
 }
 
+// what: VS_WARP_ALL = tables (when d_tabs is given) and warp; VS_WARP_TABLES_ONLY / VS_WARP_ONLY = the two halves apart, so
+// that a caller whose maps are ready long before it warps (the batch tail of the stabilizer) builds the tables then.
 template <int CN>
-void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, hipStream_t st) {
+void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, int what, hipStream_t st) {
     a.tabs = d_tabs;
     const TabLayout tl = tab_layout(a.c.dw, a.c.dh);
     a.tab_stride = tl.stride; a.tab_row = tl.row; a.tab_ad = tl.ad;
     if (d_tabs) {
-        hipLaunchKernelGGL(warp_tables_kernel, dim3((a.c.dw + a.c.dh + grid.x + grid.y + NT - 1) / NT, grid.z), dim3(NT), 0, st, a);
-        if (CN == 3 && tab_kernel_setting()) {
-            hipLaunchKernelGGL(warp_tab_kernel, grid, dim3(NT), 0, st, (gtab_t)a.tabs, a.tab_stride, a.tab_row, a.tab_ad, a.c.sstride, a.c.dstride,
-                               a.c.sw, a.c.sh, a.c.dw, a.c.dh, a.c.src_aligned, a.c.dst_aligned, a.c.border);
+        if (what != VS_WARP_ONLY)
+            hipLaunchKernelGGL(warp_tables_kernel, dim3((a.c.dw + a.c.dh + grid.x + grid.y + NT - 1) / NT, grid.z), dim3(NT), 0, st, a);
+        if (what == VS_WARP_TABLES_ONLY) return;
+        const bool packs = a.c.sw < 65536 && a.c.sh < 65536 && a.c.dw < 65536 && a.c.dh < 65536 && a.c.sstride < (1ull << 32) && a.c.dstride < (1ull << 32);
+        if (CN == 3 && packs && tab_kernel_setting()) {
+            // 10 dwords of arguments: all of them among the 14 the hardware preloads into scalar registers
+            hipLaunchKernelGGL(warp_tab_kernel, grid, dim3(NT), 0, st, (gtab_t)a.tabs, a.tab_stride, a.tab_row, a.tab_ad, (uint32_t)a.c.sstride,
+                               (uint32_t)a.c.dstride, (uint32_t)a.c.sw | (uint32_t)a.c.sh << 16, (uint32_t)a.c.dw | (uint32_t)a.c.dh << 16,
+                               (uint32_t)(a.c.src_aligned ? 1 : 0) | (uint32_t)(a.c.dst_aligned ? 2 : 0) | (uint32_t)a.c.border << 2);
         } else {
             hipLaunchKernelGGL((warp_affine_kernel<CN, true>), grid, dim3(NT), 0, st, a);
         }
@@ -803,10 +813,10 @@ void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, hipStream_t st) {
     }
 }
 
-void launch_cn(WarpArgs& a, dim3 grid, int cn, int32_t* d_tabs, hipStream_t st) {
-    if (cn == 3) launch_one<3>(a, grid, d_tabs, st);
-    else if (cn == 1) launch_one<1>(a, grid, d_tabs, st);
-    else launch_one<2>(a, grid, d_tabs, st);
+void launch_cn(WarpArgs& a, dim3 grid, int cn, int32_t* d_tabs, hipStream_t st, int what = VS_WARP_ALL) {
+    if (cn == 3) launch_one<3>(a, grid, d_tabs, what, st);
+    else if (cn == 1) launch_one<1>(a, grid, d_tabs, what, st);
+    else launch_one<2>(a, grid, d_tabs, what, st);
 }
 
 void fill_common(WarpArgs& a, const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh, uint8_t* d_dst,
@@ -882,8 +892,8 @@ int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int 
 // all share one geometry.  d_Minv: inverse maps on the device, minv_stride doubles apart.
 int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
                             size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, int32_t* d_tabs,
-                            hipStream_t st) {
-    if (n < 1 || n > MAXB || !srcs || !dsts || bad_args(srcs[0], dsts[0], d_Minv, sstride, sw, sh, dstride, dw, dh, cn, n)) {
+                            hipStream_t st, int what) {
+    if ((what != VS_WARP_ALL && !d_tabs) || n < 1 || n > MAXB || !srcs || !dsts || bad_args(srcs[0], dsts[0], d_Minv, sstride, sw, sh, dstride, dw, dh, cn, n)) {
         set_last_error("warp_affine_list: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
@@ -900,7 +910,7 @@ int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, in
     a.Minv_dev = d_Minv;
     a.minv_stride = minv_stride;
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, n);
-    launch_cn(a, grid, cn, d_tabs, st);
+    launch_cn(a, grid, cn, d_tabs, st, what);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

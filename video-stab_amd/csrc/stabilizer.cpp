@@ -174,7 +174,9 @@ struct vs_stab {
     std::vector<PendWarp> pend;
     size_t pend_stride = 0;
     double* d_MinvB[2] = {nullptr, nullptr};   // inverse maps of the pending frames, 12 doubles each; two sets
-    int32_t* d_tabs[2] = {nullptr, nullptr};   // coordinate tables of a batched warp launch: [0] launches on `main`, [1] on the warp stream
+    // coordinate tables of batched warp launches: [set] frame plane and [2 + set] chroma plane of the batch whose maps are in
+    // d_MinvB[set] (built behind the batch tail, used by the warps issued one run_batch later); [4] deferred warps
+    int32_t* d_tabs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int pend_set = 0;
     hipEvent_t ev_emit = nullptr, ev_warp[2] = {nullptr, nullptr};
     bool warp_valid[2] = {false, false};
@@ -212,7 +214,7 @@ struct vs_stab {
     // batch mode: the warps of batch k are issued during run_batch(k+1), behind the detection of batch k+1, so
     // that the (HBM-bound) warp has the GPU to itself: pre/det of k+1 overlap the tracking and tail of k instead
     struct ReadyWarps {
-        bool valid = false;
+        bool valid = false, tabs_built = false;
         int n = 0, set = 0;
         size_t stride = 0;
         const uint8_t* srcs[BATCH_MAX];
@@ -385,7 +387,8 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
     size_t o_MinvB[2] = {take((size_t)BATCH_MAX * 96), take((size_t)BATCH_MAX * 96)};
     const size_t tab_bytes = warp_tabs_ints(w, h, WARP_BATCH_MAX) * sizeof(int32_t);
-    size_t o_tabs[2] = {take(tab_bytes), take(tab_bytes)};
+    size_t o_tabs[5];
+    for (auto& o : o_tabs) o = take(tab_bytes);
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
     S_HIP(s, hipMemsetAsync(s->d_all, 0, off, s->st));
     uint8_t* b = s->d_all;
@@ -416,7 +419,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->d_traj = (TrajState*)(b + o_traj);
     s->d_M = (float*)(b + o_M); s->d_Minv = (double*)(b + o_Minv); s->d_dbg = (vs_debug_frame*)(b + o_dbg);
     s->d_MinvB[0] = (double*)(b + o_MinvB[0]); s->d_MinvB[1] = (double*)(b + o_MinvB[1]);
-    s->d_tabs[0] = (int32_t*)(b + o_tabs[0]); s->d_tabs[1] = (int32_t*)(b + o_tabs[1]);
+    for (int i = 0; i < 5; i++) s->d_tabs[i] = (int32_t*)(b + o_tabs[i]);
     s->pend.clear(); s->pend_set = 0; s->warp_valid[0] = s->warp_valid[1] = false;
     // GFTT scratch sized for the larger of the two detection images
     const int gmaxw = std::max(s->aw, 480), gmaxh = std::max(s->ah, 270);
@@ -608,7 +611,7 @@ int flush_warps(vs_stab* s, bool on_main) {
     {
         StageScope t(s, VS_STAGE_WARP, ws);
         rc = launch_warp_affine_list(srcs, dsts, n, s->src_pitch, s->w, s->h, s->pend_stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[set], 12, n >= 4 ? s->d_tabs[on_main ? 0 : 1] : nullptr, ws);
+                                     s->d_MinvB[set], 12, n >= 4 ? s->d_tabs[4] : nullptr, ws);
     }
     if (hipEventRecord(s->ev_warp[set], ws) == hipSuccess) s->warp_valid[set] = true;
     for (int i = 0; i < n; i++) {
@@ -643,17 +646,19 @@ int defer_output(vs_stab* s, int idx, const uint8_t* frame, uint8_t* d_out, size
     return VS_OK;
 }
 
-// Batch mode: the warps of the batch whose tail was queued last, as one launch on `main`.
-int launch_ready(vs_stab* s) {
+// Batch mode: the warps of the batch whose tail was queued last (`what` = VS_WARP_ONLY / VS_WARP_ALL), or only the coordinate
+// tables of those warps (VS_WARP_TABLES_ONLY: queued right behind the tail, so they are ready long before the warps).
+int ready_launches(vs_stab* s, int what) {
     vs_stab::ReadyWarps& R = s->ready;
-    if (!R.valid) return VS_OK;
     hipStream_t st = s->st;
     int rc = VS_OK;
     for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes WARP_BATCH_MAX frames per launch
         const int m = std::min(WARP_BATCH_MAX, R.n - i0);
-        StageScope t(s, VS_STAGE_WARP, st);
+        const bool tabs = m >= 4 && R.n <= WARP_BATCH_MAX;                  // (one table set per batch)
+        if (what == VS_WARP_TABLES_ONLY && !tabs) continue;
+        const int w = tabs ? what : VS_WARP_ALL;
         rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->src_pitch, s->w, s->h, R.stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[R.set] + 12 * i0, 12, m >= 4 ? s->d_tabs[0] : nullptr, st);
+                                     s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] : nullptr, st, w);
         if (rc == VS_OK && s->fmt == VS_FMT_NV12) {
             // interleaved chroma plane: half size, two channels, the map with the halved translation
             const uint8_t* us[WARP_BATCH_MAX];
@@ -663,19 +668,31 @@ int launch_ready(vs_stab* s) {
                 ud[i] = R.dsts[i0 + i] + dst_uv(s, R.dsts[i0 + i], R.stride);
             }
             rc = launch_warp_affine_list(us, ud, m, s->src_pitch, s->w / 2, s->h / 2, R.stride, s->w / 2, s->h / 2, 2,
-                                         s->d_MinvB[R.set] + 12 * i0 + 6, 12, m >= 4 ? s->d_tabs[0] : nullptr, st);
+                                         s->d_MinvB[R.set] + 12 * i0 + 6, 12, tabs ? s->d_tabs[2 + R.set] : nullptr, st, w);
         }
+    }
+    if (rc != VS_OK) s->err = get_last_error();
+    return rc;
+}
+
+int launch_ready(vs_stab* s) {
+    vs_stab::ReadyWarps& R = s->ready;
+    if (!R.valid) return VS_OK;
+    hipStream_t st = s->st;
+    int rc;
+    {
+        StageScope t(s, VS_STAGE_WARP, st);
+        rc = ready_launches(s, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL);
     }
     if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
     for (int i = 0; i < R.n; i++) {
         const int slot = R.slots[i];
         if (slot < 0) continue;          // zero-copy: the frame is the caller's
-        if (hipEventRecord(s->ev_slot[slot], st) == hipSuccess) s->slot_valid[slot] = true;
+        if (hipEventRecord(s->ev_slot[slot], st) == hipSuccess) { s->slot_valid[slot] = true; }
         s->free_slots.push_back(slot);
     }
     R.valid = false;
-    if (rc != VS_OK) { s->err = get_last_error(); return rc; }
-    return VS_OK;
+    return rc;
 }
 
 // applyNextSmoothTransform (Stabilizer.cpp:763-1137) into d_out (device), on `main`
@@ -946,6 +963,12 @@ int run_batch(vs_stab* s) {
         for (int i = 0; i < R.n; i++) { R.srcs[i] = s->pend[i].src; R.dsts[i] = s->pend[i].dst; R.slots[i] = s->pend[i].slot; }
         s->pend.clear();
         if (R.valid) s->pend_set = set ^ 1;
+        // the maps of these warps exist once the tail has run: their coordinate tables are built right behind it
+        R.tabs_built = false;
+        if (R.valid && std::getenv("VS_STAB_TABLES_WITH_WARP") == nullptr) {
+            S_TRY(s, ready_launches(s, VS_WARP_TABLES_ONLY));
+            R.tabs_built = true;
+        }
     }
     const vs_stab::BFrame& lb = s->bq[n - 1];
     s->dbg_prev_pts = s->d_pts[lb.lk_buf]; s->dbg_next = s->items[n - 1].next;

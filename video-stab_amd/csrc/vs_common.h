@@ -82,9 +82,11 @@ size_t warp_tabs_ints(int dw, int dh, int frames);
 int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                        uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
                        const double* d_Minv, int batch, int32_t* d_tabs, hipStream_t st);
+// what: the whole launch, or its two halves apart (tables of the frames now, the warp later from the same d_tabs).
+enum { VS_WARP_ALL = 0, VS_WARP_TABLES_ONLY = 1, VS_WARP_ONLY = 2 };
 int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
                             size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, int32_t* d_tabs,
-                            hipStream_t st);
+                            hipStream_t st, int what = VS_WARP_ALL);
 int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
                        uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st);
 // Batched forms (batch mode): the images of `items` frames in one launch; d_pairs = device table of
