@@ -189,20 +189,43 @@ def traffic_from_counters(vs, roof, frame_bytes):
 
 
 def host_api_rate(vs, device, params, frames, n_timed=240):
-    """vs_stab_push: host frame in, host frame out (what vs::Stabilizer::stabilize(cv::Mat) calls) - PCIe both ways."""
-    s = vs.stabilizer(params, device=device)
+    """vs_stab_push: host frame in, host frame out (what vs::Stabilizer::stabilize(cv::Mat) calls) - PCIe both ways.
+    Three forms: pageable frames (numpy arrays as they come), page-locked frames (vs_host_alloc), and page-locked frames
+    with the host pipeline (vs_stab_set_host_pipeline: a call returns the previous call's frame)."""
     order = clip_order(len(frames), 64 + n_timed)
-    for i in order[:64]:
-        s.push(frames[i])
-    t0 = time.perf_counter()
-    n_out = 0
-    for i in order[64:]:
-        if s.push(frames[i]) is not None:
-            n_out += 1
-    dt = time.perf_counter() - t0
-    s.close()
-    return {"value": round(n_out / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n_out, 1) * 1e3, 4),
-            "what": "vs_stab_push, %d calls: host frame in, stabilized host frame out per call (H2D + D2H inside the call)" % n_timed}
+
+    def run(pinned, pipeline):
+        s = vs.stabilizer(params, device=device)
+        if pipeline:
+            s.set_host_pipeline(True)
+        src = frames
+        out = None
+        bufs = []
+        if pinned:
+            bufs = [capi.HostBuf(vs, f.shape) for f in frames] + [capi.HostBuf(vs, frames[0].shape)]
+            for b, f in zip(bufs, frames):
+                b.array[...] = f
+            src = [b.array for b in bufs[:-1]]
+            out = bufs[-1].array
+        for i in order[:64]:
+            s.push(src[i], out=out)
+        t0 = time.perf_counter()
+        n_out = 0
+        for i in order[64:]:
+            if s.push(src[i], out=out) is not None:
+                n_out += 1
+        dt = time.perf_counter() - t0
+        s.close()
+        for b in bufs:
+            b.free()
+        return round(n_out / dt, 1), round(dt / max(n_out, 1) * 1e3, 4)
+    pg, pn, pp = run(False, False), run(True, False), run(True, True)
+    return {"value": pg[0], "unit": "frames/s", "ms_per_frame": pg[1],
+            "what": "vs_stab_push, %d calls: host frame in, stabilized host frame out per call (H2D + D2H inside the call), pageable numpy frames" % n_timed,
+            "page_locked": {"value": pn[0], "ms_per_frame": pn[1], "what": "the same with frames in page-locked memory (vs_host_alloc)"},
+            "page_locked_host_pipeline": {"value": pp[0], "ms_per_frame": pp[1],
+                                          "what": "page-locked frames and vs_stab_set_host_pipeline: a call returns the frame the previous call "
+                                                  "computed; its download overlaps this call's upload, the device work runs behind the call"}}
 
 
 def config2(vs, device, args):

@@ -231,10 +231,18 @@ int vs_stab_get_debug_arrays(vs_stab* s, float* prev_pts, float* curr_pts,
                              float* detected_pts, uint8_t* gray, int* aw, int* ah);
 const char* vs_stab_last_error(const vs_stab* s);
 void*       vs_stab_stream(vs_stab* s);    /* hipStream_t of the instance     */
-/* Reserved: accepted and ignored.  Graph replay of the per-frame step was superseded by
- * the batch mode below (the step is bound by latency chains, not by launch overhead -
- * DESIGN.md section 5); kept so that callers written against ABI 1 keep linking. */
-int vs_stab_enable_graph(vs_stab* s, int enable);
+/* Host pipeline for vs_stab_push / vs_stab_flush (replaces the synchronous upload - compute - download of the reference's
+ * GPU branch, /root/reference/src/Stabilizer.cpp:1021-1031): a call returns the frame the call BEFORE it computed - one
+ * more call of latency than vs::Stabilizer::stabilize(): clamp(smoothingRadius,5,35) empty results instead of one less -
+ * while its own frame is uploaded; the analysis and the warp of that frame then run behind the caller's back.  Same
+ * frames in the same order; vs_stab_flush first hands out the frame that is still held.  Off by default.  Choose while no
+ * frame is queued. */
+int vs_stab_set_host_pipeline(vs_stab* s, int enable);
+/* Page-locked host memory for frames handed to vs_stab_push / vs_stab_flush and the other host entry points: transfers
+ * from and to such buffers are DMA transfers of their own (pageable memory is staged by the runtime, about half the
+ * rate). */
+int  vs_host_alloc(void** p, size_t bytes);
+void vs_host_free(void* p);
 /* Deferred output for vs_stab_push_dev / vs_stab_flush_dev (batch / file-to-file use): the
  * warps of up to `frames` (1..32) consecutive results are issued as ONE kernel launch, each
  * result into the d_out its push named.  Results are complete after vs_stab_sync(); with

@@ -526,3 +526,132 @@ def test_errors_are_loud(gpu):
     with pytest.raises(capi.VsError):
         s.push(np.zeros((100, 160, 3), np.uint8))     # geometry change without clean()
     s.close()
+
+
+def _unsynced_outputs(gpu, clip, order, batch, **params):
+    """All frames pushed without a host synchronisation in between (device entry point); the stabilized frames."""
+    w, h = clip[0].shape[1], clip[0].shape[0]
+    fb = clip[0].nbytes
+    s = gpu.stabilizer(gpu.params(**params))
+    if batch > 1:
+        s.set_batch(batch)
+    d_in = capi.DevBuf(gpu, fb * len(clip))
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_out = capi.DevBuf(gpu, fb * (len(order) + 2))
+    k = 0
+    for i in order:
+        k += s.push_dev(d_in.ptr + i * fb, w, h, w * 3, capi.FMT_BGR8, d_out.ptr + k * fb, w * 3)
+    while s.flush_dev(d_out.ptr + k * fb, w * 3):
+        k += 1
+    s.sync()
+    out = d_out.download((k, h, w, 3), np.uint8)
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+def test_keypoint_buffers_are_not_recycled_under_the_ransac_kernels(gpu, oracle, monkeypatch, batch):
+    """Regression test for a write-after-read hazard: the event that lets a re-detection overwrite a keypoint buffer used to
+    be recorded behind the tracker, but the RANSAC scoring / selection kernels read the same buffer after it.  With a
+    spin kernel between tracker and RANSAC (VS_STAB_DEBUG_DELAY_US) and no host synchronisation between pushes the window
+    is wide open: the result must still be the oracle's."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 31, 320, 240, 20)
+    order = list(range(20))
+    ref = []
+    so = oracle.stabilizer(oracle.params(smoothing_radius=5))
+    for i in order:
+        r = so.push(clip[i])
+        if r is not None:
+            ref.append(r)
+    while True:
+        r = so.flush(clip[0])
+        if r is None:
+            break
+        ref.append(r)
+    so.close()
+    monkeypatch.setenv("VS_STAB_DEBUG_DELAY_US", "400")
+    got = _unsynced_outputs(gpu, clip, order, batch, smoothing_radius=5)
+    assert len(got) == len(ref) == 20
+    for a, b in zip(got, ref):
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        assert d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(smoothing_method=capi.SMOOTH_GAUSSIAN, gaussian_sigma=2.0),
+                                   dict(smoothing_method=capi.SMOOTH_KALMAN), dict(drone_high_freq_mode=1)])
+@pytest.mark.parametrize("batch", [1, 32])
+def test_long_stream_wraps_the_trajectory_rings(gpu, oracle, extra, batch):
+    """340 frames: the 256-entry device rings of transforms / path (traj_state.h) wrap, the incremental Kalman walk and the
+    Gaussian reflect window run past the wrap; per-frame pipeline and batch mode (flush included) against the oracle, whose
+    history grows without bound like the reference's."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 33, 192, 144, 20)
+    order = [i % 20 if (i // 20) % 2 == 0 else 19 - i % 20 for i in range(340)]
+    params = dict(smoothing_radius=9, **extra)
+    so = oracle.stabilizer(oracle.params(**params))
+    ref = []
+    for i in order:
+        r = so.push(clip[i])
+        if r is not None:
+            ref.append(r)
+    while True:
+        r = so.flush(clip[0])
+        if r is None:
+            break
+        ref.append(r)
+    so.close()
+    got = _unsynced_outputs(gpu, clip, order, batch, **params)
+    assert len(got) == len(ref) == 340
+    # the bar of the other pipeline tests (a last-ulp difference of the device's sinf / cosf / atan2f can move a 1/1024-px
+    # coordinate across a 1/32-px rounding boundary: one weight step at a hard edge is up to 8 levels) - a ring that wrapped
+    # wrongly would move whole frames
+    bad, frames_touched = 0, 0
+    for a, b in zip(got, ref):
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        assert d.max() <= 8
+        bad = max(bad, np.count_nonzero(d))
+        frames_touched += int(d.max() > 0)
+    assert bad <= 64 and frames_touched <= 8      # (64 of the 82 944 samples of these small frames)
+
+
+def test_host_pipeline_returns_the_same_frames_one_call_later(gpu):
+    """vs_stab_set_host_pipeline: a call hands out the frame the call before it computed (its download overlaps the next
+    upload); the sequence of frames, flush included, is the synchronous entry point's.  Page-locked and pageable buffers."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 35, 320, 240, 26)
+    p = gpu.params(smoothing_radius=6)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_host_pipeline(True)
+    pin_in = capi.HostBuf(gpu, clip[0].shape)
+    pin_out = capi.HostBuf(gpu, clip[0].shape)
+    ref, got = [], []
+    for k, f in enumerate(clip):
+        r = s1.push(f)
+        if r is not None:
+            ref.append(r)
+        if k % 2:                       # page-locked frames on odd calls, pageable ones on even calls
+            pin_in.array[...] = f
+            g = s2.push(pin_in.array, out=pin_out.array)
+        else:
+            g = s2.push(f)
+        assert (g is not None) == (len(ref) > 1 or (len(ref) == 1 and r is None)), k
+        if g is not None:
+            got.append(g.copy())
+    assert len(got) == len(ref) - 1
+    while True:
+        r = s1.flush(clip[0])
+        if r is None:
+            break
+        ref.append(r)
+    while True:
+        g = s2.flush(clip[0])
+        if g is None:
+            break
+        got.append(g)
+    assert len(got) == len(ref) == 26
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    with pytest.raises(capi.VsError):
+        s1.push(clip[0]); s1.set_host_pipeline(True)      # only while nothing is queued
+    for s in (s1, s2):
+        s.close()
+    pin_in.free(); pin_out.free()

@@ -25,6 +25,12 @@ __global__ __launch_bounds__(64) void traj_emit_kernel(TrajState* s, TrajParams 
     traj_emit_device(s, p, idx, M_out, Minv_out, dbg);
 }
 
+// test hook (VS_STAB_DEBUG_DELAY_US): one wave that does nothing for about `ticks` of the 100 MHz clock
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 __global__ void traj_reset_kernel(TrajState* s, int smoothing_radius) {
     if (threadIdx.x != 0) return;
     s->n = 0;
@@ -77,6 +83,12 @@ int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, d
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
+int launch_spin(int microseconds, hipStream_t st) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)microseconds * 100ull);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
 int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st) {
     hipLaunchKernelGGL(traj_reset_kernel, dim3(1), dim3(64), 0, st, s, smoothing_radius);
     VS_HIP_TRY(hipGetLastError());

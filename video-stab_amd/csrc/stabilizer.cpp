@@ -68,6 +68,7 @@ int launch_gftt_batch(const void* d_table, int items, int w, int h, int block_si
 int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
                      hipStream_t st);
 int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st);
+int launch_spin(int microseconds, hipStream_t st);
 int launch_make_border(const uint8_t* src, size_t sstride, int w, int h, int cn, uint8_t* dst, size_t dstride,
                        int b, int border, hipStream_t st);
 int launch_resize_linear(const uint8_t* d_src, size_t sstride, int sw, int sh, int cn, uint8_t* d_dst,
@@ -122,6 +123,7 @@ struct vs_stab {
     int last_out_w = 0, last_out_h = 0;
     int orig_w = 0, orig_h = 0;
     int host_radius = 30;
+    int dbg_delay_us = 0;           // VS_STAB_DEBUG_DELAY_US: a spin kernel between tracking and RANSAC (ordering tests)
     // analysis images
     uint8_t* d_first_gray = nullptr;     // 480x270 (Stabilizer.cpp:277)
     std::vector<Pyramid> pyr;           // ring: NPYR buffers, 2*batch+2 in batch mode
@@ -156,6 +158,12 @@ struct vs_stab {
     size_t tmp_bytes = 0;
     uint8_t* d_out = nullptr;
     size_t out_bytes = 0;
+    // host pipeline (vs_stab_set_host_pipeline): the result of a call stays in d_hold[] and travels to the host during the
+    // NEXT call, next to that call's upload and ahead of its analysis
+    bool host_pipe = false, hold_valid = false;
+    uint8_t* d_hold[2] = {nullptr, nullptr};
+    int hold_cur = 0, hold_w = 0, hold_h = 0;
+    hipEvent_t ev_hold = nullptr;
     uint8_t* d_all = nullptr;           // one allocation for the small buffers
     vs_counters counters;
     // cross-stream dependencies
@@ -310,6 +318,8 @@ void free_all(vs_stab* s) {
     if (s->d_gftt_scratch) (void)hipFree(s->d_gftt_scratch);
     if (s->d_tmp) (void)hipFree(s->d_tmp);
     if (s->d_out) (void)hipFree(s->d_out);
+    for (auto& h : s->d_hold) { if (h) (void)hipFree(h); h = nullptr; }
+    s->hold_valid = false;
     s->d_ring = s->d_all = s->d_tmp = s->d_out = nullptr;
     s->d_gftt_scratch = nullptr;
     s->allocated = false;
@@ -575,8 +585,8 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame, int f) {
         S_TRY(s, launch_pyr_lk(L, s->levels, s->d_pts[pp], cap, s->d_npts[pp], s->d_next, s->d_status, s->d_err,
                                p.lk_win_size, p.lk_max_iters, p.lk_epsilon, s->st));   // :611-619
     }
-    S_HIP(s, hipEventRecord(s->ev_lk[f % EVR], s->st));
     s->last_lk_pp = pp;
+    if (s->dbg_delay_us > 0) S_TRY(s, launch_spin(s->dbg_delay_us, s->st));        // test hook: widen the window between LK and RANSAC
     {
         // status compaction (:629-641) + estimateAffinePartial2D (:644-659) + transform append (:660-693)
         StageScope t(s, VS_STAGE_RANSAC, s->st);
@@ -584,6 +594,10 @@ int generate_transform(vs_stab* s, const uint8_t* d_frame, int f) {
                                s->d_m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab, s->d_counts, s->d_model,
                                s->d_inliers, s->d_info, s->d_traj, &s->tp, s->d_dbg, s->have_prev_gray ? 1 : 0, s->st));
     }
+    // `pre` (pyramid buffers) and `det` (keypoint buffer pts[pp^1] two frames on) wait for this event: the tracker AND the
+    // scoring / selection kernels have read pts[pp] and its count by then (recorded right behind the tracker, a re-detection
+    // two frames later could overwrite the buffer under the RANSAC kernels)
+    S_HIP(s, hipEventRecord(s->ev_lk[f % EVR], s->st));
     s->dbg_prev_pts = s->d_pts[pp]; s->dbg_next = s->d_next; s->dbg_status = s->d_status; s->dbg_inliers = s->d_inliers;
     s->n_transforms++;
     s->pp = next_pp;
@@ -944,7 +958,7 @@ int run_batch(vs_stab* s) {
         StageScope t(s, VS_STAGE_RANSAC, st);
         S_TRY(s, launch_ransac_score_batch(s->d_rs_table, n, p.ransac_max_iters, n_max, st));
     }
-    S_HIP(s, hipEventRecord(s->ev_blk[k % 4], st));
+    if (s->dbg_delay_us > 0) S_TRY(s, launch_spin(s->dbg_delay_us, st));
     // ---- ordered tail, ONE launch: per frame in push order, selection + trajectory append (:644-693), then the
     // map of the output that has become due (applyNextSmoothTransform sees exactly the transforms appended so
     // far); all due warps of the batch then leave as one launch.
@@ -957,6 +971,9 @@ int run_batch(vs_stab* s) {
             StageScope t(s, VS_STAGE_TRAJ, st);
             S_TRY(s, launch_ransac_tail_batch(s->d_rs_table, s->d_tail_table, n, s->d_M, st));
         }
+        // the keypoint and pyramid buffers of this batch may be recycled (two batches on) once the tail, which still reads
+        // the points and their counts, has run
+        S_HIP(s, hipEventRecord(s->ev_blk[k % 4], st));
         // the warps of this batch wait for the next run_batch (or a drain)
         vs_stab::ReadyWarps& R = s->ready;
         R.n = (int)s->pend.size(); R.set = set; R.stride = s->pend_stride; R.valid = R.n > 0;
@@ -1066,7 +1083,7 @@ void destroy_events(vs_stab* s) {
     for (auto& e : s->ev_lk) kill(e);
     for (auto& e : s->ev_det) kill(e);
     for (auto& e : s->ev_slot) kill(e);
-    kill(s->ev_first);
+    kill(s->ev_first); kill(s->ev_hold);
     kill(s->ev_emit); kill(s->ev_warp[0]); kill(s->ev_warp[1]);
     kill(s->ev_bpre); kill(s->ev_bgray);
     for (auto& e : s->ev_bdet) kill(e);
@@ -1080,7 +1097,7 @@ int create_events(vs_stab* s) {
     for (auto& e : s->ev_lk) S_HIP(s, mk(e));
     for (auto& e : s->ev_det) S_HIP(s, mk(e));
     for (auto& e : s->ev_slot) S_HIP(s, mk(e));
-    S_HIP(s, mk(s->ev_first));
+    S_HIP(s, mk(s->ev_first)); S_HIP(s, mk(s->ev_hold));
     S_HIP(s, mk(s->ev_emit)); S_HIP(s, mk(s->ev_warp[0])); S_HIP(s, mk(s->ev_warp[1]));
     S_HIP(s, mk(s->ev_bpre));
     S_HIP(s, mk(s->ev_bgray));
@@ -1174,6 +1191,7 @@ int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
     s->p = *params;
     s->device = device;
     s->host_radius = params->smoothing_radius;
+    if (const char* e = std::getenv("VS_STAB_DEBUG_DELAY_US")) s->dbg_delay_us = std::max(0, std::min(std::atoi(e), 20000));
     memset(&s->counters, 0, sizeof s->counters);
     fill_traj_params(s);
     hipError_t e = acquire_streams(s);
@@ -1207,6 +1225,7 @@ int vs_stab_clean(vs_stab* s) {   // Stabilizer.cpp:221-256
     S_TRY(s, sync_all(s));
     free_all(s);
     s->q_slot.clear(); s->q_idx.clear(); s->q_ptr.clear();
+    s->hold_valid = false; s->hold_cur = 0;
     s->first = true; s->next_index = 0; s->w = s->h = 0; s->orig_w = s->orig_h = 0; s->n_transforms = 0;
     s->have_prev_gray = false; s->prev_small = false; s->pp = 0;
     s->host_radius = s->p.smoothing_radius;
@@ -1257,6 +1276,41 @@ int vs_stab_flush_dev(vs_stab* s, void* d_out, size_t out_stride, int* produced)
     return flush_dev_impl(s, d_out, out_stride, produced, true);
 }
 
+// Host pipeline: a call returns the frame that the call before it computed.  Its download runs on the copy stream while
+// this call's frame is uploaded (PCIe is full duplex) and the call returns as soon as both transfers are done: the
+// analysis and the warp of this call's frame go on behind the caller's back and are picked up by the next call.
+static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, int fmt, uint8_t* out,
+                               size_t out_stride, int* produced) {
+    int ow, oh;
+    out_size(s, w, h, &ow, &oh);
+    const size_t orow = (size_t)ow * s->cn;
+    const int orows = fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh;
+    if (!out || out_stride < orow) return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
+    for (auto& hld : s->d_hold)
+        if (!hld) S_HIP(s, hipMalloc((void**)&hld, s->out_bytes));
+    const bool have_prev = s->hold_valid;
+    if (have_prev) {       // the held result: on its way while this call's frame comes in
+        S_HIP(s, hipStreamWaitEvent(s->st_warp, s->ev_hold, 0));
+        S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_hold[s->hold_cur ^ 1], orow, orow, orows, hipMemcpyDeviceToHost, s->st_warp));
+    }
+    int slot;
+    S_TRY(s, take_slot(s, &slot));
+    S_TRY(s, enqueue_copy_in(s, slot, data, stride, hipMemcpyHostToDevice));
+    int now = 0;
+    int rc = push_common(s, slot, nullptr, s->d_hold[s->hold_cur], orow, &now, false);
+    S_HIP(s, hipStreamSynchronize(s->st_pre));        // the caller's frame has been consumed
+    if (have_prev) S_HIP(s, hipStreamSynchronize(s->st_warp));
+    if (rc != VS_OK) return rc;
+    s->hold_valid = now != 0;
+    if (now) {
+        S_HIP(s, hipEventRecord(s->ev_hold, s->st));
+        s->hold_cur ^= 1;
+        s->hold_w = s->last_out_w; s->hold_h = s->last_out_h;
+    }
+    *produced = have_prev ? 1 : 0;
+    return VS_OK;
+}
+
 int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, int fmt, uint8_t* out,
                  size_t out_stride, int* produced) {
     if (!s || !produced) return VS_ERR_INVALID_ARG;
@@ -1266,18 +1320,29 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
     if (rc != VS_OK) return rc;
     if (s->zero_copy && (s->src_pitch != s->row_bytes || (s->fmt == VS_FMT_NV12 && s->in_uv_off)))
         return fail(s, VS_ERR_INVALID_ARG, "push: host frames cannot join a queue of pitched zero-copy surfaces");
-    int slot;
-    S_TRY(s, take_slot(s, &slot));
-    S_TRY(s, enqueue_copy_in(s, slot, data, stride, hipMemcpyHostToDevice));
+    if (s->host_pipe && !s->batch_active) return push_host_pipelined(s, data, w, h, stride, fmt, out, out_stride, produced);
     int ow, oh;
     out_size(s, w, h, &ow, &oh);
     const size_t orow = (size_t)ow * s->cn;
-    S_TRY(s, drain_batch(s));
-    S_TRY(s, flush_warps(s));
-    rc = push_common(s, slot, nullptr, s->d_out, orow, produced, false);
-    if (rc != VS_OK) return rc;
+    // (the output buffer is checked before the frame is consumed: a bad call loses nothing)
+    const int R = effective_radius(s->host_radius);
+    if ((!out || out_stride < orow) && !s->first && (int)s->q_idx.size() + 1 >= R)
+        return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
+    int slot;
+    S_TRY(s, take_slot(s, &slot));
+    rc = enqueue_copy_in(s, slot, data, stride, hipMemcpyHostToDevice);
+    if (rc == VS_OK) rc = drain_batch(s);
+    if (rc == VS_OK) rc = flush_warps(s);
+    if (rc == VS_OK) rc = push_common(s, slot, nullptr, s->d_out, orow, produced, false);
+    if (rc != VS_OK) {
+        (void)hipStreamSynchronize(s->st_pre);       // the upload from the caller's buffer may still be in flight
+        return rc;
+    }
     if (*produced) {
-        if (!out || out_stride < orow) return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
+        if (!out || out_stride < orow) {
+            (void)hipStreamSynchronize(s->st_pre);
+            return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
+        }
         const int orows = fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh;
         S_HIP(s, hipStreamSynchronize(s->st_warp));   // batch mode: the warp ran on the warp stream
         S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_out, orow, orow, orows, hipMemcpyDeviceToHost, s->st));
@@ -1291,7 +1356,20 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
 int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced) {
     if (!s || !produced) return VS_ERR_INVALID_ARG;
     *produced = 0;
-    if (!s->allocated || s->q_slot.empty()) return VS_OK;
+    if (!s->allocated) return VS_OK;
+    if (s->hold_valid) {      // host pipeline: the frame the last push computed
+        const size_t orow = (size_t)s->hold_w * s->cn;
+        if (!out || out_stride < orow) return fail(s, VS_ERR_INVALID_ARG, "flush: output buffer/stride too small");
+        const int orows = s->fmt == VS_FMT_NV12 ? s->hold_h * 3 / 2 : s->hold_h;
+        S_HIP(s, hipStreamWaitEvent(s->st_warp, s->ev_hold, 0));
+        S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_hold[s->hold_cur ^ 1], orow, orow, orows, hipMemcpyDeviceToHost, s->st_warp));
+        S_HIP(s, hipStreamSynchronize(s->st_warp));
+        s->hold_valid = false;
+        s->last_out_w = s->hold_w; s->last_out_h = s->hold_h;
+        *produced = 1;
+        return VS_OK;
+    }
+    if (s->q_slot.empty()) return VS_OK;
     int ow, oh;
     out_size(s, s->w, s->h, &ow, &oh);
     const size_t orow = (size_t)ow * s->cn;
@@ -1304,6 +1382,15 @@ int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced) {
     S_HIP(s, hipStreamSynchronize(s->st_warp));
     S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_out, orow, orow, orows, hipMemcpyDeviceToHost, s->st));
     S_HIP(s, hipStreamSynchronize(s->st));
+    return VS_OK;
+}
+
+// Host pipeline for vs_stab_push / vs_stab_flush (see push_host_pipelined): one more call of latency, the transfers of
+// consecutive calls overlap each other and the device work.  To be chosen while no frame is queued.
+int vs_stab_set_host_pipeline(vs_stab* s, int enable) {
+    if (!s) return VS_ERR_INVALID_ARG;
+    if (!s->q_slot.empty() || s->hold_valid) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_host_pipeline: the frame queue must be empty");
+    s->host_pipe = enable != 0;
     return VS_OK;
 }
 
@@ -1448,12 +1535,6 @@ int vs_stab_get_stage_times(vs_stab* s, double* total_ms, int64_t* launches) {
         s->ev_pool.push_back(pe.b);
     }
     s->pending.clear();
-    return VS_OK;
-}
-
-int vs_stab_enable_graph(vs_stab* s, int enable) {
-    if (!s) return VS_ERR_INVALID_ARG;
-    (void)enable;   // reserved (see vs_stab.h): the batch mode replaced graph replay
     return VS_OK;
 }
 

@@ -50,6 +50,17 @@ int vs_abi_version(void) { return VS_STAB_ABI_VERSION; }
 #endif
 const char* vs_build_tag(void) { return VS_BUILD_TAG; }
 
+int vs_host_alloc(void** p, size_t bytes) {
+    if (!p) return VS_ERR_INVALID_ARG;
+    *p = nullptr;
+    VS_TRY(vsd::ensure_device());
+    VS_HIP_TRY(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+    return VS_OK;
+}
+void vs_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 const char* vs_build_info(void) {
     return "libvideo-stab gfx950 (CDNA4, wave64) hipcc -ffp-contract=off; warp=classic-fixed-point";
 }

@@ -133,6 +133,30 @@ class DevBuf:
             pass
 
 
+class HostBuf:
+    """Page-locked host memory (vs_host_alloc) as a numpy array: frames that the host entry points move by DMA."""
+
+    def __init__(self, vs, shape, dtype=np.uint8):
+        self.vs = vs
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        vs.check(vs.lib.vs_host_alloc(C.byref(p), max(n, 1)))
+        self.ptr = p.value
+        self.array = np.frombuffer((C.c_uint8 * max(n, 1)).from_address(self.ptr), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.vs.lib.vs_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class VsLib:
     def __init__(self, lib):
         self.lib = lib
@@ -166,7 +190,6 @@ class VsLib:
         L.vs_stab_last_error.argtypes = [vp]
         L.vs_stab_stream.restype = vp
         L.vs_stab_stream.argtypes = [vp]
-        L.vs_stab_enable_graph.argtypes = [vp, C.c_int]
         L.vs_stab_set_warp_batch.argtypes = [vp, C.c_int]
         L.vs_stab_set_batch.argtypes = [vp, C.c_int]
         L.vs_stab_set_zero_copy.argtypes = [vp, C.c_int]
@@ -175,6 +198,13 @@ class VsLib:
         L.vs_stab_get_stage_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.vs_dev_set_device.argtypes = [C.c_int]
         L.vs_dev_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+        try:
+            L.vs_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+            L.vs_host_free.argtypes = [vp]
+            L.vs_host_free.restype = None
+            L.vs_stab_set_host_pipeline.argtypes = [vp, C.c_int]
+        except AttributeError:      # a library of an earlier build (A/B measurements)
+            pass
         L.vs_dev_free.argtypes = [vp]
         L.vs_dev_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
         L.vs_dev_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
@@ -756,11 +786,13 @@ class Stabilizer:
             return (oh.value * 3 // 2, ow.value)
         return (oh.value, ow.value)
 
-    def push(self, frame, fmt=FMT_BGR8):
-        """stabilize(frame): returns the stabilized frame or None (warm-up)."""
+    def push(self, frame, fmt=FMT_BGR8, out=None):
+        """stabilize(frame): returns the stabilized frame or None (warm-up).  `out`: a caller's array for the result (for
+        instance page-locked: HostBuf), else a new one."""
         frame = np.ascontiguousarray(frame)
         w, h, cn = self._geom(frame, fmt)
-        out = np.zeros(self.out_shape(w, h, fmt), np.uint8)
+        if out is None:
+            out = np.zeros(self.out_shape(w, h, fmt), np.uint8)
         produced = C.c_int32(0)
         self.vs.check(self.lib.vs_stab_push(self.h, _p(frame, u8p), w, h, w * cn, fmt, _p(out, u8p),
                                             out.shape[1] * cn, C.byref(produced)), self.h)
@@ -772,6 +804,9 @@ class Stabilizer:
         produced = C.c_int32(0)
         self.vs.check(self.lib.vs_stab_flush(self.h, _p(out, u8p), out.shape[1] * cn, C.byref(produced)), self.h)
         return out if produced.value else None
+
+    def set_host_pipeline(self, on=True):
+        self.vs.check(self.lib.vs_stab_set_host_pipeline(self.h, int(on)), self.h)
 
     def push_dev(self, d_in, w, h, stride, fmt, d_out, out_stride):
         produced = C.c_int32(0)
@@ -801,9 +836,6 @@ class Stabilizer:
 
     def set_warp_batch(self, frames):
         self.vs.check(self.lib.vs_stab_set_warp_batch(self.h, int(frames)), self.h)
-
-    def enable_graph(self, on=True):
-        self.vs.check(self.lib.vs_stab_enable_graph(self.h, int(on)), self.h)
 
     def set_profiling(self, mode):
         self.vs.check(self.lib.vs_stab_set_profiling(self.h, int(mode)), self.h)
