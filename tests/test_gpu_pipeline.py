@@ -655,3 +655,126 @@ def test_host_pipeline_returns_the_same_frames_one_call_later(gpu):
     for s in (s1, s2):
         s.close()
     pin_in.free(); pin_out.free()
+
+
+@pytest.mark.parametrize("extra", [dict(border_size=16, border_type=capi.BORDER_REFLECT), dict(border_size=9, border_type=capi.BORDER_REPLICATE),
+                                   dict(border_size=12, border_type=capi.BORDER_WRAP), dict(border_size=16, border_type=capi.BORDER_REFLECT_101),
+                                   dict(border_size=8, border_type=capi.BORDER_BLACK), dict(border_size=20, crop_n_zoom=1)])
+def test_batch_mode_with_border_pad_and_crop_n_zoom(gpu, extra):
+    """copyMakeBorder in front of the warp (Stabilizer.cpp:981-990) and crop-and-zoom behind it (:1108-1124) in batch mode:
+    the frames of the per-frame pipeline, flush included."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 37, 320, 240, 24)
+    n = 45
+    order = [i % 24 if (i // 24) % 2 == 0 else 23 - i % 24 for i in range(n)]
+    p = gpu.params(smoothing_radius=7, **extra)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(8)
+    oh, ow, _ = s1.out_shape(320, 240, capi.FMT_BGR8)
+    fb, ob = clip[0].nbytes, oh * ow * 3
+    d_in = capi.DevBuf(gpu, fb * 24)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, ob * (n + 2)), capi.DevBuf(gpu, ob * (n + 2))
+    k1 = k2 = 0
+    for i in range(n):
+        k1 += s1.push_dev(d_in.ptr + order[i] * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_ref.ptr + k1 * ob, ow * 3)
+        k2 += s2.push_dev(d_in.ptr + order[i] * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_got.ptr + k2 * ob, ow * 3)
+        assert k1 == k2
+    s1.sync(); s2.sync()
+    assert k1 == n - 6
+    ref = d_ref.download((k1, oh, ow, 3), np.uint8)
+    got = d_got.download((k2, oh, ow, 3), np.uint8)
+    assert np.array_equal(ref, got)
+    for s in (s1, s2):
+        s.close()
+
+
+@pytest.mark.parametrize("extra", [dict(border_size=32, border_type=capi.BORDER_REFLECT), dict(border_size=32, crop_n_zoom=1)])
+def test_batch_mode_border_and_crop_full_hd_against_oracle(gpu, oracle, extra):
+    """configs[1] size (1920x1080, 200 corners, 21x21 LK) with a border pad / crop-and-zoom, batch mode against the oracle."""
+    clip = synth.make_clip(synth.SEED_CONFIG2 + 3, 1920, 1080, 14)
+    params = dict(smoothing_radius=5, max_corners=200, lk_win_size=21, **extra)
+    so = oracle.stabilizer(oracle.params(**params))
+    ref = [r for r in (so.push(f) for f in clip) if r is not None]
+    so.close()
+    s = gpu.stabilizer(gpu.params(**params))
+    s.set_batch(8)
+    oh, ow, _ = s.out_shape(1920, 1080, capi.FMT_BGR8)
+    fb, ob = clip[0].nbytes, oh * ow * 3
+    d_in, d_out = capi.DevBuf(gpu, fb * len(clip)), capi.DevBuf(gpu, ob * len(clip))
+    k = 0
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+        k += s.push_dev(d_in.ptr + i * fb, 1920, 1080, 1920 * 3, capi.FMT_BGR8, d_out.ptr + k * ob, ow * 3)
+    s.sync()
+    assert k == len(ref) == 10
+    got = d_out.download((k, oh, ow, 3), np.uint8)
+    for a, b in zip(got, ref):
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        assert d.max() <= 8 and np.count_nonzero(d) <= 1e-4 * d.size
+    s.close()
+
+
+def test_config0_640x480_300_frames_radius_25(gpu, oracle):
+    """BASELINE configs[0]: 300 frames of 640x480, smoothingRadius 25 (the analysis image is an UPSCALE to 960x540): inputs
+    0-23 return nothing, input 24 returns frame 0, 276 frames from stabilize() and 24 from flush() - on the
+    HIP path in both execution models, every frame against the oracle."""
+    clip = synth.make_clip(synth.SEED_CONFIG1, 640, 480, 60)
+    order = [i % 60 if (i // 60) % 2 == 0 else 59 - i % 60 for i in range(300)]
+    so = oracle.stabilizer(oracle.params(smoothing_radius=25))
+    ref, first_out = [], None
+    for k, i in enumerate(order):
+        r = so.push(clip[i])
+        if r is not None:
+            if first_out is None:
+                first_out = k
+            ref.append(r)
+    n_push = len(ref)
+    while True:
+        r = so.flush(clip[0])
+        if r is None:
+            break
+        ref.append(r)
+    so.close()
+    assert first_out == 24 and n_push == 276 and len(ref) == 300
+    for batch in (1, 32):
+        got = _unsynced_outputs(gpu, clip, order, batch, smoothing_radius=25)
+        assert len(got) == 300
+        touched = 0
+        for a, b in zip(got, ref):
+            d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+            assert d.max() <= 8 and np.count_nonzero(d) <= 1e-4 * d.size
+            touched += int(d.max() > 0)
+        assert touched <= 6
+
+
+def test_eight_instances_on_one_gpu_keep_their_streams_apart(gpu):
+    """BASELINE configs[4], one GPU's share: 8 streams in batch mode on the device's shared HIP streams, pushes interleaved
+    frame by frame; every stream's frames equal those of a run on its own."""
+    n_streams, n = 8, 70
+    clips = [synth.make_clip(synth.SEED_CONFIG1 + 40 + g, 320, 240, 16) for g in range(n_streams)]
+    order = [i % 16 if (i // 16) % 2 == 0 else 15 - i % 16 for i in range(n)]
+    alone = [_unsynced_outputs(gpu, clips[g], order, 16, smoothing_radius=6 + g % 3) for g in range(n_streams)]
+    fb = clips[0][0].nbytes
+    stabs, d_in, d_out, k = [], [], [], [0] * n_streams
+    for g in range(n_streams):
+        s = gpu.stabilizer(gpu.params(smoothing_radius=6 + g % 3))
+        s.set_batch(16)
+        s.set_zero_copy(True)
+        stabs.append(s)
+        b = capi.DevBuf(gpu, fb * 16)
+        for i, f in enumerate(clips[g]):
+            b.upload(f, i * fb)
+        d_in.append(b)
+        d_out.append(capi.DevBuf(gpu, fb * (n + 2)))
+    for i in order:
+        for g in range(n_streams):
+            k[g] += stabs[g].push_dev(d_in[g].ptr + i * fb, 320, 240, 320 * 3, capi.FMT_BGR8, d_out[g].ptr + k[g] * fb, 320 * 3)
+    for g in range(n_streams):
+        while stabs[g].flush_dev(d_out[g].ptr + k[g] * fb, 320 * 3):
+            k[g] += 1
+    for g in range(n_streams):
+        stabs[g].sync()
+        got = d_out[g].download((k[g], 240, 320, 3), np.uint8)
+        assert k[g] == n and np.array_equal(got, alone[g]), g
+        stabs[g].close()

@@ -156,6 +156,8 @@ struct vs_stab {
     // scratch for border / host I/O
     uint8_t* d_tmp = nullptr;
     size_t tmp_bytes = 0;
+    uint8_t* d_padB = nullptr;          // batch mode with a border: one padded (or to-be-cropped) frame per frame of a batch
+    size_t pad_frame_bytes = 0;
     uint8_t* d_out = nullptr;
     size_t out_bytes = 0;
     // host pipeline (vs_stab_set_host_pipeline): the result of a call stays in d_hold[] and travels to the host during the
@@ -317,6 +319,8 @@ void free_all(vs_stab* s) {
     if (s->d_all) (void)hipFree(s->d_all);
     if (s->d_gftt_scratch) (void)hipFree(s->d_gftt_scratch);
     if (s->d_tmp) (void)hipFree(s->d_tmp);
+    if (s->d_padB) (void)hipFree(s->d_padB);
+    s->d_padB = nullptr;
     if (s->d_out) (void)hipFree(s->d_out);
     for (auto& h : s->d_hold) { if (h) (void)hipFree(h); h = nullptr; }
     s->hold_valid = false;
@@ -355,7 +359,9 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
             if (sw <= s->p.lk_win_size || sh <= s->p.lk_win_size) break;
         }
     }
-    s->batch_active = s->batch > 1 && s->p.border_size <= 0 && !s->p.adaptive_smoothing;
+    // (adaptive smoothing stays with the per-frame pipeline: whether a push produces a frame then depends on the data - the
+    // radius moves the warm-up threshold, Stabilizer.cpp:383,1482-1486 - and a push answers that at once)
+    s->batch_active = s->batch > 1 && !s->p.adaptive_smoothing;
     const int B = s->batch_active ? s->batch : 1;
     s->npyr = s->batch_active ? 2 * B + 2 : NPYR;
     // keypoint buffers: one per detection, recycled after two batches' worth of detections
@@ -396,7 +402,9 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     const size_t o_pairs = take(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
     size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
     size_t o_MinvB[2] = {take((size_t)BATCH_MAX * 96), take((size_t)BATCH_MAX * 96)};
-    const size_t tab_bytes = warp_tabs_ints(w, h, WARP_BATCH_MAX) * sizeof(int32_t);
+    int tow, toh;
+    out_size(s, w, h, &tow, &toh);
+    const size_t tab_bytes = warp_tabs_ints(std::max(w, tow), std::max(h, toh), WARP_BATCH_MAX) * sizeof(int32_t);
     size_t o_tabs[5];
     for (auto& o : o_tabs) o = take(tab_bytes);
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
@@ -447,6 +455,10 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     S_HIP(s, hipMalloc((void**)&s->d_out, s->out_bytes));
     s->tmp_bytes = std::max(s->out_bytes, s->frame_bytes);
     S_HIP(s, hipMalloc((void**)&s->d_tmp, s->tmp_bytes));
+    if (s->batch_active && s->p.border_size > 0) {
+        s->pad_frame_bytes = (s->tmp_bytes + 255) & ~(size_t)255;
+        S_HIP(s, hipMalloc((void**)&s->d_padB, s->pad_frame_bytes * B));
+    }
     S_TRY(s, launch_traj_reset(s->d_traj, s->p.smoothing_radius, s->st));
     // the zero-fill and the reset ran on `main`; nothing may touch the buffers before that
     S_HIP(s, hipStreamSynchronize(s->st));
@@ -665,12 +677,38 @@ int defer_output(vs_stab* s, int idx, const uint8_t* frame, uint8_t* d_out, size
 int ready_launches(vs_stab* s, int what) {
     vs_stab::ReadyWarps& R = s->ready;
     hipStream_t st = s->st;
+    const vs_params_c& p = s->p;
+    const int bsz = p.border_size;
+    const bool pad = bsz > 0 && !p.crop_n_zoom;                                                       // Stabilizer.cpp:981-990
+    const bool crop = bsz > 0 && p.crop_n_zoom && s->w - 2 * bsz > 0 && s->h - 2 * bsz > 0;            // :1108-1124
     int rc = VS_OK;
     for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes WARP_BATCH_MAX frames per launch
         const int m = std::min(WARP_BATCH_MAX, R.n - i0);
         const bool tabs = m >= 4 && R.n <= WARP_BATCH_MAX;                  // (one table set per batch)
         if (what == VS_WARP_TABLES_ONLY && !tabs) continue;
         const int w = tabs ? what : VS_WARP_ALL;
+        if (pad || crop) {
+            // pad: the frames get their border first and the padded frames are warped into the (larger) results;
+            // crop-and-zoom: the frames are warped into scratch frames, whose inner part is then resized to the results
+            const uint8_t* srcs[WARP_BATCH_MAX];
+            uint8_t* dsts[WARP_BATCH_MAX];
+            const int pw = pad ? s->w + 2 * bsz : s->w, ph = pad ? s->h + 2 * bsz : s->h;
+            const size_t prow = (size_t)pw * s->cn;
+            for (int i = 0; i < m; i++) {
+                uint8_t* scratch = s->d_padB + (size_t)(i0 + i) * s->pad_frame_bytes;
+                srcs[i] = pad ? scratch : R.srcs[i0 + i];
+                dsts[i] = pad ? R.dsts[i0 + i] : scratch;
+                if (pad && what != VS_WARP_TABLES_ONLY && rc == VS_OK)
+                    rc = launch_make_border(R.srcs[i0 + i], s->src_pitch, s->w, s->h, s->cn, scratch, prow, bsz, p.border_type, st);
+            }
+            if (rc == VS_OK)
+                rc = launch_warp_affine_list(srcs, dsts, m, pad ? prow : s->src_pitch, pw, ph, pad ? R.stride : prow, pw, ph, s->cn,
+                                             s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] : nullptr, st, w);
+            for (int i = 0; crop && what != VS_WARP_TABLES_ONLY && i < m && rc == VS_OK; i++)
+                rc = launch_resize_linear(dsts[i] + ((size_t)bsz * s->w + bsz) * s->cn, prow, s->w - 2 * bsz, s->h - 2 * bsz, s->cn,
+                                          R.dsts[i0 + i], R.stride, s->orig_w, s->orig_h, st);
+            continue;
+        }
         rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->src_pitch, s->w, s->h, R.stride, s->w, s->h, s->cn,
                                      s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] : nullptr, st, w);
         if (rc == VS_OK && s->fmt == VS_FMT_NV12) {
