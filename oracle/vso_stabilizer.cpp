@@ -5,7 +5,7 @@
 //     (:696; identical for a single instance - SURVEY Q3);
 //   * queued frames are always copied (:376 aliases the caller's buffer);
 //   * NV12 input (no reference path): analysis runs on the luma plane.
-//   * borderType "fade" and enableVirtualCanvas are not restated.
+//   * enableVirtualCanvas is not restated.
 #include "vso_internal.h"
 
 #include <algorithm>
@@ -29,6 +29,8 @@ struct vso_stab {
     int nextFrameIndex = 0;
     int frameW = 0, frameH = 0, fmt = VS_FMT_BGR8;
     int origW = 0, origH = 0;
+    std::vector<uint8_t> borderHistory;   // Stabilizer.h:356-358 (borderHistory_, fadeFrameCount_)
+    int fadeFrameCount = 0;
     int detectCounter = 0;
     // drone (Stabilizer.h:418-429)
     std::deque<std::pair<float, float>> hfHistory;
@@ -286,6 +288,32 @@ static int apply_next(vso_stab* s, uint8_t* out, size_t out_stride) {
         return 1;
     }
     int b = p.border_size;
+    if (b > 0 && !p.crop_n_zoom && p.border_type == VS_BORDER_FADE) {  // :914-978, :1069-1106
+        // The "border mask" of the reference is drawn as two filled rectangles of which the second, over the whole image,
+        // is 255 (:935-947, :1074-1084): the blend with the history and the history update act on EVERY pixel of the
+        // padded frame, not on the border only.  Restated as written.
+        int bw = w + 2 * b, bh = h + 2 * b;
+        const size_t nb = (size_t)bw * bh * cn;
+        std::vector<uint8_t> padded(nb);
+        copy_make_border(frame.data(), w, h, fstride, cn, padded.data(), (size_t)bw * cn, b, VS_BORDER_BLACK);   // :927-932
+        if (s->borderHistory.size() != nb) { s->borderHistory = padded; s->fadeFrameCount = 0; }                 // :917-926
+        float alpha = p.fade_alpha;
+        if (s->fadeFrameCount < p.fade_duration) {                                                               // :957-961
+            alpha = alpha * (static_cast<float>(s->fadeFrameCount) / p.fade_duration);
+            s->fadeFrameCount++;
+        }
+        // cv::addWeighted(borderHistory_, alpha, frameWithBorder, 1.0f - alpha, 0.0, ...) copied back under the all-255 mask
+        vso_add_weighted_u8(s->borderHistory.data(), (double)alpha, padded.data(), (double)(1.0f - alpha), 0.0, padded.data(), nb);
+        warp_affine(padded.data(), bw, bh, (size_t)bw * cn, cn, out, out_stride, T, g_threads);                  // :1056-1060
+        const float updateRate = 0.1f;                                                                           // :1091-1098
+        for (int y = 0; y < bh; y++) {
+            uint8_t* hrow = &s->borderHistory[(size_t)y * bw * cn];
+            const uint8_t* srow = out + (size_t)y * out_stride;
+            for (int x = 0; x < bw * cn; x++)
+                hrow[x] = static_cast<uint8_t>((1.0f - updateRate) * hrow[x] + updateRate * srow[x]);
+        }
+        return 1;
+    }
     if (b > 0 && !p.crop_n_zoom) {  // :981-990
         int bw = w + 2 * b, bh = h + 2 * b;
         std::vector<uint8_t> padded((size_t)bw * bh * cn);

@@ -486,6 +486,9 @@ class OracleStab:
     def __del__(self):
         self.close()
 
+    def clean(self):
+        self.lib.vso_stab_clean(self.h)
+
     def out_shape(self, frame, fmt):
         w = frame.shape[1]
         h = frame.shape[0] if fmt != 1 else frame.shape[0] * 2 // 3

@@ -108,6 +108,35 @@ def test_pipeline_border_modes(gpu, oracle):
         run_both(gpu, oracle, clip, smoothing_radius=5, border_size=16, border_type=border)
 
 
+@pytest.mark.parametrize("alpha,duration", [(0.1, 30), (0.35, 4), (0.9, 0)])
+def test_pipeline_border_fade(gpu, oracle, alpha, duration):
+    """borderType "fade" (Stabilizer.cpp:914-978, 1069-1106): the padded frame is blended with a history that every output
+    updates; the fade-in of the history weight over fadeDuration frames, and the steady state behind it."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 5, 256, 192, 16)
+    n_out, _ = run_both(gpu, oracle, clip, smoothing_radius=5, border_size=12, border_type=capi.BORDER_FADE, fade_alpha=alpha,
+                        fade_duration=duration)
+    assert n_out == 16
+
+
+def test_fade_history_survives_clean_and_batch_mode_is_declined(gpu, oracle):
+    """borderHistory_ is not reset by Stabilizer::clean() (Stabilizer.cpp:221-256): a second pass over the clip starts from
+    the history of the first; and set_batch() leaves a fade stream with the per-frame pipeline (each output depends on the
+    history the output before it updated)."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 6, 192, 144, 10)
+    kw = dict(smoothing_radius=5, border_size=8, border_type=capi.BORDER_FADE, fade_alpha=0.5, fade_duration=3)
+    sg, so = gpu.stabilizer(gpu.params(**kw)), oracle.stabilizer(oracle.params(**kw))
+    sg.set_batch(8)
+    for rep in range(2):
+        for f in clip:
+            a, b = sg.push(f), so.push(f)
+            assert (a is None) == (b is None)
+            if a is not None:
+                d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+                assert d.max() <= 8 and np.count_nonzero(d) <= max(1e-4 * d.size, 64), rep
+        sg.clean(); so.clean()
+    sg.close(); so.close()
+
+
 def test_pipeline_crop_n_zoom(gpu, oracle):
     clip = synth.make_clip(synth.SEED_CONFIG1 + 5, 256, 192, 12)
     run_both(gpu, oracle, clip, smoothing_radius=5, border_size=12, crop_n_zoom=1)

@@ -58,8 +58,8 @@ def test_bad_params_rejected_before_touching_the_gpu(vs):
     assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 1       # VS_ERR_INVALID_ARG
     p = vs.params(enable_virtual_canvas=1)
     assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 4       # VS_ERR_UNSUPPORTED
-    p = vs.params(border_type=capi.BORDER_FADE, border_size=8)
-    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 4
+    p = vs.params(border_type=capi.BORDER_FADE + 1, border_size=8)
+    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 1
 
 
 def test_no_gpu_means_loud_failure_not_fallback(vs):

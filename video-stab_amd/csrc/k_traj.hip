@@ -75,7 +75,54 @@ __global__ __launch_bounds__(256) void make_border_kernel(const uint8_t* __restr
         dst[(size_t)y * dstride + (size_t)x * cn + k] = (sx >= 0 && sy >= 0) ? src[(size_t)sy * sstride + (size_t)sx * cn + k] : 0;
 }
 
+// borderType "fade" (Stabilizer.cpp:914-978): frame = addWeighted(history, alpha, frame, 1 - alpha) over the whole padded
+// frame (the reference's border mask is all 255), cv::addWeighted on 8-bit data = fma(a, alpha, fma(b, beta, 0)) in float,
+// rounded half to even and saturated.  One thread = 4 bytes.
+__global__ __launch_bounds__(256) void fade_blend_kernel(const uint8_t* __restrict__ hist, uint8_t* __restrict__ frame, size_t n4, float alpha,
+                                                        float beta) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const uint32_t hv = reinterpret_cast<const uint32_t*>(hist)[i], fv = reinterpret_cast<const uint32_t*>(frame)[i];
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float a = (float)((hv >> (8 * k)) & 255u), b = (float)((fv >> (8 * k)) & 255u);
+        int v = __float2int_rn(fmaf(a, alpha, fmaf(b, beta, 0.0f)));
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        o |= (uint32_t)v << (8 * k);
+    }
+    reinterpret_cast<uint32_t*>(frame)[i] = o;
+}
+
+// history = (uchar)((1 - 0.1f) * history + 0.1f * stabilized) for every sample (:1086-1100; two float products, one sum,
+// truncation - the library is built without contraction).  `stab` has row pitch sstride, the history is packed.
+__global__ __launch_bounds__(256) void fade_update_kernel(uint8_t* __restrict__ hist, const uint8_t* __restrict__ stab, size_t sstride, int row_bytes,
+                                                          int rows) {
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x >= row_bytes || y >= rows) return;
+    uint8_t* h = hist + (size_t)y * row_bytes + x;
+    const uint8_t* s = stab + (size_t)y * sstride + x;
+    const float updateRate = 0.1f;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (x + k < row_bytes) h[k] = (uint8_t)((1.0f - updateRate) * (float)h[k] + updateRate * (float)s[k]);
+}
+
 }  // namespace
+
+int launch_fade_blend(const uint8_t* d_hist, uint8_t* d_frame, size_t bytes, float alpha, float beta, hipStream_t st) {
+    const size_t n4 = bytes / 4;        // (padded frames of the stabilizer: bytes is a multiple of 4 after rounding the buffer)
+    hipLaunchKernelGGL(fade_blend_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, d_hist, d_frame, n4, alpha, beta);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_fade_update(uint8_t* d_hist, const uint8_t* d_stab, size_t sstride, int row_bytes, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(fade_update_kernel, dim3((row_bytes / 4 + 1 + 255) / 256, rows), dim3(256), 0, st, d_hist, d_stab, sstride, row_bytes, rows);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
 
 int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
                      hipStream_t st) {

@@ -69,6 +69,8 @@ int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, d
                      hipStream_t st);
 int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st);
 int launch_spin(int microseconds, hipStream_t st);
+int launch_fade_blend(const uint8_t* d_hist, uint8_t* d_frame, size_t bytes, float alpha, float beta, hipStream_t st);
+int launch_fade_update(uint8_t* d_hist, const uint8_t* d_stab, size_t sstride, int row_bytes, int rows, hipStream_t st);
 int launch_make_border(const uint8_t* src, size_t sstride, int w, int h, int cn, uint8_t* dst, size_t dstride,
                        int b, int border, hipStream_t st);
 int launch_resize_linear(const uint8_t* d_src, size_t sstride, int sw, int sh, int cn, uint8_t* d_dst,
@@ -156,6 +158,9 @@ struct vs_stab {
     // scratch for border / host I/O
     uint8_t* d_tmp = nullptr;
     size_t tmp_bytes = 0;
+    uint8_t* d_fade = nullptr;          // borderType "fade": borderHistory_ (padded frame, packed rows)
+    bool fade_valid = false;
+    int fade_count = 0, fade_w = 0, fade_h = 0;     // fadeFrameCount_; geometry of the history
     uint8_t* d_padB = nullptr;          // batch mode with a border: one padded (or to-be-cropped) frame per frame of a batch
     size_t pad_frame_bytes = 0;
     uint8_t* d_out = nullptr;
@@ -321,6 +326,7 @@ void free_all(vs_stab* s) {
     if (s->d_tmp) (void)hipFree(s->d_tmp);
     if (s->d_padB) (void)hipFree(s->d_padB);
     s->d_padB = nullptr;
+    // (d_fade, the fade history, outlives vs_stab_clean like borderHistory_ outlives Stabilizer::clean())
     if (s->d_out) (void)hipFree(s->d_out);
     for (auto& h : s->d_hold) { if (h) (void)hipFree(h); h = nullptr; }
     s->hold_valid = false;
@@ -361,7 +367,9 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     }
     // (adaptive smoothing stays with the per-frame pipeline: whether a push produces a frame then depends on the data - the
     // radius moves the warm-up threshold, Stabilizer.cpp:383,1482-1486 - and a push answers that at once)
-    s->batch_active = s->batch > 1 && !s->p.adaptive_smoothing;
+    // (so does borderType "fade": each output is blended with a history the output before it has just updated)
+    const bool fade = s->p.border_type == VS_BORDER_FADE && s->p.border_size > 0 && !s->p.crop_n_zoom;
+    s->batch_active = s->batch > 1 && !s->p.adaptive_smoothing && !fade;
     const int B = s->batch_active ? s->batch : 1;
     s->npyr = s->batch_active ? 2 * B + 2 : NPYR;
     // keypoint buffers: one per detection, recycled after two batches' worth of detections
@@ -454,7 +462,7 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->out_bytes = (size_t)ow * s->cn * (fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh);
     S_HIP(s, hipMalloc((void**)&s->d_out, s->out_bytes));
     s->tmp_bytes = std::max(s->out_bytes, s->frame_bytes);
-    S_HIP(s, hipMalloc((void**)&s->d_tmp, s->tmp_bytes));
+    S_HIP(s, hipMalloc((void**)&s->d_tmp, s->tmp_bytes + 16));
     if (s->batch_active && s->p.border_size > 0) {
         s->pad_frame_bytes = (s->tmp_bytes + 255) & ~(size_t)255;
         S_HIP(s, hipMalloc((void**)&s->d_padB, s->pad_frame_bytes * B));
@@ -785,6 +793,30 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
             rc = launch_warp_affine(frame + src_uv(s), s->src_pitch, 0, s->w / 2, s->h / 2,
                                     d_out + dst_uv(s, d_out, out_stride), out_stride, 0, s->w / 2, s->h / 2, 2,
                                     s->d_Minv + 6, 1, nullptr, st);
+    } else if (p.border_size > 0 && !p.crop_n_zoom && p.border_type == VS_BORDER_FADE) {     // :914-978, :1069-1106
+        const int b = p.border_size, bw = s->w + 2 * b, bh = s->h + 2 * b;
+        const size_t prow = (size_t)bw * s->cn, nb = prow * bh;
+        rc = launch_make_border(frame, s->src_pitch, s->w, s->h, s->cn, s->d_tmp, prow, b, VS_BORDER_BLACK, st);
+        if (rc == VS_OK && (!s->d_fade || s->fade_w != bw || s->fade_h != bh)) {     // :917-926 the first padded frame is the history
+            if (s->d_fade) { (void)hipStreamSynchronize(st); (void)hipFree(s->d_fade); s->d_fade = nullptr; }
+            S_HIP(s, hipMalloc((void**)&s->d_fade, (nb + 3) & ~(size_t)3));
+            s->fade_w = bw; s->fade_h = bh; s->fade_valid = false;
+        }
+        if (rc == VS_OK && !s->fade_valid) {
+            S_HIP(s, hipMemcpyAsync(s->d_fade, s->d_tmp, nb, hipMemcpyDeviceToDevice, st));
+            s->fade_valid = true; s->fade_count = 0;
+        }
+        float alpha = p.fade_alpha;                                                       // :953-961
+        if (s->fade_count < p.fade_duration) {
+            alpha = alpha * (static_cast<float>(s->fade_count) / p.fade_duration);
+            s->fade_count++;
+        }
+        if (rc == VS_OK) rc = launch_fade_blend(s->d_fade, s->d_tmp, (nb + 3) & ~(size_t)3, alpha, 1.0f - alpha, st);
+        {
+            StageScope t(s, VS_STAGE_WARP, st);
+            if (rc == VS_OK) rc = launch_warp_affine(s->d_tmp, prow, 0, bw, bh, d_out, out_stride, 0, bw, bh, s->cn, s->d_Minv, 1, nullptr, st);
+        }
+        if (rc == VS_OK) rc = launch_fade_update(s->d_fade, d_out, out_stride, (int)prow, bh, st);
     } else if (p.border_size > 0 && !p.crop_n_zoom) {                                 // :981-990
         const int b = p.border_size, bw = s->w + 2 * b, bh = s->h + 2 * b;
         rc = launch_make_border(frame, s->src_pitch, s->w, s->h, s->cn, s->d_tmp, (size_t)bw * s->cn, b, p.border_type, st);
@@ -1035,7 +1067,6 @@ int run_batch(vs_stab* s) {
 int check_params(const vs_params_c* p, std::string* why) {
     if (!p || p->struct_size != (int32_t)sizeof(vs_params_c)) { *why = "params: struct_size mismatch"; return VS_ERR_INVALID_ARG; }
     if (p->enable_virtual_canvas) { *why = "enableVirtualCanvas is outside the accelerated path"; return VS_ERR_UNSUPPORTED; }
-    if (p->border_type == VS_BORDER_FADE && p->border_size > 0 && !p->crop_n_zoom) { *why = "borderType 'fade' is outside the accelerated path"; return VS_ERR_UNSUPPORTED; }
     if (p->max_corners < 1 || p->max_corners > 4096) { *why = "maxCorners must be in [1,4096]"; return VS_ERR_INVALID_ARG; }
     if (p->block_size < 1 || p->block_size > 7) { *why = "blockSize must be in [1,7]"; return VS_ERR_INVALID_ARG; }
     if (p->lk_win_size < 3 || p->lk_win_size > 31 || p->lk_max_level < 0 || p->lk_max_level > 7) { *why = "LK window/levels out of range"; return VS_ERR_INVALID_ARG; }
@@ -1251,6 +1282,7 @@ void vs_stab_destroy(vs_stab* s) {
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st_warp) (void)hipStreamSynchronize(s->st_warp);
     free_all(s);
+    if (s->d_fade) (void)hipFree(s->d_fade);
     for (auto& pe : s->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     destroy_events(s);
