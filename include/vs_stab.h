@@ -86,7 +86,7 @@ typedef struct vs_params_c {
     int32_t max_smoothing_radius; /* :116 default 50                           */
     float   fade_alpha;           /* :128 default 0.1                          */
     int32_t fade_duration;        /* :129 default 30                           */
-    int32_t enable_virtual_canvas;/* :154 default 0 (VS_ERR_UNSUPPORTED if 1)  */
+    int32_t enable_virtual_canvas;/* :154 default 0 (BGR8 streams only)        */
     int32_t drone_high_freq_mode; /* :165 default 0                            */
     float   hf_shake_px;          /* :166 default 1.5                          */
     int32_t hf_analysis_max_width;/* :167 default 960                          */
@@ -102,7 +102,17 @@ typedef struct vs_params_c {
     double  lk_epsilon;           /* 0.03                                      */
     int32_t ransac_max_iters;     /* 500 (Stabilizer.cpp:649)                  */
     double  ransac_threshold;     /* 5.0                                       */
-    int32_t reserved[8];
+    /* --- virtual canvas (Stabilizer.h:155-162), read when enable_virtual_canvas != 0; carved out of the
+     *     reserved tail, so sizeof(vs_params_c) did not change.  preserveEdgeQuality (:161) is never read
+     *     by the reference and has no field. ------------------------------------------------------------ */
+    float   canvas_scale_factor;  /* :155 default 1.5                          */
+    int32_t temporal_buffer_size; /* :156 default 30   (0..256)                */
+    float   canvas_blend_weight;  /* :157 default 0.7  (0..1)                  */
+    int32_t adaptive_canvas_size; /* :158 default 1                            */
+    float   max_canvas_scale;     /* :159 default 2.0                          */
+    float   min_canvas_scale;     /* :160 default 1.2                          */
+    int32_t edge_blend_radius;    /* :162 default 20                           */
+    int32_t reserved[1];
 } vs_params_c;
 
 /* Throughput / health counters ("Metrics"). */
@@ -223,6 +233,10 @@ int vs_stab_out_size(const vs_stab* s, int w, int h, int* out_w, int* out_h);
 int vs_stab_last_out_dims(const vs_stab* s, int* w, int* h);
 int vs_stab_get_counters(vs_stab* s, vs_counters* out);      /* synchronises  */
 int vs_stab_get_debug(vs_stab* s, vs_debug_frame* out);      /* synchronises  */
+/* enableVirtualCanvas, state after the last output: {canvas w, canvas h, canvas scale (float bits), empty regions,
+ * regions filled from the temporal buffer, temporal index of the last fill or -1, window x, window y}
+ * (Stabilizer.cpp:2083-2088, 2232-2241, 2115-2132).  Zeros when the canvas is off. */
+int vs_stab_canvas_info(const vs_stab* s, int32_t info[8]);
 /* copies the debug arrays of the last push: any pointer may be NULL.
  * prev/curr: n_prev * 2 floats; status: n_prev bytes; inliers: n_valid bytes;
  * detected: n_detected * 2 floats; gray: analysis image (aw*ah bytes). */
@@ -421,6 +435,11 @@ int vs_op_content_mask(const void* d_src, size_t stride, int w, int h, int cn, v
  * drawContours(FILLED) mask.  Needs no device. */
 int vs_azc_crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, int32_t* info8,
                           uint8_t* filled_out);
+/* cv::boundingRect of every contour cv::findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) returns, in the order of
+ * that vector: the region list of the virtual canvas (Stabilizer.cpp:2232-2241).  HOST mask; xywh receives up to
+ * max_boxes rectangles, *n_boxes the number found.  Needs no device. */
+int vs_op_external_boxes(const uint8_t* mask, int w, int h, size_t stride, int32_t* xywh, int max_boxes,
+                         int32_t* n_boxes);
 
 /* ---- image enhancer: vs::Enhancer (Enhancer.h:10-60, Enhancer.cpp:138-239) ------------ */
 /* Enhancer::Parameters defaults, Enhancer.h:12-43 */

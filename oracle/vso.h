@@ -98,6 +98,8 @@ int vso_stab_push(vso_stab* s, const uint8_t* data, int w, int h, size_t stride,
 int vso_stab_flush(vso_stab* s, uint8_t* out, size_t out_stride);
 void vso_stab_out_size(const vso_stab* s, int w, int h, int* ow, int* oh);
 void vso_stab_get_debug(const vso_stab* s, vs_debug_frame* d);
+/* {canvas w, h, scale (float bits), regions, regions filled, temporal index of the last fill, window x, y} */
+void vso_stab_canvas_info(const vso_stab* s, int32_t info[8]);
 int  vso_stab_get_debug_arrays(const vso_stab* s, float* prev_pts, float* curr_pts,
                                uint8_t* status, uint8_t* inliers, float* detected_pts,
                                uint8_t* gray, int* aw, int* ah);

@@ -48,8 +48,6 @@ void content_mask(const uint8_t* src, int w, int h, size_t stride, int cn, uint8
     morph5(t.data(), w, h, mask, false);
 }
 
-struct Pt { int x, y; };
-
 // cv::findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
 void find_contours_external(const uint8_t* mask, int w, int h, size_t stride, std::vector<std::vector<Pt>>& out) {
     out.clear();
@@ -112,6 +110,9 @@ void find_contours_external(const uint8_t* mask, int w, int h, size_t stride, st
             }
         }
     }
+    // cvInsertNodeIntoTree() puts every finished contour at the head of its parent's child list: the vector
+    // cv::findContours returns lists the contours last found first (bottom of the image to top)
+    std::reverse(out.begin(), out.end());
 }
 
 // cv::drawContours(mask, {c}, 0, 255, FILLED): even-odd scanline fill of the polygon through the

@@ -239,10 +239,11 @@ void warp_rows(const uint8_t* src, int sw, int sh, size_t sstride, int cn, uint8
             int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
             int w[4];
             bilinear_tab(X & 31, Y & 31, w);
-            if (border == VS_BORDER_REPLICATE) {
-                // remapBilinear, BORDER_REPLICATE: tap coordinates are clamped into the image
-                auto clip = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
-                const int sx0 = clip(sx, sw), sx1 = clip(sx + 1, sw), sy0 = clip(sy, sh), sy1 = clip(sy + 1, sh);
+            if (border != VS_BORDER_BLACK) {
+                // remapBilinear, borders other than CONSTANT: every tap coordinate goes through borderInterpolate
+                // (REPLICATE: clip()), each axis by itself
+                const int sx0 = border_interpolate(sx, sw, border), sx1 = border_interpolate(sx + 1, sw, border);
+                const int sy0 = border_interpolate(sy, sh, border), sy1 = border_interpolate(sy + 1, sh, border);
                 for (int k = 0; k < cn; k++) {
                     int t = src[(size_t)sy0 * sstride + sx0 * cn + k] * w[0] + src[(size_t)sy0 * sstride + sx1 * cn + k] * w[1] +
                             src[(size_t)sy1 * sstride + sx0 * cn + k] * w[2] + src[(size_t)sy1 * sstride + sx1 * cn + k] * w[3];

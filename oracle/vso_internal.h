@@ -71,6 +71,20 @@ int adaptive_radius(const std::vector<float>& px, const std::vector<float>& py,
 int motion_intent(const std::vector<float>& tr /* n*3 */, const float motion[3], int frame_index);
 float adaptive_strength(int intent, const float motion[3]);
 
+struct Pt { int x, y; };
+// cv::findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE), in the order of the vector OpenCV returns
+void find_contours_external(const uint8_t* mask, int w, int h, size_t stride, std::vector<std::vector<Pt>>& out);
+
+// Virtual canvas (Stabilizer.cpp:1130-1134, 2066-2443): vso_canvas.cpp
+struct CanvasState;
+CanvasState* canvas_new();
+void canvas_delete(CanvasState* c);
+// out <- the frame the reference returns for `frame` (w x h BGR) whose correction is t = (dx, dy, da);
+// transforms = transforms_ (n * 3) at the time of the call
+void canvas_apply(CanvasState* c, const vs_params_c& p, const uint8_t* frame, int w, int h, size_t stride, const float t[3],
+                  const std::vector<float>& transforms, uint8_t* out, size_t out_stride);
+void canvas_info(const CanvasState* c, int32_t info[8]);
+
 extern int g_threads;
 
 }  // namespace vso

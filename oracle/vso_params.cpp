@@ -24,6 +24,13 @@ extern "C" void vso_params_default(vs_params_c* p) {
     p->max_smoothing_radius = 50;
     p->fade_alpha = 0.1f;
     p->fade_duration = 30;
+    p->canvas_scale_factor = 1.5f;
+    p->temporal_buffer_size = 30;
+    p->canvas_blend_weight = 0.7f;
+    p->adaptive_canvas_size = 1;
+    p->max_canvas_scale = 2.0f;
+    p->min_canvas_scale = 1.2f;
+    p->edge_blend_radius = 20;
     p->enable_virtual_canvas = 0;
     p->drone_high_freq_mode = 0;
     p->hf_shake_px = 1.5f;

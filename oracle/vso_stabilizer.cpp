@@ -5,7 +5,8 @@
 //     (:696; identical for a single instance - SURVEY Q3);
 //   * queued frames are always copied (:376 aliases the caller's buffer);
 //   * NV12 input (no reference path): analysis runs on the luma plane.
-//   * enableVirtualCanvas is not restated.
+//   * enableVirtualCanvas (vso_canvas.cpp) replaces the warped frame (:1130-1134): the warp and the fade history behind
+//     it cannot be observed then and are not run; BGR8 streams only (cv::cvtColor(BGR2GRAY) of :2225 needs 3 channels).
 #include "vso_internal.h"
 
 #include <algorithm>
@@ -31,6 +32,7 @@ struct vso_stab {
     int origW = 0, origH = 0;
     std::vector<uint8_t> borderHistory;   // Stabilizer.h:356-358 (borderHistory_, fadeFrameCount_)
     int fadeFrameCount = 0;
+    CanvasState* canvas = nullptr;        // Stabilizer.h:408-416
     int detectCounter = 0;
     // drone (Stabilizer.h:418-429)
     std::deque<std::pair<float, float>> hfHistory;
@@ -225,8 +227,11 @@ static void generate_transform(vso_stab* s, const uint8_t* data, int w, int h, s
     s->dbgGray = curr;
 }
 
-static void out_size(const vs_params_c& p, int w, int h, int origW, int origH, int* ow, int* oh) {
+static bool canvas_on(const vs_params_c& p, int fmt) { return p.enable_virtual_canvas && !p.crop_n_zoom && fmt == VS_FMT_BGR8; }
+
+static void out_size(const vs_params_c& p, int w, int h, int origW, int origH, int* ow, int* oh, int fmt = VS_FMT_BGR8) {
     int b = p.border_size;
+    if (canvas_on(p, fmt)) { *ow = w; *oh = h; return; }      // the canvas window has the size of the unpadded frame (:2121-2126)
     if (b > 0 && !p.crop_n_zoom) { *ow = w + 2 * b; *oh = h + 2 * b; return; }
     if (p.crop_n_zoom && b > 0 && w - 2 * b > 0 && h - 2 * b > 0 && origW > 0) { *ow = origW; *oh = origH; return; }
     *ow = w; *oh = h;
@@ -287,6 +292,12 @@ static int apply_next(vso_stab* s, uint8_t* out, size_t out_stride) {
         vso_warp_affine_nv12(frame.data(), w, h, fstride, out, out_stride, T);
         return 1;
     }
+    if (canvas_on(p, s->fmt)) {  // :1130-1134
+        const float t[3] = {dx, dy, da};
+        if (!s->canvas) s->canvas = canvas_new();
+        canvas_apply(s->canvas, p, frame.data(), w, h, fstride, t, s->transforms, out, out_stride);
+        return 1;
+    }
     int b = p.border_size;
     if (b > 0 && !p.crop_n_zoom && p.border_type == VS_BORDER_FADE) {  // :914-978, :1069-1106
         // The "border mask" of the reference is drawn as two filled rectangles of which the second, over the whole image,
@@ -341,7 +352,15 @@ vso_stab* vso_stab_create(const vs_params_c* p) {
     s->dbg.out_index = -1;
     return s;
 }
-void vso_stab_destroy(vso_stab* s) { delete s; }
+void vso_stab_destroy(vso_stab* s) {
+    if (s && s->canvas) canvas_delete(s->canvas);
+    delete s;
+}
+/* {canvas w, h, scale (float bits), regions, regions filled, temporal index of the last fill, window x, y} */
+void vso_stab_canvas_info(const vso_stab* s, int32_t info[8]) {
+    memset(info, 0, 8 * sizeof(int32_t));
+    if (s->canvas) canvas_info(s->canvas, info);
+}
 
 void vso_stab_clean(vso_stab* s) {  // Stabilizer.cpp:221-256
     s->frameQueue.clear(); s->idxQueue.clear();
@@ -352,7 +371,7 @@ void vso_stab_clean(vso_stab* s) {  // Stabilizer.cpp:221-256
 
 void vso_stab_out_size(const vso_stab* s, int w, int h, int* ow, int* oh) {
     int oW = s->origW > 0 ? s->origW : w, oH = s->origH > 0 ? s->origH : h;
-    out_size(s->p, w, h, oW, oH, ow, oh);
+    out_size(s->p, w, h, oW, oH, ow, oh, s->fmt);
 }
 
 int vso_stab_push(vso_stab* s, const uint8_t* data, int w, int h, size_t stride, int fmt,

@@ -42,6 +42,7 @@ class Oracle:
         lib.vso_stab_flush.argtypes = [C.c_void_p, u8p, C.c_size_t]
         lib.vso_stab_out_size.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, i32p]
         lib.vso_stab_get_debug.argtypes = [C.c_void_p, C.POINTER(VsDebugFrame)]
+        lib.vso_stab_canvas_info.argtypes = [C.c_void_p, i32p]
         lib.vso_stab_get_debug_arrays.argtypes = [C.c_void_p, f32p, f32p, u8p, u8p, f32p, u8p, i32p, i32p]
         lib.vso_params_default.argtypes = [C.POINTER(VsParams)]
         lib.vso_resize_linear_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, u8p, C.c_int, C.c_int, C.c_size_t]
@@ -488,6 +489,11 @@ class OracleStab:
 
     def clean(self):
         self.lib.vso_stab_clean(self.h)
+
+    def canvas_info(self):
+        info = np.zeros(8, np.int32)
+        self.lib.vso_stab_canvas_info(self.h, info.ctypes.data_as(C.POINTER(C.c_int32)))
+        return info
 
     def out_shape(self, frame, fmt):
         w = frame.shape[1]

@@ -83,7 +83,7 @@ def test_contour_special_shapes(oracle):
     assert oracle.find_contours(m)[0].tolist() == [[0, 0], [0, 8], [8, 8], [8, 0]]
 
 
-def test_contours_external_only_and_raster_order(oracle):
+def test_contours_external_only_and_last_found_first(oracle):
     m = np.zeros((40, 60), np.uint8)
     m[5:30, 10:50] = 255
     m[12:20, 20:35] = 0                 # hole
@@ -91,7 +91,38 @@ def test_contours_external_only_and_raster_order(oracle):
     m[33:36, 3:8] = 255                 # second external component, later in raster order
     cs = oracle.find_contours(m)
     assert len(cs) == 2
-    assert cs[0][0].tolist() == [10, 5] and cs[1][0].tolist() == [3, 33]
+    # every finished contour goes to the head of OpenCV's list (cvInsertNodeIntoTree): the vector runs from the
+    # bottom of the image to the top
+    assert cs[0][0].tolist() == [3, 33] and cs[1][0].tolist() == [10, 5]
+
+
+def test_external_boxes_match_the_oracle_contours_in_order(vs, oracle):
+    """The product's region list for the virtual canvas (vs_op_external_boxes, host code) = cv::boundingRect of the
+    oracle's contours, same order."""
+    total = 0
+    for m in random_masks():
+        want = []
+        for c in oracle.find_contours(m):
+            x0, y0, x1, y1 = c[:, 0].min(), c[:, 1].min(), c[:, 0].max(), c[:, 1].max()
+            want.append([x0, y0, x1 - x0 + 1, y1 - y0 + 1])
+        got = vs.external_boxes(m)
+        assert got.tolist() == want
+        total += len(want)
+    assert total > 100
+    ring = np.full((50, 70), 255, np.uint8); ring[10:40, 12:60] = 0; ring[20:25, 30:40] = 255   # canvas ring + a dark blob in the frame
+    assert vs.external_boxes(ring).tolist() == [[0, 0, 70, 50]]
+
+
+def test_largest_contour_tie_goes_to_the_first_of_opencvs_vector(vs, oracle):
+    """AutoZoomCrop.cpp:155-164 keeps the first contour of maximal size in the vector cv::findContours returned, i.e.
+    the one found LAST in raster order."""
+    m = np.zeros((40, 60), np.uint8)
+    m[4:14, 5:25] = 255                 # two rectangles: 4 contour points each
+    m[22:36, 30:55] = 255
+    info = vs.azc_crop_from_mask(m)
+    want = oracle.azc_crop_rect(m)
+    assert info.tolist() == want.tolist()
+    assert info[3] >= 22                # the crop sits in the lower rectangle
 
 
 def _true_outer_fill(mask, start_xy):

@@ -137,6 +137,89 @@ def test_fade_history_survives_clean_and_batch_mode_is_declined(gpu, oracle):
     sg.close(); so.close()
 
 
+def _canvas_run(gpu, oracle, clip, passes=1, batch=0, **kw):
+    """Both stabilizers over the clip with the virtual canvas on: the canvas state (size, scale, regions, fills, window)
+    must agree output by output; returns the outputs and the number of fills."""
+    kw = dict(dict(smoothing_radius=5, enable_virtual_canvas=1), **kw)
+    sg, so = gpu.stabilizer(gpu.params(**kw)), oracle.stabilizer(oracle.params(**kw))
+    if batch:
+        sg.set_batch(batch)
+    outs, fills = [], 0
+    for rep in range(passes):
+        for k, f in enumerate(clip):
+            a, b = sg.push(f), so.push(f)
+            assert (a is None) == (b is None), k
+            if a is None:
+                continue
+            assert a.shape == b.shape == f.shape
+            ig, io = sg.canvas_info(), so.canvas_info()
+            assert ig.tolist() == io.tolist(), (rep, k, ig, io)
+            fills += int(io[4])
+            outs.append((a, b))
+        while True:
+            a, b = sg.flush(clip[0]), so.flush(clip[0])
+            assert (a is None) == (b is None)
+            if a is None:
+                break
+            outs.append((a, b))
+        sg.clean(); so.clean()
+    sg.close(); so.close()
+    return outs, fills
+
+
+def test_virtual_canvas_default_scale_is_a_shifted_copy(gpu, oracle):
+    """enableVirtualCanvas with the defaults (Stabilizer.cpp:1130-1134, 2066-2149): scale >= 1.5, the one empty region is
+    the whole canvas, no frame covers half of it, nothing is filled: the output is the unwarped frame moved by the
+    integer part of the correction, black where the canvas shows.  Bit-exact; a border pad does not change its size."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 11, 256, 192, 14)
+    outs, fills = _canvas_run(gpu, oracle, clip, border_size=8, border_type=capi.BORDER_REFLECT)
+    assert fills == 0 and len(outs) == 14
+    for a, b in outs:
+        assert np.array_equal(a, b)
+    assert any((a == 0).all(axis=2).any() for a, _ in outs[1:-1])      # some canvas shows
+
+
+@pytest.mark.parametrize("scale", [1.2, 1.0, 0.8])
+def test_virtual_canvas_temporal_fill(gpu, oracle, scale):
+    """Scales at which the reference fills: 1.2 (the ring region = whole canvas, filled from the previous frame stretched
+    to the canvas), 1.0 (no ring: the regions are the dark parts of the picture, from the gray <= 1 mask and its external
+    contours), 0.8 (the window does not fit: the frame comes back as it is).  Two passes: the temporal buffer and the
+    canvas outlive clean()."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 12, 224, 160, 12)
+    clip = [f.copy() for f in clip]
+    for k, f in enumerate(clip):
+        f[40:70, 60 + k:110 + k] = 0                # a dark object that moves
+        f[100:160, 0:25] = 0                        # one that touches the picture's border
+        f[10:16, 10:20] = 1                         # small: area <= 100, ignored
+    outs, fills = _canvas_run(gpu, oracle, clip, passes=2, adaptive_canvas_size=0, canvas_scale_factor=scale, temporal_buffer_size=4,
+                              edge_blend_radius=6, batch=8)
+    assert fills > 0           # (at 0.8 too: the reference blends into a canvas it then does not use)
+    worst = 0
+    for a, b in outs:
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        # the compensation matrix comes from differences of corrections that may differ in the last bit between
+        # the device's and the oracle's smoothing: a few samples may land on the other side of a 1/32-pixel step
+        assert np.count_nonzero(d) <= max(2e-4 * d.size, 32), np.count_nonzero(d)
+        worst = max(worst, int(d.max()))
+    if scale < 0.9:
+        assert worst == 0
+
+
+def test_virtual_canvas_adaptive_scale_follows_the_motion(gpu, oracle):
+    """calculateOptimalCanvasSize (:2281-2314): the scale is chosen once, from the largest of the last 30 transforms."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 13, 256, 192, 10, pan_q8=16 * 256)      # 60 analysis pixels per frame
+    kw = dict(smoothing_radius=5, enable_virtual_canvas=1, canvas_scale_factor=1.1, min_canvas_scale=1.05, max_canvas_scale=3.0)
+    so = oracle.stabilizer(oracle.params(**kw))
+    for f in clip:
+        so.push(f)
+    scale = so.canvas_info()[2:3].view(np.float32)[0]
+    so.close()
+    assert 1.15 < scale < 3.0, scale          # the clip does move the scale off its base value
+    outs, _ = _canvas_run(gpu, oracle, clip, **{k: v for k, v in kw.items() if k not in ("smoothing_radius", "enable_virtual_canvas")})
+    for a, b in outs:
+        assert np.array_equal(a, b)
+
+
 def test_pipeline_crop_n_zoom(gpu, oracle):
     clip = synth.make_clip(synth.SEED_CONFIG1 + 5, 256, 192, 12)
     run_both(gpu, oracle, clip, smoothing_radius=5, border_size=12, crop_n_zoom=1)
@@ -547,7 +630,11 @@ def test_nv12_layout_and_zero_copy_switch_need_an_empty_queue(gpu):
 
 def test_errors_are_loud(gpu):
     with pytest.raises(capi.VsError):
-        gpu.stabilizer(gpu.params(enable_virtual_canvas=1))
+        gpu.stabilizer(gpu.params(enable_virtual_canvas=1, canvas_blend_weight=2.0))
+    s = gpu.stabilizer(gpu.params(enable_virtual_canvas=1, smoothing_radius=5))
+    with pytest.raises(capi.VsError):
+        s.push(np.zeros((120, 160), np.uint8), capi.FMT_GRAY8)      # the reference's canvas needs three channels
+    s.close()
     with pytest.raises(capi.VsError):
         gpu.stabilizer(gpu.params(max_corners=0))
     s = gpu.stabilizer(gpu.params(smoothing_radius=5))

@@ -56,8 +56,12 @@ def test_bad_params_rejected_before_touching_the_gpu(vs):
     p.struct_size = 4
     h = C.c_void_p()
     assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 1       # VS_ERR_INVALID_ARG
-    p = vs.params(enable_virtual_canvas=1)
-    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 4       # VS_ERR_UNSUPPORTED
+    p = vs.params(enable_virtual_canvas=1, canvas_blend_weight=1.5)
+    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 4       # VS_ERR_UNSUPPORTED (uchar cast out of range in the reference)
+    p = vs.params(enable_virtual_canvas=1, temporal_buffer_size=-1)
+    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 1
+    p = vs.params(enable_virtual_canvas=1, temporal_buffer_size=-1, crop_n_zoom=1)   # never reached behind crop-and-zoom
+    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) != 1
     p = vs.params(border_type=capi.BORDER_FADE + 1, border_size=8)
     assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 1
 

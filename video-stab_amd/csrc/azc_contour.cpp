@@ -17,13 +17,14 @@ namespace vsd {
 void set_last_error(const std::string& msg);      // vs_api.cpp
 
 // Follows the outer borders of the mask the way cv::findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
-// numbers them and keeps the one with the most points (first wins ties, AutoZoomCrop.cpp:155-164).
+// finds them and keeps the one with the most points.  cv::findContours lists the contours last found first and
+// AutoZoomCrop.cpp:155-164 keeps the first of equals in that list: of equals the one found LAST wins here.
 // Border pixels already followed carry one of two marks (bit planes ML / MR beside the mask): MR where the
 // border passed with the outside to its east, ML elsewhere.  Scanning a row, an unmarked mask pixel with
 // background to its west starts a new outer border unless the last mark before it on the row is an ML (then the
 // scan is inside a component already followed: a hole, or something within a hole).  Returns the number of
 // contours.
-static int trace_largest(const BitFrame& bf, CropScratch& S) {
+static int trace_largest(const BitFrame& bf, CropScratch& S, std::vector<Box>* boxes = nullptr) {
     const int h = bf.h, P = bf.pitch;
     const uint64_t* F = bf.F;
     // the mark planes start from zero: only the words the last call marked need wiping
@@ -117,7 +118,16 @@ static int trace_largest(const BitFrame& bf, CropScratch& S) {
                 if (kind != 1) {
                     ++n_contours;
                     follow(k * 64 + b, y);
-                    if (S.cur.size() > S.best.size()) { S.best.swap(S.cur); S.chain_best.swap(S.chain_cur); }
+                    if (boxes) {
+                        Box bx{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
+                        for (const int c : S.chain_cur) {
+                            const int cx = c & 0xFFFF, cy = c >> 16;
+                            bx.x0 = std::min(bx.x0, cx); bx.x1 = std::max(bx.x1, cx);
+                            bx.y0 = std::min(bx.y0, cy); bx.y1 = std::max(bx.y1, cy);
+                        }
+                        boxes->push_back(bx);
+                    }
+                    if (S.cur.size() >= S.best.size()) { S.best.swap(S.cur); S.chain_best.swap(S.chain_cur); }
                 }
                 // the planes may have changed under the scan: look again at what is left of the word
                 const uint64_t above = b == 63 ? 0 : ~((2ull << b) - 1);
@@ -126,6 +136,14 @@ static int trace_largest(const BitFrame& bf, CropScratch& S) {
         }
     }
     return n_contours;
+}
+
+// Bounding boxes of the outer borders, in the order of the vector cv::findContours(RETR_EXTERNAL) returns (every contour
+// goes to the head of the list when it is finished: last found first).
+void external_boxes(const BitFrame& bf, CropScratch& S, std::vector<Box>& out) {
+    out.clear();
+    trace_largest(bf, S, &out);
+    std::reverse(out.begin(), out.end());
 }
 
 // 0 / non-zero bytes -> BitFrame planes in S.bits (the host-only entry point; the device hands over bits)
@@ -280,5 +298,20 @@ int vs_azc_crop_from_mask(const uint8_t* mask, int w, int h, size_t stride, int3
     return VS_OK;
 }
 
+// Host logic only: cv::boundingRect of the contours cv::findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) returns, in
+// the order of that vector (the virtual canvas's region list, Stabilizer.cpp:2232-2241).
+int vs_op_external_boxes(const uint8_t* mask, int w, int h, size_t stride, int32_t* xywh, int max_boxes, int32_t* n_boxes) {
+    if (!mask || !xywh || !n_boxes || max_boxes < 0 || w <= 0 || h <= 0 || stride < (size_t)w) return VS_ERR_INVALID_ARG;
+    if (w > 65535 || h > 32767) { set_last_error("external boxes: image too large"); return VS_ERR_INVALID_ARG; }
+    static thread_local CropScratch S;
+    static thread_local std::vector<Box> boxes;
+    external_boxes(pack_mask(mask, w, h, stride, S), S, boxes);
+    *n_boxes = (int32_t)boxes.size();
+    for (int i = 0; i < (int)boxes.size() && i < max_boxes; i++) {
+        xywh[4 * i] = boxes[i].x0; xywh[4 * i + 1] = boxes[i].y0;
+        xywh[4 * i + 2] = boxes[i].x1 - boxes[i].x0 + 1; xywh[4 * i + 3] = boxes[i].y1 - boxes[i].y0 + 1;
+    }
+    return VS_OK;
+}
 
 }  // extern "C"

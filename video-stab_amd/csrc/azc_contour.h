@@ -10,6 +10,7 @@
 namespace vsd {
 
 struct P2 { int x, y; };
+struct Box { int x0, y0, x1, y1; };     // inclusive corners
 
 // Scratch kept between frames so that the per-frame host work allocates nothing.
 struct CropScratch {
@@ -42,6 +43,10 @@ BitFrame pack_mask(const uint8_t* mask, int w, int h, size_t stride, CropScratch
 // info = {n_contours, contour_points, x, y, w, h, iterations, valid}; filled_dump (optional) receives the filled
 // largest contour as w*h bytes.  w <= 65535, h <= 32767.
 void crop_from_mask(const BitFrame& bf, CropScratch& S, int32_t info[8], std::vector<uint8_t>* filled_dump);
+
+// cv::boundingRect of every contour cv::findContours(mask, RETR_EXTERNAL, ...) returns, in the order of that vector
+// (virtual canvas, Stabilizer.cpp:2232-2241).
+void external_boxes(const BitFrame& bf, CropScratch& S, std::vector<Box>& out);
 
 }  // namespace vsd
 

@@ -462,7 +462,14 @@ int vs_config_read_stab(const vs_config* c, const char* section, int zero_missin
     r.flag("horizon_lock", p->horizon_lock);
     r.i32("fadeDuration", p->fade_duration);
     r.f32("fadeAlpha", p->fade_alpha);
-    r.flag("enable_virtual_canvas", p->enable_virtual_canvas);
+    r.flag("enable_virtual_canvas", p->enable_virtual_canvas);     // examples/vsg.cpp:1086-1094
+    r.f32("canvas_scale_factor", p->canvas_scale_factor);
+    r.i32("temporal_buffer_size", p->temporal_buffer_size);
+    r.f32("canvas_blend_weight", p->canvas_blend_weight);
+    r.flag("adaptive_canvas_size", p->adaptive_canvas_size);
+    r.f32("max_canvas_scale", p->max_canvas_scale);
+    r.f32("min_canvas_scale", p->min_canvas_scale);
+    r.i32("edge_blend_radius", p->edge_blend_radius);
     r.flag("drone_high_freq_mode", p->drone_high_freq_mode);
     r.f32("hf_shake_px", p->hf_shake_px);
     r.i32("hf_analysis_max_width", p->hf_analysis_max_width);

@@ -21,8 +21,8 @@ namespace vsd {
 namespace {
 
 __global__ __launch_bounds__(64) void traj_emit_kernel(TrajState* s, TrajParams p, int idx, float* __restrict__ M_out,
-                                                       double* __restrict__ Minv_out, vs_debug_frame* dbg) {
-    traj_emit_device(s, p, idx, M_out, Minv_out, dbg);
+                                                       double* __restrict__ Minv_out, vs_debug_frame* dbg, float* t_out) {
+    traj_emit_device(s, p, idx, M_out, Minv_out, dbg, t_out);
 }
 
 // test hook (VS_STAB_DEBUG_DELAY_US): one wave that does nothing for about `ticks` of the 100 MHz clock
@@ -125,8 +125,8 @@ int launch_fade_update(uint8_t* d_hist, const uint8_t* d_stab, size_t sstride, i
 }
 
 int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
-                     hipStream_t st) {
-    hipLaunchKernelGGL(traj_emit_kernel, dim3(1), dim3(64), 0, st, s, p, idx, M_out, Minv_out, dbg);
+                     hipStream_t st, float* t_out) {
+    hipLaunchKernelGGL(traj_emit_kernel, dim3(1), dim3(64), 0, st, s, p, idx, M_out, Minv_out, dbg, t_out);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

@@ -34,6 +34,7 @@
 #include <new>
 #include <vector>
 
+#include "canvas.h"
 #include "traj_state.h"
 #include "vs_common.h"
 
@@ -66,7 +67,7 @@ int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w,
                    double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
 int launch_gftt_batch(const void* d_table, int items, int w, int h, int block_size, hipStream_t st);
 int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
-                     hipStream_t st);
+                     hipStream_t st, float* t_out = nullptr);
 int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st);
 int launch_spin(int microseconds, hipStream_t st);
 int launch_fade_blend(const uint8_t* d_hist, uint8_t* d_frame, size_t bytes, float alpha, float beta, hipStream_t st);
@@ -160,6 +161,8 @@ struct vs_stab {
     size_t tmp_bytes = 0;
     uint8_t* d_fade = nullptr;          // borderType "fade": borderHistory_ (padded frame, packed rows)
     bool fade_valid = false;
+    Canvas* canvas = nullptr;           // enableVirtualCanvas: temporal buffer and canvas geometry (outlive clean(), like the fade history)
+    float* d_ct = nullptr;              // the correction (dx, dy, da) of the output being produced, for the canvas
     int fade_count = 0, fade_w = 0, fade_h = 0;     // fadeFrameCount_; geometry of the history
     uint8_t* d_padB = nullptr;          // batch mode with a border: one padded (or to-be-cropped) frame per frame of a batch
     size_t pad_frame_bytes = 0;
@@ -291,8 +294,12 @@ int fail(vs_stab* s, int code, const std::string& msg) {
 
 int effective_radius(int r) { return std::max(5, std::min(r, 35)); }
 
+// enableVirtualCanvas acts where the reference reaches it: not behind the crop-and-zoom returns (Stabilizer.cpp:1108-1127)
+bool canvas_on(const vs_stab* s) { return s->p.enable_virtual_canvas && !s->p.crop_n_zoom; }
+
 void out_size(const vs_stab* s, int w, int h, int* ow, int* oh) {
     const int b = s->p.border_size;
+    if (canvas_on(s)) { *ow = w; *oh = h; return; }     // the canvas window has the size of the unpadded frame (:2121-2126)
     if (b > 0 && !s->p.crop_n_zoom) { *ow = w + 2 * b; *oh = h + 2 * b; return; }
     *ow = w; *oh = h;   // crop+zoom resizes back to origSize_ == frame size
 }
@@ -355,6 +362,8 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->src_pitch = s->row_bytes;
     analysis_size(s, w, h, &s->aw, &s->ah);
     if (s->aw < 3 || s->ah < 3) return fail(s, VS_ERR_INVALID_ARG, "analysis size too small");
+    // (the reference's cvtColor(BGR2GRAY) of the canvas, Stabilizer.cpp:2225, throws on anything but three channels)
+    if (canvas_on(s) && fmt != VS_FMT_BGR8) return fail(s, VS_ERR_UNSUPPORTED, "enableVirtualCanvas needs a BGR8 stream");
     // buildOpticalFlowPyramid: levels that fit the window
     {
         int sw = s->aw, sh = s->ah;
@@ -369,7 +378,8 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     // radius moves the warm-up threshold, Stabilizer.cpp:383,1482-1486 - and a push answers that at once)
     // (so does borderType "fade": each output is blended with a history the output before it has just updated)
     const bool fade = s->p.border_type == VS_BORDER_FADE && s->p.border_size > 0 && !s->p.crop_n_zoom;
-    s->batch_active = s->batch > 1 && !s->p.adaptive_smoothing && !fade;
+    // (and the virtual canvas: the window offset and the temporal fill are host decisions on each output's correction)
+    s->batch_active = s->batch > 1 && !s->p.adaptive_smoothing && !fade && !canvas_on(s);
     const int B = s->batch_active ? s->batch : 1;
     s->npyr = s->batch_active ? 2 * B + 2 : NPYR;
     // keypoint buffers: one per detection, recycled after two batches' worth of detections
@@ -765,7 +775,7 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
     int ow, oh;
     out_size(s, s->w, s->h, &ow, &oh);
     s->last_out_w = ow; s->last_out_h = oh;
-    const bool plain = idx < s->n_transforms && s->fmt != VS_FMT_NV12 && p.border_size <= 0;
+    const bool plain = idx < s->n_transforms && s->fmt != VS_FMT_NV12 && p.border_size <= 0 && !canvas_on(s);
     if (may_defer && plain && s->warp_batch > 1) {
         S_TRY(s, defer_output(s, idx, frame, d_out, out_stride, slot));
         s->counters.frames_out++;
@@ -773,7 +783,8 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
     }
     {
         StageScope t(s, VS_STAGE_TRAJ, st);
-        S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_Minv, s->d_dbg, st));
+        if (canvas_on(s) && !s->d_ct) S_HIP(s, hipMalloc((void**)&s->d_ct, 4 * sizeof(float)));
+        S_TRY(s, launch_traj_emit(s->d_traj, s->tp, idx, s->d_M, s->d_Minv, s->d_dbg, st, canvas_on(s) ? s->d_ct : nullptr));
     }
     int rc = VS_OK;
     if (idx >= s->n_transforms) {
@@ -786,6 +797,11 @@ int apply_next(vs_stab* s, uint8_t* d_out, size_t out_stride, bool may_defer) {
             S_HIP(s, hipMemcpy2DAsync(d_out + dst_uv(s, d_out, out_stride), out_stride, frame + src_uv(s), s->src_pitch, s->row_bytes,
                                       s->h / 2, hipMemcpyDeviceToDevice, st));
         s->last_out_w = s->w; s->last_out_h = s->h;
+    } else if (canvas_on(s)) {                                                        // :1130-1134
+        // the canvas replaces the warped frame, so the warp (and a fade history behind it) cannot be observed and is not run
+        if (!s->canvas && !(s->canvas = canvas_new())) return fail(s, VS_ERR_HIP, "out of host memory");
+        StageScope t(s, VS_STAGE_WARP, st);
+        rc = canvas_apply(s->canvas, p, frame, s->src_pitch, s->w, s->h, s->d_ct, s->d_traj, d_out, out_stride, st);
     } else if (s->fmt == VS_FMT_NV12) {
         StageScope t(s, VS_STAGE_WARP, st);
         rc = launch_warp_affine(frame, s->src_pitch, 0, s->w, s->h, d_out, out_stride, 0, s->w, s->h, 1, s->d_Minv, 1, nullptr, st);
@@ -1066,7 +1082,15 @@ int run_batch(vs_stab* s) {
 
 int check_params(const vs_params_c* p, std::string* why) {
     if (!p || p->struct_size != (int32_t)sizeof(vs_params_c)) { *why = "params: struct_size mismatch"; return VS_ERR_INVALID_ARG; }
-    if (p->enable_virtual_canvas) { *why = "enableVirtualCanvas is outside the accelerated path"; return VS_ERR_UNSUPPORTED; }
+    if (p->enable_virtual_canvas && !p->crop_n_zoom) {
+        // temporalBufferSize < 0 never trims in the reference (size_t compare, Stabilizer.cpp:2159); a blend weight outside
+        // [0, 1] leaves the range of the uchar cast of :2392-2396
+        if (p->temporal_buffer_size < 0 || p->temporal_buffer_size > 256) { *why = "temporalBufferSize must be in [0,256]"; return VS_ERR_INVALID_ARG; }
+        if (!(p->canvas_blend_weight >= 0.0f && p->canvas_blend_weight <= 1.0f)) { *why = "canvasBlendWeight must be in [0,1]"; return VS_ERR_UNSUPPORTED; }
+        if (!(p->canvas_scale_factor > 0.0f && p->canvas_scale_factor <= 16.0f) || !(p->min_canvas_scale > 0.0f) || !(p->max_canvas_scale <= 16.0f)) {
+            *why = "canvas scale factors must be in (0,16]"; return VS_ERR_INVALID_ARG;
+        }
+    }
     if (p->max_corners < 1 || p->max_corners > 4096) { *why = "maxCorners must be in [1,4096]"; return VS_ERR_INVALID_ARG; }
     if (p->block_size < 1 || p->block_size > 7) { *why = "blockSize must be in [1,7]"; return VS_ERR_INVALID_ARG; }
     if (p->lk_win_size < 3 || p->lk_win_size > 31 || p->lk_max_level < 0 || p->lk_max_level > 7) { *why = "LK window/levels out of range"; return VS_ERR_INVALID_ARG; }
@@ -1283,6 +1307,8 @@ void vs_stab_destroy(vs_stab* s) {
     if (s->st_warp) (void)hipStreamSynchronize(s->st_warp);
     free_all(s);
     if (s->d_fade) (void)hipFree(s->d_fade);
+    if (s->d_ct) (void)hipFree(s->d_ct);
+    canvas_delete(s->canvas);
     for (auto& pe : s->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     destroy_events(s);
@@ -1526,6 +1552,12 @@ int vs_stab_get_counters(vs_stab* s, vs_counters* out) {
         out->last_candidates = c[0];
         out->gftt_overflow = c[2];
     }
+    return VS_OK;
+}
+
+int vs_stab_canvas_info(const vs_stab* s, int32_t info[8]) {
+    if (!s || !info) return VS_ERR_INVALID_ARG;
+    canvas_info(s->canvas, info);
     return VS_OK;
 }
 

@@ -235,7 +235,10 @@ __device__ __forceinline__ void traj_emit_wave0(TrajState* s, const TrajParams& 
     if (p.horizon_lock) da = 0.0f;                   // :897-899
     const float r4[4] = {dx, dy, da, 1.f};
     if (DEFER) { for (int c = 0; c < 4; c++) t3[c] = r4[c]; }
-    else traj_matrix_lane(r4, M_out, Minv_out, dbg);
+    else {
+        traj_matrix_lane(r4, M_out, Minv_out, dbg);
+        if (t3) for (int c = 0; c < 3; c++) t3[c] = r4[c];       // the correction itself, for the virtual canvas
+    }
 }
 
 // magnitude / direction of transform istart + lane, for the intent analysis (lanes 0..14 of wave 0)
@@ -260,7 +263,7 @@ __device__ __forceinline__ void traj_emit_lds_wave0(TrajState* s, const TrajPara
 }
 
 __device__ __forceinline__ void traj_emit_device(TrajState* s, const TrajParams& p, int idx, float* __restrict__ M_out,
-                                                 double* __restrict__ Minv_out, vs_debug_frame* dbg) {
+                                                 double* __restrict__ Minv_out, vs_debug_frame* dbg, float* t_out = nullptr) {
     // The history rings are mirrored into LDS by all lanes and the per-sample transcendental work of
     // the intent analysis is spread over lanes.
     __shared__ float l_path[TRAJ_RING][3], l_tr[TRAJ_RING][3];
@@ -274,7 +277,7 @@ __device__ __forceinline__ void traj_emit_device(TrajState* s, const TrajParams&
     if (threadIdx.x < 64) {
         float mg, dr;
         traj_intent_samples(l_tr, idx, n, istart, mg, dr);
-        traj_emit_wave0<false>(s, p, idx, M_out, Minv_out, dbg, l_path, l_tr, mg, dr, n, istart, nullptr);
+        traj_emit_wave0<false>(s, p, idx, M_out, Minv_out, dbg, l_path, l_tr, mg, dr, n, istart, t_out);
     }
 }
 

@@ -48,6 +48,13 @@ vs_params_c to_c(const Stabilizer::Parameters &p) {
     c.fade_alpha = p.fadeAlpha;
     c.fade_duration = p.fadeDuration;
     c.enable_virtual_canvas = p.enableVirtualCanvas;
+    c.canvas_scale_factor = p.canvasScaleFactor;
+    c.temporal_buffer_size = p.temporalBufferSize;
+    c.canvas_blend_weight = p.canvasBlendWeight;
+    c.adaptive_canvas_size = p.adaptiveCanvasSize;
+    c.max_canvas_scale = p.maxCanvasScale;
+    c.min_canvas_scale = p.minCanvasScale;
+    c.edge_blend_radius = p.edgeBlendRadius;
     c.drone_high_freq_mode = p.droneHighFreqMode;
     c.hf_shake_px = p.hfShakePx;
     c.hf_analysis_max_width = p.hfAnalysisMaxWidth;

@@ -37,7 +37,9 @@ class VsParams(C.Structure):
         ("hf_freeze_duration", C.c_int32), ("hf_motion_accumulator_decay", C.c_float),
         ("lk_win_size", C.c_int32), ("lk_max_level", C.c_int32), ("lk_max_iters", C.c_int32),
         ("lk_epsilon", C.c_double), ("ransac_max_iters", C.c_int32), ("ransac_threshold", C.c_double),
-        ("reserved", C.c_int32 * 8),
+        ("canvas_scale_factor", C.c_float), ("temporal_buffer_size", C.c_int32), ("canvas_blend_weight", C.c_float),
+        ("adaptive_canvas_size", C.c_int32), ("max_canvas_scale", C.c_float), ("min_canvas_scale", C.c_float),
+        ("edge_blend_radius", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -185,6 +187,7 @@ class VsLib:
         L.vs_stab_last_out_dims.argtypes = [vp, i32p, i32p]
         L.vs_stab_get_counters.argtypes = [vp, C.POINTER(VsCounters)]
         L.vs_stab_get_debug.argtypes = [vp, C.POINTER(VsDebugFrame)]
+        L.vs_stab_canvas_info.argtypes = [vp, i32p]
         L.vs_stab_get_debug_arrays.argtypes = [vp, f32p, f32p, u8p, u8p, f32p, u8p, i32p, i32p]
         L.vs_stab_last_error.restype = C.c_char_p
         L.vs_stab_last_error.argtypes = [vp]
@@ -248,6 +251,7 @@ class VsLib:
         L.vs_azc_get_info.argtypes = [vp, i32p]
         L.vs_op_content_mask.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.vs_azc_crop_from_mask.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i32p, u8p]
+        L.vs_op_external_boxes.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i32p, C.c_int, i32p]
         cp = C.c_char_p
         L.vs_config_open.argtypes = [cp, C.POINTER(vp)]
         L.vs_config_parse.argtypes = [cp, C.c_size_t, C.POINTER(vp)]
@@ -468,6 +472,16 @@ class VsLib:
         self.check(self.lib.vs_azc_crop_from_mask(_p(mask, u8p), w, h, w, _p(info, i32p),
                                                   _p(filled, u8p) if want_filled else None))
         return (info, filled) if want_filled else info
+
+    def external_boxes(self, mask):
+        """Bounding rectangles (x, y, w, h) of the external contours of a host mask, in cv::findContours order."""
+        mask = np.ascontiguousarray(mask)
+        h, w = mask.shape
+        cap = w * h // 2 + 4
+        xywh = np.zeros((cap, 4), np.int32)
+        n = C.c_int32()
+        self.check(self.lib.vs_op_external_boxes(_p(mask, u8p), w, h, w, _p(xywh, i32p), cap, C.byref(n)))
+        return xywh[:n.value].copy()
 
     def auto_zoom_crop(self, device=0):
         return AutoZoomCrop(self, device)
@@ -856,6 +870,11 @@ class Stabilizer:
         d = VsDebugFrame()
         self.vs.check(self.lib.vs_stab_get_debug(self.h, C.byref(d)), self.h)
         return d
+
+    def canvas_info(self):
+        info = np.zeros(8, np.int32)
+        self.vs.check(self.lib.vs_stab_canvas_info(self.h, info.ctypes.data_as(C.POINTER(C.c_int32))), self.h)
+        return info
 
     def debug_arrays(self):
         d = self.debug()
