@@ -23,13 +23,16 @@ static void min_eigen(const uint8_t* g, int w, int h, size_t stride, int bs, flo
     std::vector<float> cov((size_t)w * h * 3);
     // horizontal intermediates per source row (reflect applies to the source image)
     std::vector<float> rdx((size_t)w * h), tdy((size_t)w * h);
-    for (int y = 0; y < h; y++)
+    parallel_rows(h, [&](int ya, int yb) {
+    for (int y = ya; y < yb; y++)
         for (int x = 0; x < w; x++) {
             int a = px(y, x - 1), c = px(y, x), b = px(y, x + 1);
             rdx[(size_t)y * w + x] = (float)(b - a);
             tdy[(size_t)y * w + x] = (float)c * f0 + (float)(a + b) * f1;
         }
-    for (int y = 0; y < h; y++) {
+    });
+    parallel_rows(h, [&](int ya, int yb) {
+    for (int y = ya; y < yb; y++) {
         int y0 = R(y - 1, h), y2 = R(y + 1, h);
         for (int x = 0; x < w; x++) {
             float r0 = rdx[(size_t)y0 * w + x], r1 = rdx[(size_t)y * w + x], r2 = rdx[(size_t)y2 * w + x];
@@ -41,8 +44,10 @@ static void min_eigen(const uint8_t* g, int w, int h, size_t stride, int bs, flo
             cv[2] = dy * dy;
         }
     }
+    });
     int anchor = bs / 2;
-    for (int y = 0; y < h; y++)
+    parallel_rows(h, [&](int ya, int yb) {
+    for (int y = ya; y < yb; y++)
         for (int x = 0; x < w; x++) {
             double s[3] = {0, 0, 0};
             for (int j = 0; j < bs; j++) {
@@ -61,6 +66,7 @@ static void min_eigen(const uint8_t* g, int w, int h, size_t stride, int bs, flo
             float d = (a - c) * (a - c) + b * b;
             eig[(size_t)y * w + x] = (a + c) - std::sqrt(d);
         }
+    });
 }
 
 int gftt(const uint8_t* gray, int w, int h, size_t stride, int max_corners, double quality,

@@ -86,10 +86,11 @@ void resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride, int cn
         ibeta[dy * 2] = sat_short(cv_round((1.f - fy) * SCALE));
         ibeta[dy * 2 + 1] = sat_short(cv_round(fy * SCALE));
     }
+    parallel_rows(dh, [&](int ya, int yb) {
     std::vector<int> rows[2];
     rows[0].resize((size_t)dw * cn);
     rows[1].resize((size_t)dw * cn);
-    for (int dy = 0; dy < dh; dy++) {
+    for (int dy = ya; dy < yb; dy++) {
         for (int k = 0; k < 2; k++) {
             int sy = yofs[dy] + k;
             sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;  // clip()
@@ -112,6 +113,7 @@ void resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride, int cn
         for (int x = 0; x < dw * cn; x++)
             d[x] = (uint8_t)((((b0 * (S0[x] >> 4)) >> 16) + ((b1 * (S1[x] >> 4)) >> 16) + 2) >> 2);
     }
+    });
 }
 
 // cv::cvtColor BGR2GRAY 8U: (B*3735 + G*19235 + R*9798 + 2^14) >> 15

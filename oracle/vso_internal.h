@@ -6,6 +6,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "vso.h"
@@ -86,6 +87,22 @@ void canvas_apply(CanvasState* c, const vs_params_c& p, const uint8_t* frame, in
 void canvas_info(const CanvasState* c, int32_t info[8]);
 
 extern int g_threads;
+
+// fn(y0, y1) over [0, n) in g_threads contiguous pieces (the pieces are independent: the result does not depend on
+// the number of threads)
+template <class F>
+static inline void parallel_rows(int n, F fn) {
+    const int nt = g_threads < 1 ? 1 : (g_threads > n ? (n > 0 ? n : 1) : g_threads);
+    if (nt <= 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const int per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) {
+        const int y0 = t * per, y1 = y0 + per < n ? y0 + per : n;
+        if (y0 >= y1) break;
+        th.emplace_back([=] { fn(y0, y1); });
+    }
+    for (auto& t : th) t.join();
+}
 
 }  // namespace vso
 #endif

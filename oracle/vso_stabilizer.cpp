@@ -423,11 +423,16 @@ void vso_stab_get_debug(const vso_stab* s, vs_debug_frame* d) { *d = s->dbg; }
 
 int vso_stab_get_debug_arrays(const vso_stab* s, float* prev_pts, float* curr_pts, uint8_t* status,
                               uint8_t* inliers, float* detected_pts, uint8_t* gray, int* aw, int* ah) {
-    if (prev_pts) std::copy(s->dbgPrev.begin(), s->dbgPrev.end(), prev_pts);
-    if (curr_pts) std::copy(s->dbgCurr.begin(), s->dbgCurr.end(), curr_pts);
-    if (status) std::copy(s->dbgStatus.begin(), s->dbgStatus.end(), status);
-    if (inliers) std::copy(s->dbgInliers.begin(), s->dbgInliers.end(), inliers);
-    if (detected_pts) std::copy(s->dbgDetected.begin(), s->dbgDetected.end(), detected_pts);
+    // The caller sizes its buffers by the counts of vso_stab_get_debug(): never more than that is written, whatever the
+    // vectors hold (round 1 lost a GPU run to a stale dbgDetected copied over a 2-float numpy array: heap overflow in
+    // the test process, SIGSEGV in the next library call).
+    const vs_debug_frame& d = s->dbg;
+    auto bounded = [](const auto& v, size_t cap, auto* out) { std::copy(v.begin(), v.begin() + std::min(v.size(), cap), out); };
+    if (prev_pts) bounded(s->dbgPrev, (size_t)std::max(d.n_prev, 0) * 2, prev_pts);
+    if (curr_pts) bounded(s->dbgCurr, (size_t)std::max(d.n_prev, 0) * 2, curr_pts);
+    if (status) bounded(s->dbgStatus, (size_t)std::max(d.n_prev, 0), status);
+    if (inliers) bounded(s->dbgInliers, (size_t)std::max(d.n_valid, 0), inliers);
+    if (detected_pts) bounded(s->dbgDetected, (size_t)std::max(d.n_detected, 0) * 2, detected_pts);
     if (gray) std::copy(s->dbgGray.d.begin(), s->dbgGray.d.end(), gray);
     if (aw) *aw = s->dbgGray.w;
     if (ah) *ah = s->dbgGray.h;

@@ -218,6 +218,30 @@ def test_pyr_lk_large_motion_restages_the_search_region(gpu, oracle, grays, shif
     assert moved.size and np.median(moved) > 6                       # the case is what it claims to be
 
 
+def test_pyr_lk_points_whose_fourth_bilinear_weight_is_minus_one(gpu, oracle, grays):
+    """The window weights are round(.. * 2^14) for three corners and the remainder for the fourth, which is -1 for about
+    one sub-pixel offset in 80 000 (three round-ups): the tracker's 24-bit multiplies must be the signed ones.  (Round-1
+    crash record gpu6.log, 142 of 143 tracked: an unsigned 24-bit multiply took the -1 for 2^24 - 1 in one iteration of
+    one point.)  Every point here starts on such an offset, so its template patch is built with w11 = -1."""
+    g0, g1 = grays[0], grays[1]
+    f = np.float32
+    rng = np.random.default_rng(7)
+    pts = []
+    while len(pts) < 64:
+        x = (rng.integers(40, g0.shape[1] - 40, 200000).astype(f) + (rng.random(200000) * 0.02).astype(f)).astype(f)
+        y = (rng.integers(40, g0.shape[0] - 40, 200000).astype(f) + (rng.random(200000) * 0.02).astype(f)).astype(f)
+        a, b = x - np.floor(x), y - np.floor(y)          # halfWin is an integer: the window's offset is the point's
+        w00 = np.rint((f(1) - a) * (f(1) - b) * f(16384)); w01 = np.rint(a * (f(1) - b) * f(16384)); w10 = np.rint((f(1) - a) * b * f(16384))
+        for i in np.nonzero(16384 - w00 - w01 - w10 < 0)[0]:
+            pts.append((x[i], y[i]))
+    pts = np.array(pts[:64], f)
+    no, so, eo = oracle.pyr_lk(g0, g1, pts, 15, 2, 20, 0.03)
+    ng, sg, eg = gpu.pyr_lk(g0, g1, pts, 15, 2, 20, 0.03)
+    assert np.array_equal(sg, so) and so.sum() > 8
+    assert np.array_equal(ng.view(np.uint32), no.view(np.uint32))
+    assert np.array_equal(eg.view(np.uint32), eo.view(np.uint32))
+
+
 # ---- R1 RANSAC ------------------------------------------------------------------------
 def _correspondences(seed, n, n_out, noise=0.2):
     rng = np.random.default_rng(seed)

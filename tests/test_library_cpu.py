@@ -62,6 +62,14 @@ def test_bad_params_rejected_before_touching_the_gpu(vs):
     assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 1
     p = vs.params(enable_virtual_canvas=1, temporal_buffer_size=-1, crop_n_zoom=1)   # never reached behind crop-and-zoom
     assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) != 1
+    p = vs.params(smoothing_method=capi.SMOOTH_GAUSSIAN, gaussian_sigma=10.6)     # 65 taps: more than the device kernel holds
+    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 4
+    p = vs.params(smoothing_method=capi.SMOOTH_GAUSSIAN, gaussian_sigma=0.0)
+    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 1
+    p = vs.params(smoothing_method=capi.SMOOTH_GAUSSIAN, gaussian_sigma=10.4)     # 63 taps
+    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) not in (1, 4)
+    p = vs.params(gaussian_sigma=50.0)                                            # not read by box smoothing
+    assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) not in (1, 4)
     p = vs.params(border_type=capi.BORDER_FADE + 1, border_size=8)
     assert vs.lib.vs_stab_create(C.byref(p), 0, C.byref(h)) == 1
 

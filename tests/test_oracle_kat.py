@@ -277,3 +277,57 @@ def test_stabilizer_static_clip_is_identity(oracle):
     assert [i for i, _ in outs] == list(range(8))
     for i, o in outs[1:]:
         assert np.array_equal(o, f), i
+
+
+def test_debug_arrays_never_write_past_the_counts_they_report(oracle):
+    """Round-1 crash record gpu2.log: the oracle copied a stale list of detected points (200 of them, kept from the
+    frame before) into the 2-float array the test had sized by n_detected = 0 - a heap overflow in the test process that
+    surfaced as SIGSEGV inside the NEXT call, vs_stab_push.  The copies are bounded by the reported counts now; this
+    walks a clip that alternates detecting and non-detecting frames with canaries behind every buffer."""
+    import ctypes as C
+    from vsamd import synth
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 21, 320, 240, 8)
+    so = oracle.stabilizer(oracle.params(smoothing_radius=5))
+    seen_quiet_frame = False
+    for f in clip:
+        so.push(f)
+        d = so.debug()
+        sizes = dict(prev=d.n_prev * 2, cur=d.n_prev * 2, det=d.n_detected * 2)
+        bufs = {k: np.full(n + 4096, np.float32(-7.0), np.float32) for k, n in sizes.items()}
+        st = np.full(d.n_prev + 4096, 0xAB, np.uint8)
+        inl = np.full(d.n_valid + 4096, 0xAB, np.uint8)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        bp = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+        oracle.lib.vso_stab_get_debug_arrays(so.h, fp(bufs["prev"]), fp(bufs["cur"]), bp(st), bp(inl), fp(bufs["det"]), None, None, None)
+        for k, n in sizes.items():
+            assert (bufs[k][n:] == np.float32(-7.0)).all(), k
+        assert (st[d.n_prev:] == 0xAB).all() and (inl[d.n_valid:] == 0xAB).all()
+        seen_quiet_frame |= d.n_detected == 0 and d.n_prev > 0
+    assert seen_quiet_frame
+    so.close()
+
+
+def test_threaded_stages_do_not_depend_on_the_thread_count(oracle):
+    """vso_set_threads spreads rows / points over threads (resize, min-eigenvalue map, LK, warp): same bits as one thread."""
+    from vsamd import synth
+    f0, f1 = synth.make_clip(synth.SEED_CONFIG1 + 22, 331, 247, 2)
+
+    def everything():
+        small = oracle.resize(f0, 223, 131)
+        g0, g1 = oracle.bgr2gray(f0), oracle.bgr2gray(f1)
+        pts, nc = oracle.gftt(g0, 120, 0.02, 9.0, 3)
+        nxt, st, err = oracle.pyr_lk(g0, g1, pts, 15, 2, 20, 0.03)
+        so = oracle.stabilizer(oracle.params(smoothing_radius=5))
+        outs = [so.push(f) for f in (f0, f1, f0, f1, f0, f1)]
+        so.close()
+        return [small, pts, np.int64(nc), nxt, st, err] + [o for o in outs if o is not None]
+
+    one = everything()
+    try:
+        oracle.lib.vso_set_threads(5)
+        many = everything()
+    finally:
+        oracle.lib.vso_set_threads(1)
+    assert len(one) == len(many) > 6
+    for a, b in zip(one, many):
+        assert np.array_equal(a, b)

@@ -182,6 +182,17 @@ def test_hough_empty_edges(gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_hough_resolution_out_of_range_is_an_error_not_a_crash(gpu):
+    """hough_rho / hough_theta come from config.yaml: values that would overflow the accumulator geometry are refused."""
+    from vsamd import capi
+    e = np.zeros((64, 64), np.uint8)
+    for rho, theta in ((1.0, 1e-12), (1e-9, THETA), (1.0, -1.0), (0.0, THETA), (1.0, float("nan"))):
+        with pytest.raises(capi.VsError):
+            gpu.hough_lines(e, rho, theta, 10)
+    assert len(gpu.hough_lines(e, 1.0, THETA, 10)) == 0          # the library is still usable
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("deg", [0.0, 0.7, -2.3, 9.5, 45.0])
 def test_warp_replicate_bit_exact(gpu, oracle, deg):
     rng = np.random.default_rng(11)

@@ -424,6 +424,11 @@ static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hi
     if (k.base && k.w == w && k.h == h && k.rho == rho && k.theta == theta) return VS_OK;
     roll_work_free(k);
     if (!(rho > 0) || !(theta > 0)) { set_last_error("hough: rho and theta must be positive"); return VS_ERR_INVALID_ARG; }
+    // the accumulator has (pi / theta) x (2 (w + h) / rho) cells: bounded before the int casts of hough_geom can overflow
+    if (!(3.1415926535897932 / (double)theta <= 4096.0) || !((2.0 * (w + h) + 1.0) / (double)rho <= 65536.0)) {
+        set_last_error("hough: theta / rho too fine (more than 4096 angles or 65536 distance bins)");
+        return VS_ERR_INVALID_ARG;
+    }
     k.w = w; k.h = h; k.mw = w + 2; k.wpr = (w + 63) / 64; k.rho = rho; k.theta = theta;
     k.geom = hough_geom(w, h, rho, theta);
     const size_t npx = (size_t)w * h, nfr = (size_t)(w + 2) * (h + 2);

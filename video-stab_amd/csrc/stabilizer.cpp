@@ -353,7 +353,19 @@ void analysis_size(const vs_stab* s, int w, int h, int* aw, int* ah) {
     }
 }
 
+int allocate_buffers(vs_stab* s, int w, int h, int fmt);
+
+// A failure half way leaves nothing behind: the next push starts from scratch instead of overwriting live pointers.
 int allocate(vs_stab* s, int w, int h, int fmt) {
+    const int rc = allocate_buffers(s, w, h, fmt);
+    if (rc != VS_OK) {
+        if (s->st) (void)hipStreamSynchronize(s->st);
+        free_all(s);
+    }
+    return rc;
+}
+
+int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     s->w = w; s->h = h; s->fmt = fmt;
     s->cn = fmt == VS_FMT_BGR8 ? 3 : 1;
     s->rows_total = fmt == VS_FMT_NV12 ? h * 3 / 2 : h;
@@ -389,7 +401,8 @@ int allocate(vs_stab* s, int w, int h, int fmt) {
     s->items.assign(B, vs_stab::ItemBufs());
     s->bq.clear(); s->batch_id = 0; s->kp_cur = 0; s->kp_next = 1; s->last_det_batch = -1; s->ready.valid = false; s->last_warp_set = -1;
     for (auto& v : s->bdet_valid) v = false;
-    S_HIP(s, hipMalloc((void**)&s->d_ring, s->frame_bytes * FRAME_RING));
+    // (the frame queue ring - 128 frames, 3.2 GB at 4K BGR8 - is allocated by the first push that copies a frame in: a
+    // stream that only ever hands over device frames in zero-copy mode never needs it)
     s->free_slots.clear();
     for (int i = 0; i < FRAME_RING; i++) { s->free_slots.push_back(i); s->slot_valid[i] = false; }
     s->ncap = std::max(s->p.max_corners, 1);
@@ -1097,6 +1110,15 @@ int check_params(const vs_params_c* p, std::string* why) {
     if (p->ransac_max_iters < 1 || p->ransac_max_iters > 4096) { *why = "ransac_max_iters out of range"; return VS_ERR_INVALID_ARG; }
     if (p->border_size < 0 || p->border_type < 0 || p->border_type > VS_BORDER_FADE) { *why = "border parameters out of range"; return VS_ERR_INVALID_ARG; }
     if (p->smoothing_method < 0 || p->smoothing_method > VS_SMOOTH_KALMAN) { *why = "smoothing_method out of range"; return VS_ERR_INVALID_ARG; }
+    if (p->smoothing_method == VS_SMOOTH_GAUSSIAN) {
+        // gaussianFilterConvolve's kernel has max(3, ceil(6 sigma)) taps (Stabilizer.cpp:1368-1370); the device evaluates one
+        // tap per lane of a wave, at most GAUSS_MAX: a wider kernel would be cut short without a word
+        const float sigma = (float)p->gaussian_sigma;
+        if (!(sigma > 0.0f)) { *why = "gaussianSigma must be positive"; return VS_ERR_INVALID_ARG; }
+        int ks = std::max(3, (int)std::ceil(6 * sigma));
+        if (ks % 2 == 0) ks++;
+        if (!(sigma <= 1e6f) || ks > GAUSS_MAX) { *why = "gaussianSigma above 10.5 (a smoothing kernel of more than 63 taps) is outside the accelerated path"; return VS_ERR_UNSUPPORTED; }
+    }
     return VS_OK;
 }
 
@@ -1150,6 +1172,7 @@ int push_common(vs_stab* s, int slot, const uint8_t* zc_frame, uint8_t* d_out, s
 }
 
 int take_slot(vs_stab* s, int* slot) {
+    if (!s->d_ring) S_HIP(s, hipMalloc((void**)&s->d_ring, s->frame_bytes * FRAME_RING));
     if (s->free_slots.empty()) return fail(s, VS_ERR_CAPACITY, "frame ring exhausted");
     *slot = s->free_slots.front();
     s->free_slots.pop_front();
