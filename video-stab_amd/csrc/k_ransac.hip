@@ -242,11 +242,6 @@ __device__ __forceinline__ void ransac_score(const RansacArgs& a, const int k) {
 
 __global__ __launch_bounds__(64) void ransac_score_kernel(RansacArgs a) { ransac_score(a, blockIdx.x); }
 
-// Several frames per launch: blockIdx.y selects the frame's argument block in a device table.
-__global__ __launch_bounds__(64) void ransac_score_batch_kernel(const RansacArgs* __restrict__ table) {
-    ransac_score(table[blockIdx.y], blockIdx.x);
-}
-
 __device__ __forceinline__ double wave_butterfly_sum(double v) {
     // fixed combine order (mirrored by oracle/vso_ransac.cpp): s[l] += s[l ^ off], off = 32..1
 #pragma unroll
@@ -365,6 +360,20 @@ __device__ __forceinline__ void ransac_select(const RansacArgs& a, const bool wr
 
 __global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) { ransac_select<false>(a); }
 
+// Several frames per launch: blockIdx.y selects the frame's argument block in a device table, blockIdx.x the hypothesis.
+__global__ __launch_bounds__(64) void ransac_score_batch_kernel(const RansacArgs* __restrict__ table) {
+    ransac_score(table[blockIdx.y], blockIdx.x);
+}
+
+// The selections of a batch, one wave (workgroup) per frame, launched right behind the scoring: they do not depend on
+// each other, so they do not belong into the one-workgroup tail (where they took two rounds of sixteen waves on one CU).
+// (Tried first: the scoring workgroup that finishes a frame last selects for it - a counter per frame and a device-scope
+// fence per workgroup.  16 000 L2 write-backs per launch: the scoring launch went from 20 to 320 us and dragged the
+// kernels beside it along.)
+__global__ __launch_bounds__(64) void ransac_select_batch_kernel(const RansacArgs* __restrict__ table, int last_item) {
+    ransac_select<true>(table[blockIdx.x], (int)blockIdx.x == last_item);
+}
+
 // Ordered tail of a batch, ONE launch: for every frame in push order, hypothesis selection + trajectory append,
 // then - when that push produces an output - the map of the frame leaving the queue, which must see exactly
 // the transforms appended so far (Stabilizer.cpp:380-389).
@@ -400,13 +409,11 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     for (int i = tid; i < (int)(sizeof(TrajParams) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(&l_tp)[i] = reinterpret_cast<const uint32_t*>(&table[0].tp)[i];
     if (tid < 12) l_M[tid] = M_out[tid];
-    // phase 1: the selections do not depend on each other: wave i serves frame i
+    // phase 1: per-frame inputs of the ordered part: wave i serves frame i
     const int nwaves = blockDim.x >> 6;
+    // (the selections themselves ran behind the scoring launch, one workgroup per frame: ransac_select_batch_kernel)
     for (int f = wave; f < n; f += nwaves) {
         const RansacArgs& a = table[f];
-        ransac_select<true>(a, f == n - 1);
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
         if (lane < 6) l_model[f][lane] = a.model[lane];
         if (lane < 4) l_info[f][lane] = a.info[lane];
         if (lane == 0) {
@@ -551,6 +558,7 @@ int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_m
     }
     hipLaunchKernelGGL(ransac_score_batch_kernel, dim3(iters, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
                        static_cast<const RansacArgs*>(d_table));
+    hipLaunchKernelGGL(ransac_select_batch_kernel, dim3(items), dim3(64), 0, st, static_cast<const RansacArgs*>(d_table), items - 1);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

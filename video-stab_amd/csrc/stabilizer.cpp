@@ -217,9 +217,13 @@ struct vs_stab {
     std::vector<GfttWork> gws;                       // one GFTT scratch per detection of a batch
     struct ItemBufs { float *next, *err, *vp, *vc; uint8_t *status, *inliers; int32_t *m, *info, *counts; double* model; };
     std::vector<ItemBufs> items;
-    std::vector<uint8_t> h_lk, h_rs, h_gf, h_tail;   // host images of the argument tables
-    std::vector<ImgPair> h_pairs;                    // (source, destination) of the batched gray / pyramid launches
-    uint8_t *d_lk_table = nullptr, *d_rs_table = nullptr, *d_gf_table = nullptr, *d_tail_table = nullptr;
+    // Host images of the argument tables of a batch, in page-locked memory so that their uploads are asynchronous (from
+    // pageable memory hipMemcpyAsync holds the host until the stream gets to the copy, and the host then no longer runs
+    // ahead of the GPU): four sets, batch k writes set k % 4 once the tail of batch k-4 has run.  On the device the tracker /
+    // scoring / tail tables exist twice (k & 1): batch k+1's are uploaded on `pre` while batch k's are still read on `main`.
+    uint8_t* h_tables = nullptr;                     // 4 x h_set_bytes
+    size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0;
+    uint8_t *d_lk_table[2] = {nullptr, nullptr}, *d_rs_table[2] = {nullptr, nullptr}, *d_gf_table = nullptr, *d_tail_table[2] = {nullptr, nullptr};
     ImgPair* d_pairs = nullptr;
     hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
     bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
@@ -333,6 +337,8 @@ void free_all(vs_stab* s) {
     if (s->d_tmp) (void)hipFree(s->d_tmp);
     if (s->d_padB) (void)hipFree(s->d_padB);
     s->d_padB = nullptr;
+    if (s->h_tables) (void)hipHostFree(s->h_tables);
+    s->h_tables = nullptr;
     // (d_fade, the fade history, outlives vs_stab_clean like borderHistory_ outlives Stabilizer::clean())
     if (s->d_out) (void)hipFree(s->d_out);
     for (auto& h : s->d_hold) { if (h) (void)hipFree(h); h = nullptr; }
@@ -428,8 +434,10 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
         o_it[k].m = take(16); o_it[k].info = take(16); o_it[k].counts = take((size_t)s->p.ransac_max_iters * 4);
         o_it[k].model = take(48);
     }
-    const size_t o_lkt = take(lk_item_bytes() * B), o_rst = take(ransac_item_bytes() * B), o_gft = take(gftt_item_bytes() * ngw);
-    const size_t o_tail = take(tail_item_bytes() * B);
+    const size_t o_gft = take(gftt_item_bytes() * ngw);
+    const size_t o_lkt[2] = {take(lk_item_bytes() * B), take(lk_item_bytes() * B)};
+    const size_t o_rst[2] = {take(ransac_item_bytes() * B), take(ransac_item_bytes() * B)};
+    const size_t o_tail[2] = {take(tail_item_bytes() * B), take(tail_item_bytes() * B)};
     const size_t o_pairs = take(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
     size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
     size_t o_MinvB[2] = {take((size_t)BATCH_MAX * 96), take((size_t)BATCH_MAX * 96)};
@@ -460,11 +468,19 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     s->d_next = s->items[0].next; s->d_err = s->items[0].err; s->d_vp = s->items[0].vp; s->d_vc = s->items[0].vc;
     s->d_status = s->items[0].status; s->d_inliers = s->items[0].inliers;
     s->d_m = s->items[0].m; s->d_info = s->items[0].info; s->d_counts = s->items[0].counts; s->d_model = s->items[0].model;
-    s->d_lk_table = b + o_lkt; s->d_rs_table = b + o_rst; s->d_gf_table = b + o_gft; s->d_tail_table = b + o_tail;
-    s->h_tail.assign(tail_item_bytes() * B, 0);
+    s->d_gf_table = b + o_gft;
+    for (int i = 0; i < 2; i++) { s->d_lk_table[i] = b + o_lkt[i]; s->d_rs_table[i] = b + o_rst[i]; s->d_tail_table[i] = b + o_tail[i]; }
     s->d_pairs = (ImgPair*)(b + o_pairs);
-    s->h_pairs.assign((size_t)B * (2 + 2 * MAX_PYR), ImgPair{nullptr, nullptr});
-    s->h_lk.assign(lk_item_bytes() * B, 0); s->h_rs.assign(ransac_item_bytes() * B, 0); s->h_gf.assign(gftt_item_bytes() * ngw, 0);
+    {
+        size_t ho = 0;
+        auto htake = [&](size_t bytes) { size_t o = ho; ho += (bytes + 255) & ~(size_t)255; return o; };
+        s->ho_pairs = htake(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
+        s->ho_lk = htake(lk_item_bytes() * B); s->ho_rs = htake(ransac_item_bytes() * B);
+        s->ho_tail = htake(tail_item_bytes() * B); s->ho_gf = htake(gftt_item_bytes() * ngw);
+        s->h_set_bytes = ho;
+        S_HIP(s, hipHostMalloc((void**)&s->h_tables, 4 * ho));
+        memset(s->h_tables, 0, 4 * ho);
+    }
     s->d_traj = (TrajState*)(b + o_traj);
     s->d_M = (float*)(b + o_M); s->d_Minv = (double*)(b + o_Minv); s->d_dbg = (vs_debug_frame*)(b + o_dbg);
     s->d_MinvB[0] = (double*)(b + o_MinvB[0]); s->d_MinvB[1] = (double*)(b + o_MinvB[1]);
@@ -924,6 +940,13 @@ int run_batch(vs_stab* s) {
     if (n == 0) return VS_OK;
     const vs_params_c& p = s->p;
     const int k = s->batch_id++;
+    // host images of this batch's tables: the set batch k-4 used (its tail, the last reader of anything uploaded from it, has run
+    // by now unless the host is four batches ahead of the GPU - then it waits here)
+    if (k >= 4) S_HIP(s, hipEventSynchronize(s->ev_blk[k % 4]));
+    uint8_t* hset = s->h_tables + (size_t)(k % 4) * s->h_set_bytes;
+    ImgPair* h_pairs = reinterpret_cast<ImgPair*>(hset + s->ho_pairs);
+    uint8_t *h_lk = hset + s->ho_lk, *h_rs = hset + s->ho_rs, *h_tail = hset + s->ho_tail, *h_gf = hset + s->ho_gf;
+    const int dset = k & 1;
     // ---- pre: gray images and pyramids of all frames of the batch, one launch per stage and level
     if (k >= 2) {
         // ring reuse: these slots were read by the analysis two batches ago (npyr = 2*batch + 2)
@@ -935,6 +958,45 @@ int run_batch(vs_stab* s) {
         // pyramid / detection kernels start after the warps issued during the previous run_batch (batch k-2's)
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_warp[s->last_warp_set], 0));
     }
+    // ---- argument tables of the tracker, the scoring and the tail: they do not depend on this batch's images.  Uploaded on
+    // `main`, where they run while `main` waits for this batch's pyramids anyway (on `pre` they sat in front of the gray
+    // stage, on the detector's critical path); the device copies alternate because `main` may still be in the batch before.
+    int n_max = 0;
+    for (int i = 0; i < n; i++) {
+        const vs_stab::BFrame& b = s->bq[i];
+        const vs_stab::ItemBufs& it = s->items[i];
+        LKLevel L[MAX_PYR];
+        for (int l = 0; l <= s->levels; l++) {
+            L[l].prev = s->pyr[b.pv].img[l]; L[l].next = s->pyr[b.c].img[l]; L[l].deriv = s->pyr[b.pv].der[l];
+            L[l].w = s->lw[l]; L[l].h = s->lh[l]; L[l].stride = s->lw[l];
+        }
+        const int cap = std::max(b.lk_cap, 0);
+        n_max = std::max(n_max, cap);
+        S_TRY(s, lk_fill_item(h_lk + lk_item_bytes() * i, L, s->levels, s->d_pts[b.lk_buf], cap, s->d_npts[b.lk_buf],
+                              it.next, it.status, it.err, p.lk_win_size, p.lk_max_iters, p.lk_epsilon));   // :611-619
+        S_TRY(s, ransac_fill_item(h_rs + ransac_item_bytes() * i, s->d_pts[b.lk_buf], it.next, it.status, cap,
+                                  s->d_npts[b.lk_buf], it.vp, it.vc, it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab,
+                                  it.counts, it.model, it.inliers, it.info, s->d_traj, &s->tp, s->d_dbg, b.have_prev_gray));
+    }
+    S_HIP(s, hipMemcpyAsync(s->d_lk_table[dset], h_lk, lk_item_bytes() * n, hipMemcpyHostToDevice, s->st));
+    S_HIP(s, hipMemcpyAsync(s->d_rs_table[dset], h_rs, ransac_item_bytes() * n, hipMemcpyHostToDevice, s->st));
+    // the tail's table as well (which outputs become due and where their maps go is known on the host)
+    S_TRY(s, flush_warps(s));                      // the list of pending warps starts empty
+    const int set = s->pend_set;
+    bool tail_any = false;
+    for (int i = 0; i < n; i++) tail_any |= s->bq[i].out_due;
+    for (int i = 0; i < n; i++) {
+        const vs_stab::BFrame& b = s->bq[i];
+        double* minv = nullptr;
+        if (b.out_due) {
+            if (!s->pend.empty() && s->pend_stride != b.out_stride) return fail(s, VS_ERR_INVALID_ARG, "batch mode: the output stride must not change within a batch");
+            minv = s->d_MinvB[set] + 12 * s->pend.size();
+            s->pend.push_back({b.out_frame, b.d_out, b.out_slot});
+            s->pend_stride = b.out_stride;
+        }
+        tail_fill_item(h_tail + tail_item_bytes() * i, b.out_due ? 1 : 0, b.out_idx, minv);
+    }
+    S_HIP(s, hipMemcpyAsync(s->d_tail_table[dset], h_tail, tail_item_bytes() * n, hipMemcpyHostToDevice, s->st));
     if (s->bq[0].prev_small) {   // :598-603 (once: 480x270 -> analysis size)
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
         S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[s->bq[0].pv].img[0], s->aw, s->aw, s->ah, s->st_pre));
@@ -953,12 +1015,12 @@ int run_batch(vs_stab* s) {
             const vs_stab::BFrame& b = s->bq[i];
             const Pyramid& P = s->pyr[b.c];
             const int slot = b.detect ? n_first++ : n_detect + n_rest++;
-            s->h_pairs[slot] = ImgPair{b.frame, P.img[0]};
+            h_pairs[slot] = ImgPair{b.frame, P.img[0]};
             if ((uintptr_t)b.frame % 8) aligned = 0;
-            for (int l = 1; l <= L; l++) s->h_pairs[(size_t)l * n + i] = ImgPair{P.img[l - 1], P.img[l]};
-            for (int l = 0; l <= L; l++) s->h_pairs[(size_t)(L + 1 + l) * n + i] = ImgPair{P.img[l], P.der[l]};
+            for (int l = 1; l <= L; l++) h_pairs[(size_t)l * n + i] = ImgPair{P.img[l - 1], P.img[l]};
+            for (int l = 0; l <= L; l++) h_pairs[(size_t)(L + 1 + l) * n + i] = ImgPair{P.img[l], P.der[l]};
         }
-        S_HIP(s, hipMemcpyAsync(s->d_pairs, s->h_pairs.data(), sizeof(ImgPair) * n * (2 * L + 2), hipMemcpyHostToDevice, s->st_pre));
+        S_HIP(s, hipMemcpyAsync(s->d_pairs, h_pairs, sizeof(ImgPair) * n * (2 * L + 2), hipMemcpyHostToDevice, s->st_pre));
         {
             StageScope t(s, VS_STAGE_GRAY, s->st_pre);
             // NV12: the Y plane is the gray image (no reference path; same policy as the per-frame pipeline)
@@ -981,7 +1043,7 @@ int run_batch(vs_stab* s) {
     for (int i = 0; i < n; i++) {
         const vs_stab::BFrame& b = s->bq[i];
         if (!b.detect) continue;
-        S_TRY(s, gftt_fill_item(s->h_gf.data() + gftt_item_bytes() * ndet, s->pyr[b.c].img[0], s->aw, s->aw, s->ah,
+        S_TRY(s, gftt_fill_item(h_gf + gftt_item_bytes() * ndet, s->pyr[b.c].img[0], s->aw, s->aw, s->ah,
                                 s->pts_cap[b.det_buf], 0.02, 15.0, 3, s->gws[ndet], s->d_pts[b.det_buf], s->d_npts[b.det_buf]));
         s->dbg_det_pts = s->d_pts[b.det_buf]; s->dbg_det_n = s->d_npts[b.det_buf];
         s->dbg_gftt_counters = s->gws[ndet].counters;
@@ -991,11 +1053,12 @@ int run_batch(vs_stab* s) {
     if (ndet > 0) {
         // starts as soon as the analysis images exist, next to the pyramid levels of this batch and the tracking of the
         // previous one (VS_STAB_DET_AFTER_PRE=1: after the whole pre stage, the schedule before this was measured)
+        // (the table first: it is on the device by the time the analysis images are)
+        S_HIP(s, hipMemcpyAsync(s->d_gf_table, h_gf, gftt_item_bytes() * ndet, hipMemcpyHostToDevice, s->st_det));
         S_HIP(s, hipStreamWaitEvent(s->st_det, std::getenv("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
         // keypoint buffers are recycled after B + 4 detections (two batches): the tracking of the batch before
         // the previous one must have read them (the GFTT scratch is only touched on this stream)
         if (k >= 2) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 2) % 4], 0));
-        S_HIP(s, hipMemcpyAsync(s->d_gf_table, s->h_gf.data(), gftt_item_bytes() * ndet, hipMemcpyHostToDevice, s->st_det));
         {
             StageScope t(s, VS_STAGE_GFTT, s->st_det);
             S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det));   // :740-744: block size 3
@@ -1006,43 +1069,6 @@ int run_batch(vs_stab* s) {
     s->bdet_valid[k % 4] = ndet > 0;
     // ---- main: tracking and hypothesis scoring of all frames, one launch each
     hipStream_t st = s->st;
-    // argument tables first: their upload does not depend on this batch's images and then runs while `main` would wait
-    int n_max = 0;
-    for (int i = 0; i < n; i++) {
-        const vs_stab::BFrame& b = s->bq[i];
-        const vs_stab::ItemBufs& it = s->items[i];
-        LKLevel L[MAX_PYR];
-        for (int l = 0; l <= s->levels; l++) {
-            L[l].prev = s->pyr[b.pv].img[l]; L[l].next = s->pyr[b.c].img[l]; L[l].deriv = s->pyr[b.pv].der[l];
-            L[l].w = s->lw[l]; L[l].h = s->lh[l]; L[l].stride = s->lw[l];
-        }
-        const int cap = std::max(b.lk_cap, 0);
-        n_max = std::max(n_max, cap);
-        S_TRY(s, lk_fill_item(s->h_lk.data() + lk_item_bytes() * i, L, s->levels, s->d_pts[b.lk_buf], cap, s->d_npts[b.lk_buf],
-                              it.next, it.status, it.err, p.lk_win_size, p.lk_max_iters, p.lk_epsilon));   // :611-619
-        S_TRY(s, ransac_fill_item(s->h_rs.data() + ransac_item_bytes() * i, s->d_pts[b.lk_buf], it.next, it.status, cap,
-                                  s->d_npts[b.lk_buf], it.vp, it.vc, it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab,
-                                  it.counts, it.model, it.inliers, it.info, s->d_traj, &s->tp, s->d_dbg, b.have_prev_gray));
-    }
-    S_HIP(s, hipMemcpyAsync(s->d_lk_table, s->h_lk.data(), lk_item_bytes() * n, hipMemcpyHostToDevice, st));
-    S_HIP(s, hipMemcpyAsync(s->d_rs_table, s->h_rs.data(), ransac_item_bytes() * n, hipMemcpyHostToDevice, st));
-    // the tail's table as well (which outputs become due and where their maps go is known on the host)
-    S_TRY(s, flush_warps(s));                      // the list of pending warps starts empty
-    const int set = s->pend_set;
-    bool tail_any = false;
-    for (int i = 0; i < n; i++) tail_any |= s->bq[i].out_due;
-    for (int i = 0; i < n; i++) {
-        const vs_stab::BFrame& b = s->bq[i];
-        double* minv = nullptr;
-        if (b.out_due) {
-            if (!s->pend.empty() && s->pend_stride != b.out_stride) return fail(s, VS_ERR_INVALID_ARG, "batch mode: the output stride must not change within a batch");
-            minv = s->d_MinvB[set] + 12 * s->pend.size();
-            s->pend.push_back({b.out_frame, b.d_out, b.out_slot});
-            s->pend_stride = b.out_stride;
-        }
-        tail_fill_item(s->h_tail.data() + tail_item_bytes() * i, b.out_due ? 1 : 0, b.out_idx, minv);
-    }
-    S_HIP(s, hipMemcpyAsync(s->d_tail_table, s->h_tail.data(), tail_item_bytes() * n, hipMemcpyHostToDevice, st));
     S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
     if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
     if (s->last_det_batch >= 0 && s->last_det_batch >= k - 1) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
@@ -1051,11 +1077,11 @@ int run_batch(vs_stab* s) {
     S_TRY(s, launch_ready(s));
     {
         StageScope t(s, VS_STAGE_LK, st);
-        S_TRY(s, launch_pyr_lk_batch(s->d_lk_table, n, n_max, p.lk_win_size, st));
+        S_TRY(s, launch_pyr_lk_batch(s->d_lk_table[dset], n, n_max, p.lk_win_size, st));
     }
     {
         StageScope t(s, VS_STAGE_RANSAC, st);
-        S_TRY(s, launch_ransac_score_batch(s->d_rs_table, n, p.ransac_max_iters, n_max, st));
+        S_TRY(s, launch_ransac_score_batch(s->d_rs_table[dset], n, p.ransac_max_iters, n_max, st));
     }
     if (s->dbg_delay_us > 0) S_TRY(s, launch_spin(s->dbg_delay_us, st));
     // ---- ordered tail, ONE launch: per frame in push order, selection + trajectory append (:644-693), then the
@@ -1068,7 +1094,7 @@ int run_batch(vs_stab* s) {
         }
         {
             StageScope t(s, VS_STAGE_TRAJ, st);
-            S_TRY(s, launch_ransac_tail_batch(s->d_rs_table, s->d_tail_table, n, s->d_M, st));
+            S_TRY(s, launch_ransac_tail_batch(s->d_rs_table[dset], s->d_tail_table[dset], n, s->d_M, st));
         }
         // the keypoint and pyramid buffers of this batch may be recycled (two batches on) once the tail, which still reads
         // the points and their counts, has run
