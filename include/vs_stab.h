@@ -350,6 +350,10 @@ int vs_op_pyr_down(const void* d_src, size_t src_stride, int sw, int sh,
 /* Scharr derivative image (int16, interleaved dx,dy) of calcOpticalFlowPyrLK */
 int vs_op_scharr(const void* d_src, size_t src_stride, int w, int h,
                  void* d_dst /* int16[h][w][2] */, void* stream);
+/* One pyramid level as batch mode builds it: the Scharr derivatives of `items` images (w x h, src_frame_bytes apart) and, when
+ * d_next != NULL, their pyrDown ((w+1)/2 x (h+1)/2, next_frame_bytes apart) from one staged read of each image. */
+int vs_op_pyr_level(const void* d_src, size_t src_stride, size_t src_frame_bytes, int w, int h, void* d_der /* int16[h][w][2] per image */,
+                    void* d_next, size_t next_stride, size_t next_frame_bytes, int items, void* stream);
 /* cv::calcOpticalFlowPyrLK(prev,next,prevPts,nextPts,status,err,win,maxLevel,
  * TermCriteria(COUNT+EPS,iters,eps)) - Stabilizer.cpp:611-619 */
 int vs_op_pyr_lk(const void* d_prev, const void* d_next, size_t stride, int w, int h,

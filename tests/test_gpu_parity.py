@@ -155,6 +155,19 @@ def test_pyr_down_and_scharr(gpu, oracle, shape):
     assert np.array_equal(gpu.scharr(g), oracle.scharr(g))
 
 
+@pytest.mark.parametrize("shape", [(540, 960), (270, 480), (135, 240), (19, 25), (75, 100), (1, 7), (3, 1), (97, 131), (16, 64), (17, 65), (33, 129)])
+def test_pyramid_level_kernel(gpu, oracle, shape):
+    """One launch per pyramid level (batch mode): derivatives and the next level from one staged tile - tiles inside the
+    image (dword loads), on every border (REFLECT_101 while staging), images smaller than a tile, odd sizes."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    g = rng.integers(0, 256, shape, dtype=np.uint8)
+    der, nxt = gpu.pyr_level(g)
+    assert np.array_equal(der, oracle.scharr(g))
+    assert np.array_equal(nxt, oracle.pyr_down(g))
+    der, nxt = gpu.pyr_level(g, down=False)
+    assert nxt is None and np.array_equal(der, oracle.scharr(g))
+
+
 # ---- F1 goodFeaturesToTrack -----------------------------------------------------
 @pytest.mark.parametrize("args", [(200, 0.02, 15.0, 3), (200, 0.01, 30.0, 3), (50, 0.05, 8.0, 5), (400, 0.01, 5.0, 3),
                                   (30, 0.01, 0.0, 3)])

@@ -375,6 +375,47 @@ def test_batch_mode_matches_per_frame_pipeline(gpu, batch, radius, n):
         s.close()
 
 
+@pytest.mark.parametrize("size,levels,win", [((200, 150), 4, 9), ((322, 242), 3, 15), ((134, 98), 5, 5)])
+@pytest.mark.parametrize("fused", [0, 1])
+def test_batch_mode_pyramid_levels_of_odd_sizes(gpu, monkeypatch, size, levels, win, fused):
+    """Batch mode builds the pyramid levels of all frames of a batch per launch: the two stencils of the per-frame pipeline
+    over a table of images, or (VS_STAB_FUSED_PYRAMID=1) one launch per level that produces the derivatives of level l and
+    the image of level l+1 from one staged tile (k_pyr.hip pyr_level_kernel).  Drone mode analyses at the frame's own size,
+    so the levels here have odd widths and heights (200x150 -> 100x75 -> 50x38 -> 25x19 -> ...), widths that are not
+    multiples of four and tiles that hang over every border.  Same tracks, same frames as the per-frame pipeline."""
+    if fused:
+        monkeypatch.setenv("VS_STAB_FUSED_PYRAMID", "1")
+    w, h = size
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 31, w, h, 12)
+    p = gpu.params(smoothing_radius=5, drone_high_freq_mode=1, hf_analysis_max_width=1024, lk_max_level=levels, lk_win_size=win, max_corners=120)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(4)
+    fb = clip[0].nbytes
+    n = 22
+    d_in = capi.DevBuf(gpu, fb * 12)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, fb * (n + 4)), capi.DevBuf(gpu, fb * (n + 4))
+    k1 = k2 = 0
+    for i in range(n):
+        j = i % 12 if (i // 12) % 2 == 0 else 11 - i % 12
+        k1 += s1.push_dev(d_in.ptr + j * fb, w, h, w * 3, capi.FMT_BGR8, d_ref.ptr + k1 * fb, w * 3)
+        k2 += s2.push_dev(d_in.ptr + j * fb, w, h, w * 3, capi.FMT_BGR8, d_got.ptr + k2 * fb, w * 3)
+        if i % 4 == 3:                       # the batch has just run: its last frame's tracks against the per-frame pipeline's
+            s1.sync(); s2.sync()
+            a, b = s1.debug_arrays(), s2.debug_arrays()
+            for key in ("prev", "curr", "status", "inliers", "gray"):
+                assert np.array_equal(a[key].view(np.uint8), b[key].view(np.uint8)), (i, key)
+    while s1.flush_dev(d_ref.ptr + k1 * fb, w * 3):
+        k1 += 1
+    while s2.flush_dev(d_got.ptr + k2 * fb, w * 3):
+        k2 += 1
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n
+    assert np.array_equal(d_ref.download((k1, h, w, 3), np.uint8), d_got.download((k2, h, w, 3), np.uint8))
+    s1.close(); s2.close()
+
+
 @pytest.mark.parametrize("extra", [dict(smoothing_method=capi.SMOOTH_GAUSSIAN, gaussian_sigma=3.0),
                                    dict(smoothing_method=capi.SMOOTH_KALMAN),
                                    dict(drone_high_freq_mode=1, horizon_lock=1),

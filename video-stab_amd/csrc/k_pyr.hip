@@ -61,7 +61,102 @@ __global__ __launch_bounds__(NT) void scharr_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// ---- one pyramid level per launch (batch mode) --------------------------------------------------------------
+// Level l of the LK pyramid needs two things of image l: its Scharr derivatives and, if there is a level l+1, its
+// pyrDown.  The two stencils above read the image separately (5 launches for 3 levels, 25 + 9 byte loads per output
+// pixel through L1).  Here a workgroup stages a 64 x 16 tile of image l with a 2-pixel rim (REFLECT_101 applied while
+// staging: both stencils use it on source coordinates) in LDS once - dword loads when the tile is inside the image -
+// and produces the tile's 64 x 16 derivative pairs (4 per lane, one 16-byte store) and its 32 x 8 pixels of level l+1
+// (1 per lane): 3 launches for 3 levels, every level read once.
+constexpr int FT_W = 64, FT_H = 16;                    // tile of image l
+constexpr int FT_PITCH = 72;                           // staged row: 68 bytes used (x0 - 2 .. x0 + 65), dword aligned
+constexpr int FT_ROWS = FT_H + 4;                      // y0 - 2 .. y0 + 17
+
+template <bool DOWN>
+__global__ __launch_bounds__(NT) void pyr_level_kernel(const ImgPair* __restrict__ sch, const ImgPair* __restrict__ pyr, size_t sstride,
+                                                       int w, int h, size_t dstride, int dw, int dh) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_ROWS * FT_PITCH];
+    const uint8_t* __restrict__ src = static_cast<const uint8_t*>(sch[blockIdx.z].src);
+    int16_t* __restrict__ der = static_cast<int16_t*>(sch[blockIdx.z].dst);
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    // ---- stage rows y0-2 .. y0+17, columns x0-4 .. x0+67 (the dword grid of the image; tile column c = x - (x0 - 4))
+    const bool inside = x0 >= 4 && y0 >= 2 && x0 + FT_W + 4 <= w && y0 + FT_H + 2 <= h && (sstride & 3) == 0 && ((uintptr_t)src & 3) == 0;
+    if (inside) {
+        for (int i = tid; i < FT_ROWS * (FT_PITCH / 4); i += NT) {
+            const int r = i / (FT_PITCH / 4), c4 = i - r * (FT_PITCH / 4);
+            reinterpret_cast<uint32_t*>(tile)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(y0 - 2 + r) * sstride + (x0 - 4) + 4 * c4);
+        }
+    } else {
+        for (int i = tid; i < FT_ROWS * FT_PITCH; i += NT) {
+            const int r = i / FT_PITCH, c = i - r * FT_PITCH;
+            tile[i] = src[(size_t)reflect101(y0 - 2 + r, h) * sstride + reflect101(x0 - 4 + c, w)];
+        }
+    }
+    __syncthreads();
+    // ---- Scharr: lane -> row tid / 16, columns 4 * (tid % 16) .. + 3
+    {
+        const int r = tid >> 4, c = (tid & 15) * 4;
+        const int y = y0 + r, x = x0 + c;
+        if (y < h && x < w) {
+            const uint8_t* t0 = tile + (r + 1) * FT_PITCH + c + 3;      // row y-1, column x-1
+            const uint8_t* t1 = t0 + FT_PITCH;
+            const uint8_t* t2 = t1 + FT_PITCH;
+            int a[6], b[6];                                             // vertical smoothing / difference of columns x-1 .. x+4
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                a[k] = (t0[k] + t2[k]) * 3 + t1[k] * 10;
+                b[k] = t2[k] - t0[k];
+            }
+            uint32_t o[4];                                              // (dx, dy) as two 16-bit halves
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int dx = a[k + 2] - a[k], dy = (b[k + 2] + b[k]) * 3 + b[k + 1] * 10;
+                o[k] = ((uint32_t)dx & 0xFFFFu) | ((uint32_t)dy << 16);
+            }
+            int16_t* d = der + ((size_t)y * w + x) * 2;
+            if (x + 3 < w && (((uintptr_t)d) & 15) == 0) {
+                *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+                for (int k = 0; k < 4 && x + k < w; k++) reinterpret_cast<uint32_t*>(d)[k] = o[k];
+            }
+        }
+    }
+    // ---- pyrDown: lane -> output (x0 / 2 + tid % 32, y0 / 2 + tid / 32)
+    if (DOWN) {
+        uint8_t* __restrict__ dst = static_cast<uint8_t*>(pyr[blockIdx.z].dst);
+        const int xo = (x0 >> 1) + (tid & 31), yo = (y0 >> 1) + (tid >> 5);
+        if (xo < dw && yo < dh) {
+            // source rows 2 yo - 2 .. + 2 = tile rows 2 (tid / 32) .. + 4; columns 2 xo - 2 .. + 2 = tile columns 2 (tid % 32) + 2 .. + 6
+            const uint8_t* t = tile + 2 * (tid >> 5) * FT_PITCH + 2 * (tid & 31) + 2;
+            int col[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const uint8_t* s = t + j * FT_PITCH;
+                col[j] = s[2] * 6 + (s[1] + s[3]) * 4 + s[0] + s[4];
+            }
+            dst[(size_t)yo * dstride + xo] = (uint8_t)((col[2] * 6 + (col[1] + col[3]) * 4 + col[0] + col[4] + 128) >> 8);
+        }
+    }
+}
+
 }  // namespace
+
+// Derivatives of level l (d_scharr_pairs: image l -> derivative image) and, when d_pyr_pairs is given, level l+1
+// (d_pyr_pairs: image l -> image l+1) of `items` frames.  w, h: size of image l (row pitch sstride); dstride: pitch of l+1.
+int launch_pyr_level_batch(const ImgPair* d_scharr_pairs, const ImgPair* d_pyr_pairs, int items, size_t sstride, int w, int h,
+                           size_t dstride, hipStream_t st) {
+    if (!d_scharr_pairs || items < 1 || items > 65535 || w <= 0 || h <= 0 || h > 65535) {
+        set_last_error("pyr_level_batch: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    dim3 grid((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, items);
+    if (d_pyr_pairs) hipLaunchKernelGGL(pyr_level_kernel<true>, grid, dim3(NT), 0, st, d_scharr_pairs, d_pyr_pairs, sstride, w, h, dstride, dw, dh);
+    else hipLaunchKernelGGL(pyr_level_kernel<false>, grid, dim3(NT), 0, st, d_scharr_pairs, d_pyr_pairs, sstride, w, h, dstride, dw, dh);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
 
 int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst,
                     size_t dstride, hipStream_t st) {

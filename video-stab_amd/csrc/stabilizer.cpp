@@ -1032,10 +1032,21 @@ int run_batch(vs_stab* s) {
                 S_TRY(s, launch_resize_gray_batch(s->d_pairs + n_a, n - n_a, s->src_pitch, s->w, s->h, gfmt, s->aw, s->aw, s->ah, aligned, s->st_pre));
         }
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
-        for (int l = 1; l <= L; l++)
-            S_TRY(s, launch_pyr_down_batch(s->d_pairs + (size_t)l * n, n, s->lw[l - 1], s->lw[l - 1], s->lh[l - 1], s->lw[l], s->st_pre));
-        for (int l = 0; l <= L; l++)
-            S_TRY(s, launch_scharr_batch(s->d_pairs + (size_t)(L + 1 + l) * n, n, s->lw[l], s->lw[l], s->lh[l], s->st_pre));
+        // VS_STAB_FUSED_PYRAMID=1: one launch per level (pyr_level_kernel).  Measured slower in the pipeline (77.6 k against
+        // 82.3 k frames/s at 1080p): the fused level-0 launch takes 73-81 us alone - its byte-wide LDS reads and ~25 VALU
+        // operations per derivative pair bound it, not the 83 MB it moves - against 37 + 61 us for the two stencils, which
+        // overlap the detector better.  Kept for the tests and as the starting point of a packed-arithmetic version.
+        if (std::getenv("VS_STAB_FUSED_PYRAMID") == nullptr) {
+            for (int l = 1; l <= L; l++)
+                S_TRY(s, launch_pyr_down_batch(s->d_pairs + (size_t)l * n, n, s->lw[l - 1], s->lw[l - 1], s->lh[l - 1], s->lw[l], s->st_pre));
+            for (int l = 0; l <= L; l++)
+                S_TRY(s, launch_scharr_batch(s->d_pairs + (size_t)(L + 1 + l) * n, n, s->lw[l], s->lw[l], s->lh[l], s->st_pre));
+        } else {
+            // one launch per level: derivatives of level l and the image of level l+1 from one staged read of level l
+            for (int l = 0; l <= L; l++)
+                S_TRY(s, launch_pyr_level_batch(s->d_pairs + (size_t)(L + 1 + l) * n, l < L ? s->d_pairs + (size_t)(l + 1) * n : nullptr, n,
+                                                s->lw[l], s->lw[l], s->lh[l], l < L ? s->lw[l + 1] : 0, s->st_pre));
+        }
     }
     S_HIP(s, hipEventRecord(s->ev_bpre, s->st_pre));
     // ---- det: every frame of the batch that re-detects, one launch per GFTT stage

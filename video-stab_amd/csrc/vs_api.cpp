@@ -220,6 +220,28 @@ int vs_op_scharr(const void* d_src, size_t src_stride, int w, int h, void* d_dst
     return launch_scharr((const uint8_t*)d_src, src_stride, w, h, (int16_t*)d_dst, (hipStream_t)stream);
 }
 
+int vs_op_pyr_level(const void* d_src, size_t src_stride, size_t src_frame_bytes, int w, int h, void* d_der, void* d_next,
+                    size_t next_stride, size_t next_frame_bytes, int items, void* stream) {
+    VS_TRY(ensure_device());
+    if (!d_src || !d_der || items < 1 || items > 4096 || w <= 0 || h <= 0) { set_last_error("pyr_level: invalid argument"); return VS_ERR_INVALID_ARG; }
+    // the kernel takes device tables of (source, destination) pairs: built here for the call (an operator for tests and probes)
+    std::vector<ImgPair> t(2 * (size_t)items);
+    for (int i = 0; i < items; i++) {
+        const uint8_t* s = (const uint8_t*)d_src + (size_t)i * src_frame_bytes;
+        t[i] = ImgPair{s, (uint8_t*)d_der + (size_t)i * w * h * 4};
+        t[items + i] = ImgPair{s, d_next ? (uint8_t*)d_next + (size_t)i * next_frame_bytes : nullptr};
+    }
+    ImgPair* d_t = nullptr;
+    VS_HIP_TRY(hipMalloc((void**)&d_t, sizeof(ImgPair) * t.size()));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = VS_OK;
+    if (hipMemcpyAsync(d_t, t.data(), sizeof(ImgPair) * t.size(), hipMemcpyHostToDevice, st) != hipSuccess) rc = VS_ERR_HIP;
+    if (rc == VS_OK) rc = launch_pyr_level_batch(d_t, d_next ? d_t + items : nullptr, items, src_stride, w, h, next_stride, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(d_t);
+    return rc;
+}
+
 int vs_op_pyr_lk(const void* d_prev, const void* d_next, size_t stride, int w, int h,
                  const float* d_prev_pts, int n, float* d_next_pts, uint8_t* d_status, float* d_err,
                  int win, int max_level, int max_iters, double eps, void* stream) {

@@ -96,6 +96,8 @@ int launch_resize_gray_batch(const ImgPair* d_pairs, int items, size_t sstride, 
                              int dw, int dh, int aligned, hipStream_t st);
 int launch_pyr_down_batch(const ImgPair* d_pairs, int items, size_t sstride, int sw, int sh, size_t dstride, hipStream_t st);
 int launch_scharr_batch(const ImgPair* d_pairs, int items, size_t sstride, int w, int h, hipStream_t st);
+int launch_pyr_level_batch(const ImgPair* d_scharr_pairs, const ImgPair* d_pyr_pairs, int items, size_t sstride, int w, int h,
+                           size_t dstride, hipStream_t st);
 int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst,
                     size_t dstride, hipStream_t st);
 int launch_scharr(const uint8_t* d_src, size_t sstride, int w, int h, int16_t* d_dst,

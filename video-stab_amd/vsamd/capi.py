@@ -219,6 +219,7 @@ class VsLib:
         L.vs_op_resize_gray.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, vp]
         L.vs_op_pyr_down.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.vs_op_scharr.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, vp]
+        L.vs_op_pyr_level.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp]
         L.vs_op_pyr_lk.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp,
                                    C.c_int, C.c_int, C.c_int, C.c_double, vp]
         L.vs_op_gftt.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
@@ -368,6 +369,18 @@ class VsLib:
         self.check(self.lib.vs_op_scharr(d_in.ptr, w, w, h, d_out.ptr, None))
         self.sync()
         return d_out.download((h, w, 2), np.int16)
+
+    def pyr_level(self, g, down=True):
+        """One pyramid level of batch mode: (derivatives int16 (h, w, 2), next level or None) of a gray image."""
+        g = np.ascontiguousarray(g)
+        h, w = g.shape
+        dh, dw = (h + 1) // 2, (w + 1) // 2
+        d_in = DevBuf.from_array(self, g)
+        d_der = DevBuf(self, h * w * 4)
+        d_next = DevBuf(self, dw * dh) if down else None
+        self.check(self.lib.vs_op_pyr_level(d_in.ptr, w, w * h, w, h, d_der.ptr, d_next.ptr if down else None, dw, dw * dh, 1, None))
+        self.sync()
+        return d_der.download((h, w, 2), np.int16), (d_next.download((dh, dw), np.uint8) if down else None)
 
     def pyr_lk(self, prev, nxt, pts, win=15, max_level=2, iters=20, eps=0.03):
         prev = np.ascontiguousarray(prev)
