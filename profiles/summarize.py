@@ -31,8 +31,9 @@ def counter(d, name):
 fetch, write = counter(fetch_dir, "FETCH_SIZE"), counter(write_dir, "WRITE_SIZE")
 # full launches only (the first launches of a run carry fewer frames): those that write the most
 full = max(write)
-fetch_full = [f for f, w in zip(fetch, write) if w == full] if len(fetch) == len(write) else fetch[-8:]
-fetch_kib, write_kib = statistics.mean(fetch_full), full
+is_full = [w >= 0.99 * full for w in write]
+fetch_full = [f for f, ok in zip(fetch, is_full) if ok] if len(fetch) == len(write) else fetch[-8:]
+fetch_kib, write_kib = statistics.mean(fetch_full), statistics.mean([w for w, ok in zip(write, is_full) if ok])
 out = {
     "kernel": KERNEL,
     "build_tag": build_tag,
