@@ -353,7 +353,9 @@ def main():
     params = make_params(vs, args.config)
     ss = StreamSet(vs, local_rank, params, clips, W, H, capi.FMT_BGR8, args.batch, args.warp_batch, args.zero_copy)
     BT = ss.BT
-    preroll = 64   # past the 29-frame warm-up of smoothingRadius 30: every timed push produces a frame
+    # setup, not a step: past the 29-frame warm-up of smoothingRadius 30 (every later push produces a frame), and ~0.1 s of the
+    # same work so that the device's clocks and the allocator's first touches are not part of the W warm-up steps' job
+    preroll = 64 + 200 * BT
 
     def sync_all():
         ss.sync()
