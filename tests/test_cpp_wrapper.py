@@ -37,8 +37,32 @@ def test_wrapper_runs_file_capture_loop(gpu):
     build()
     r = subprocess.run([EXE, "40"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    n, outs, flushed, _ = r.stdout.split()
+    n, outs, flushed, _ = r.stdout.strip().splitlines()[-1].split()
     assert (int(n), int(outs), int(flushed)) == (40, 21, 19)     # radius 20 -> 19 warm-up empties
+
+
+def _run(mode, n=40, **env):
+    r = subprocess.run([EXE, str(n), mode], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    frames = [tuple(int(v) for v in ln.split()[1:]) for ln in lines if ln.startswith("F ")]
+    return frames, [int(v) for v in lines[-1].split()[:3]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,size", [("reflect", (240, 320)), ("fade", (264, 344)), ("canvas", (240, 320)), ("canvas12", (240, 320))])
+def test_wrapper_modes_and_the_pipelined_host_call(gpu, mode, size):
+    """vs::Stabilizer through its Parameters for the border / canvas modes of round 2 (frame sizes as the reference returns
+    them: the fade border pads, the canvas window has the unpadded size), and VS_STAB_HOST_PIPELINE=1: the same frames in
+    the same order, one stabilize() call later (the held frame comes out of flush() first)."""
+    build()
+    frames, (n, outs, flushed) = _run(mode)
+    assert (n, outs, flushed) == (40, 21, 19) and len(frames) == 40
+    # every frame but the last one (no transform: returned as it came, unpadded) has the mode's size
+    assert all(f[:2] == size for f in frames[:-1]) and frames[-1][:2] == (240, 320)
+    assert len(set(f[2] for f in frames)) > 30                      # a moving picture, not one frame forty times
+    piped, (n2, outs2, flushed2) = _run(mode, VS_STAB_HOST_PIPELINE="1")
+    assert piped == frames and (n2, outs2, flushed2) == (40, 20, 20)
 
 
 ROLL_EXE = os.path.join(ROOT, "tests", "cpp", "_build", "roll_smoke")
