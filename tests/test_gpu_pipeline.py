@@ -378,13 +378,13 @@ def test_batch_mode_matches_per_frame_pipeline(gpu, batch, radius, n):
 @pytest.mark.parametrize("size,levels,win", [((200, 150), 4, 9), ((322, 242), 3, 15), ((134, 98), 5, 5)])
 @pytest.mark.parametrize("fused", [0, 1])
 def test_batch_mode_pyramid_levels_of_odd_sizes(gpu, monkeypatch, size, levels, win, fused):
-    """Batch mode builds the pyramid levels of all frames of a batch per launch: the two stencils of the per-frame pipeline
-    over a table of images, or (VS_STAB_FUSED_PYRAMID=1) one launch per level that produces the derivatives of level l and
-    the image of level l+1 from one staged tile (k_pyr.hip pyr_level_kernel).  Drone mode analyses at the frame's own size,
+    """Batch mode builds the pyramid levels of all frames of a batch per launch: one launch per level that produces the
+    derivatives of level l and the image of level l+1 from one staged tile (k_pyr.hip pyr_level_kernel), or
+    (VS_STAB_SPLIT_PYRAMID=1) the two stencils of the per-frame pipeline over a table of images.  Drone mode analyses at the frame's own size,
     so the levels here have odd widths and heights (200x150 -> 100x75 -> 50x38 -> 25x19 -> ...), widths that are not
     multiples of four and tiles that hang over every border.  Same tracks, same frames as the per-frame pipeline."""
-    if fused:
-        monkeypatch.setenv("VS_STAB_FUSED_PYRAMID", "1")
+    if not fused:
+        monkeypatch.setenv("VS_STAB_SPLIT_PYRAMID", "1")
     w, h = size
     clip = synth.make_clip(synth.SEED_CONFIG1 + 31, w, h, 12)
     p = gpu.params(smoothing_radius=5, drone_high_freq_mode=1, hf_analysis_max_width=1024, lk_max_level=levels, lk_win_size=win, max_corners=120)

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(NT) void scharr_kernel(const uint8_t* __restrict__ 
 // pixel through L1).  Here a workgroup stages a 64 x 16 tile of image l with a 2-pixel rim (REFLECT_101 applied while
 // staging: both stencils use it on source coordinates) in LDS once - dword loads when the tile is inside the image -
 // and produces the tile's 64 x 16 derivative pairs (4 per lane, one 16-byte store) and its 32 x 8 pixels of level l+1
-// (1 per lane): 3 launches for 3 levels, every level read once.
+// (1 per lane): 3 launches for 3 levels, every level read once.  The kernel is bound by dependent LDS round trips, not by
+// bytes or arithmetic: with one ds_read_u8 per tap (18 + 25 per lane) level 0 of a 32-frame batch took 73 - 81 us, with
+// the taps fetched as dwords (9 + 10 reads, bytes picked out in registers, the 1 4 6 4 row of pyrDown as one v_dot4) 25 - 35.
 constexpr int FT_W = 64, FT_H = 16;                    // tile of image l
 constexpr int FT_PITCH = 72;                           // staged row: 68 bytes used (x0 - 2 .. x0 + 65), dword aligned
 constexpr int FT_ROWS = FT_H + 4;                      // y0 - 2 .. y0 + 17
@@ -87,26 +89,39 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const ImgPair* __restrict
             const int r = i / (FT_PITCH / 4), c4 = i - r * (FT_PITCH / 4);
             reinterpret_cast<uint32_t*>(tile)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(y0 - 2 + r) * sstride + (x0 - 4) + 4 * c4);
         }
-    } else {
-        for (int i = tid; i < FT_ROWS * FT_PITCH; i += NT) {
-            const int r = i / FT_PITCH, c = i - r * FT_PITCH;
-            tile[i] = src[(size_t)reflect101(y0 - 2 + r, h) * sstride + reflect101(x0 - 4 + c, w)];
+    } else if (tid < 3 * FT_PITCH) {
+        // a tile on the image's border: a lane keeps one column (its reflection is computed once) and takes every third row;
+        // its (up to 7) byte loads do not depend on each other
+        const int c = tid % FT_PITCH, r0 = tid / FT_PITCH;
+        const uint8_t* col = src + reflect101(x0 - 4 + c, w);
+#pragma unroll
+        for (int k = 0; k < (FT_ROWS + 2) / 3; k++) {
+            const int r = r0 + 3 * k;
+            if (r < FT_ROWS) tile[r * FT_PITCH + c] = col[(size_t)reflect101(y0 - 2 + r, h) * sstride];
         }
     }
     __syncthreads();
-    // ---- Scharr: lane -> row tid / 16, columns 4 * (tid % 16) .. + 3
+    const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
+    // ---- Scharr: lane -> row tid / 16, columns 4 * (tid % 16) .. + 3.  Three dwords per row (the byte left of the group,
+    // the group, the byte right of it) instead of six byte reads: the kernel is bound by dependent LDS round trips
     {
         const int r = tid >> 4, c = (tid & 15) * 4;
         const int y = y0 + r, x = x0 + c;
         if (y < h && x < w) {
-            const uint8_t* t0 = tile + (r + 1) * FT_PITCH + c + 3;      // row y-1, column x-1
-            const uint8_t* t1 = t0 + FT_PITCH;
-            const uint8_t* t2 = t1 + FT_PITCH;
-            int a[6], b[6];                                             // vertical smoothing / difference of columns x-1 .. x+4
+            int t[3][6];                                                // rows y-1 .. y+1, columns x-1 .. x+4
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint32_t* q = T + (r + 1 + j) * (FT_PITCH / 4) + (c >> 2);     // tile columns c .. c+11
+                const uint32_t lo = q[0], mid = q[1], hi = q[2];
+                t[j][0] = lo >> 24;
+                t[j][1] = mid & 255u; t[j][2] = (mid >> 8) & 255u; t[j][3] = (mid >> 16) & 255u; t[j][4] = mid >> 24;
+                t[j][5] = hi & 255u;
+            }
+            int a[6], b[6];                                             // vertical smoothing / difference per column
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                a[k] = (t0[k] + t2[k]) * 3 + t1[k] * 10;
-                b[k] = t2[k] - t0[k];
+                a[k] = (t[0][k] + t[2][k]) * 3 + t[1][k] * 10;
+                b[k] = t[2][k] - t[0][k];
             }
             uint32_t o[4];                                              // (dx, dy) as two 16-bit halves
 #pragma unroll
@@ -127,13 +142,17 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const ImgPair* __restrict
         uint8_t* __restrict__ dst = static_cast<uint8_t*>(pyr[blockIdx.z].dst);
         const int xo = (x0 >> 1) + (tid & 31), yo = (y0 >> 1) + (tid >> 5);
         if (xo < dw && yo < dh) {
-            // source rows 2 yo - 2 .. + 2 = tile rows 2 (tid / 32) .. + 4; columns 2 xo - 2 .. + 2 = tile columns 2 (tid % 32) + 2 .. + 6
-            const uint8_t* t = tile + 2 * (tid >> 5) * FT_PITCH + 2 * (tid & 31) + 2;
+            // source rows 2 yo - 2 .. + 2 = tile rows 2 (tid / 32) .. + 4; columns 2 xo - 2 .. + 2 = tile columns o .. o + 4 with
+            // o = 2 (tid % 32) + 2: two dwords per row, the five taps as one byte-aligned dword (1 4 6 4 by v_dot4) plus one byte
+            const int o = 2 * (tid & 31) + 2, sh = o & 3;              // sh = 0 or 2
+            const uint32_t* q = T + 2 * (tid >> 5) * (FT_PITCH / 4) + (o >> 2);
             int col[5];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                const uint8_t* s = t + j * FT_PITCH;
-                col[j] = s[2] * 6 + (s[1] + s[3]) * 4 + s[0] + s[4];
+                const uint32_t lo = q[j * (FT_PITCH / 4)], hi = q[j * (FT_PITCH / 4) + 1];
+                const uint32_t four = __builtin_amdgcn_alignbyte(hi, lo, sh);             // taps 0 .. 3
+                const uint32_t fifth = (hi >> (8 * sh)) & 255u;                              // tap 4
+                col[j] = (int)__builtin_amdgcn_udot4(four, 0x04060401u, fifth, false);
             }
             dst[(size_t)yo * dstride + xo] = (uint8_t)((col[2] * 6 + (col[1] + col[3]) * 4 + col[0] + col[4] + 128) >> 8);
         }

@@ -65,7 +65,7 @@ int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items,
 size_t gftt_item_bytes();
 int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
                    double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
-int launch_gftt_batch(const void* d_table, int items, int w, int h, int block_size, hipStream_t st);
+int launch_gftt_batch(const void* d_table, int items, int w, int h, int block_size, hipStream_t st, int what = 0);
 int launch_traj_emit(TrajState* s, const TrajParams& p, int idx, float* M_out, double* Minv_out, vs_debug_frame* dbg,
                      hipStream_t st, float* t_out = nullptr);
 int launch_traj_reset(TrajState* s, int smoothing_radius, hipStream_t st);
@@ -1032,11 +1032,12 @@ int run_batch(vs_stab* s) {
                 S_TRY(s, launch_resize_gray_batch(s->d_pairs + n_a, n - n_a, s->src_pitch, s->w, s->h, gfmt, s->aw, s->aw, s->ah, aligned, s->st_pre));
         }
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
-        // VS_STAB_FUSED_PYRAMID=1: one launch per level (pyr_level_kernel).  Measured slower in the pipeline (77.6 k against
-        // 82.3 k frames/s at 1080p): the fused level-0 launch takes 73-81 us alone - its byte-wide LDS reads and ~25 VALU
-        // operations per derivative pair bound it, not the 83 MB it moves - against 37 + 61 us for the two stencils, which
-        // overlap the detector better.  Kept for the tests and as the starting point of a packed-arithmetic version.
-        if (std::getenv("VS_STAB_FUSED_PYRAMID") == nullptr) {
+        // One launch per level (pyr_level_kernel): derivatives of level l and the image of level l+1 from one staged read of
+        // level l.  83.0 k -> 92.2 k frames/s at 1080p against the two stencils as separate launches (VS_STAB_SPLIT_PYRAMID=1,
+        // the schedule before): 3 launches instead of 5, level 0 of a batch 35 us instead of 37 + 61, and the detector's
+        // min-eigenvalue launch no longer shares the GPU with a 60 us pyrDown.  (The first version of the kernel, with
+        // byte-wide LDS reads, took 81 us for level 0 and lost: 77.6 k.)
+        if (std::getenv("VS_STAB_SPLIT_PYRAMID") != nullptr) {
             for (int l = 1; l <= L; l++)
                 S_TRY(s, launch_pyr_down_batch(s->d_pairs + (size_t)l * n, n, s->lw[l - 1], s->lw[l - 1], s->lh[l - 1], s->lw[l], s->st_pre));
             for (int l = 0; l <= L; l++)
@@ -1064,15 +1065,16 @@ int run_batch(vs_stab* s) {
     if (ndet > 0) {
         // starts as soon as the analysis images exist, next to the pyramid levels of this batch and the tracking of the
         // previous one (VS_STAB_DET_AFTER_PRE=1: after the whole pre stage, the schedule before this was measured)
-        // (the table first: it is on the device by the time the analysis images are)
+        // (the table and the reset of the counters first: they are through by the time the analysis images are)
         S_HIP(s, hipMemcpyAsync(s->d_gf_table, h_gf, gftt_item_bytes() * ndet, hipMemcpyHostToDevice, s->st_det));
-        S_HIP(s, hipStreamWaitEvent(s->st_det, std::getenv("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
         // keypoint buffers are recycled after B + 4 detections (two batches): the tracking of the batch before
         // the previous one must have read them (the GFTT scratch is only touched on this stream)
         if (k >= 2) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 2) % 4], 0));
+        S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 1));
+        S_HIP(s, hipStreamWaitEvent(s->st_det, std::getenv("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
         {
             StageScope t(s, VS_STAGE_GFTT, s->st_det);
-            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det));   // :740-744: block size 3
+            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 2));   // :740-744: block size 3
         }
         S_HIP(s, hipEventRecord(s->ev_bdet[k % 4], s->st_det));
         s->last_det_batch = k;
