@@ -225,7 +225,7 @@ struct vs_stab {
     size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0;
     uint8_t *d_lk_table[2] = {nullptr, nullptr}, *d_rs_table[2] = {nullptr, nullptr}, *d_gf_table = nullptr, *d_tail_table[2] = {nullptr, nullptr};
     ImgPair* d_pairs = nullptr;
-    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
+    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
     bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
     int last_det_batch = -1;
     // what the debug getters read (last analysed frame)
@@ -958,9 +958,8 @@ int run_batch(vs_stab* s) {
         // pyramid / detection kernels start after the warps issued during the previous run_batch (batch k-2's)
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_warp[s->last_warp_set], 0));
     }
-    // ---- argument tables of the tracker, the scoring and the tail: they do not depend on this batch's images.  Uploaded on
-    // `main`, where they run while `main` waits for this batch's pyramids anyway (on `pre` they sat in front of the gray
-    // stage, on the detector's critical path); the device copies alternate because `main` may still be in the batch before.
+    // ---- argument tables of the tracker, the scoring and the tail: filled here (they do not depend on this batch's images),
+    // uploaded at the end of `pre`; the device copies alternate because `main` may still be in the batch before.
     int n_max = 0;
     for (int i = 0; i < n; i++) {
         const vs_stab::BFrame& b = s->bq[i];
@@ -978,8 +977,6 @@ int run_batch(vs_stab* s) {
                                   s->d_npts[b.lk_buf], it.vp, it.vc, it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab,
                                   it.counts, it.model, it.inliers, it.info, s->d_traj, &s->tp, s->d_dbg, b.have_prev_gray));
     }
-    S_HIP(s, hipMemcpyAsync(s->d_lk_table[dset], h_lk, lk_item_bytes() * n, hipMemcpyHostToDevice, s->st));
-    S_HIP(s, hipMemcpyAsync(s->d_rs_table[dset], h_rs, ransac_item_bytes() * n, hipMemcpyHostToDevice, s->st));
     // the tail's table as well (which outputs become due and where their maps go is known on the host)
     S_TRY(s, flush_warps(s));                      // the list of pending warps starts empty
     const int set = s->pend_set;
@@ -996,7 +993,6 @@ int run_batch(vs_stab* s) {
         }
         tail_fill_item(h_tail + tail_item_bytes() * i, b.out_due ? 1 : 0, b.out_idx, minv);
     }
-    S_HIP(s, hipMemcpyAsync(s->d_tail_table[dset], h_tail, tail_item_bytes() * n, hipMemcpyHostToDevice, s->st));
     if (s->bq[0].prev_small) {   // :598-603 (once: 480x270 -> analysis size)
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
         S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[s->bq[0].pv].img[0], s->aw, s->aw, s->ah, s->st_pre));
@@ -1031,6 +1027,12 @@ int run_batch(vs_stab* s) {
             if (n_a < n)
                 S_TRY(s, launch_resize_gray_batch(s->d_pairs + n_a, n - n_a, s->src_pitch, s->w, s->h, gfmt, s->aw, s->aw, s->ah, aligned, s->st_pre));
         }
+        // the tracker / scoring / tail tables go up here, in the middle of `pre` (which has slack): on `main` they sat between
+        // the tail of the batch before and its warps; in front of the gray stage they delayed the detector; at the end of
+        // `pre` they delayed the event the warps wait for
+        S_HIP(s, hipMemcpyAsync(s->d_lk_table[dset], h_lk, lk_item_bytes() * n, hipMemcpyHostToDevice, s->st_pre));
+        S_HIP(s, hipMemcpyAsync(s->d_rs_table[dset], h_rs, ransac_item_bytes() * n, hipMemcpyHostToDevice, s->st_pre));
+        S_HIP(s, hipMemcpyAsync(s->d_tail_table[dset], h_tail, tail_item_bytes() * n, hipMemcpyHostToDevice, s->st_pre));
         StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
         // One launch per level (pyr_level_kernel): derivatives of level l and the image of level l+1 from one staged read of
         // level l.  83.0 k -> 92.2 k frames/s at 1080p against the two stencils as separate launches (VS_STAB_SPLIT_PYRAMID=1,
@@ -1075,6 +1077,10 @@ int run_batch(vs_stab* s) {
         {
             StageScope t(s, VS_STAGE_GFTT, s->st_det);
             S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 2));   // :740-744: block size 3
+            // the wide launches of the detection are through: the warps of the batch before may go (below); the selection -
+            // one workgroup per image - runs beside them
+            S_HIP(s, hipEventRecord(s->ev_bnms, s->st_det));
+            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 3));
         }
         S_HIP(s, hipEventRecord(s->ev_bdet[k % 4], s->st_det));
         s->last_det_batch = k;
@@ -1084,10 +1090,15 @@ int run_batch(vs_stab* s) {
     hipStream_t st = s->st;
     S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
     if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
-    if (s->last_det_batch >= 0 && s->last_det_batch >= k - 1) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
-    // `main` has now waited for this batch's gray/pyramid/detection work: the warps of the PREVIOUS batch go out
-    // here, alone on the GPU, before this batch's tracking
+    const bool wait_det = s->last_det_batch >= 0 && s->last_det_batch >= k - 1;
+    const bool early = wait_det && s->last_det_batch == k && std::getenv("VS_STAB_WARP_AFTER_SELECT") == nullptr;
+    if (early) S_HIP(s, hipStreamWaitEvent(st, s->ev_bnms, 0));
+    else if (wait_det) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
+    // `main` has now waited for this batch's gray / pyramid work and the wide launches of its detection: the warps of the
+    // PREVIOUS batch go out here, before this batch's tracking, with nothing but the corner selection (16 workgroups)
+    // beside them on the GPU
     S_TRY(s, launch_ready(s));
+    if (early) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));       // the tracker needs the selected corners
     {
         StageScope t(s, VS_STAGE_LK, st);
         S_TRY(s, launch_pyr_lk_batch(s->d_lk_table[dset], n, n_max, p.lk_win_size, st));
@@ -1240,7 +1251,7 @@ void destroy_events(vs_stab* s) {
     for (auto& e : s->ev_slot) kill(e);
     kill(s->ev_first); kill(s->ev_hold);
     kill(s->ev_emit); kill(s->ev_warp[0]); kill(s->ev_warp[1]);
-    kill(s->ev_bpre); kill(s->ev_bgray);
+    kill(s->ev_bpre); kill(s->ev_bgray); kill(s->ev_bnms);
     for (auto& e : s->ev_bdet) kill(e);
     for (auto& e : s->ev_blk) kill(e);
 }
@@ -1256,6 +1267,7 @@ int create_events(vs_stab* s) {
     S_HIP(s, mk(s->ev_emit)); S_HIP(s, mk(s->ev_warp[0])); S_HIP(s, mk(s->ev_warp[1]));
     S_HIP(s, mk(s->ev_bpre));
     S_HIP(s, mk(s->ev_bgray));
+    S_HIP(s, mk(s->ev_bnms));
     for (auto& e : s->ev_bdet) S_HIP(s, mk(e));
     for (auto& e : s->ev_blk) S_HIP(s, mk(e));
     return VS_OK;
