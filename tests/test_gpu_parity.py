@@ -89,6 +89,47 @@ def test_warp_multi_frame_launch_ragged_sizes(gpu, oracle, shape):
         assert np.array_equal(out[i], oracle.warp_affine(imgs[i], Ms[i])), (shape, i)
 
 
+@pytest.mark.parametrize("cn", [1, 2])
+def test_warp_plane_kernel_every_matrix_class(gpu, oracle, clip_small, cn):
+    """One- and two-channel planes (NV12: Y, interleaved UV) in launches of four and more frames take the plane kernel
+    (128 x 64 / 128 x 32 tiles, source box staged as bytes): every matrix class in ONE launch - interior tiles, tiles that
+    leave the image on every side, boxes that do not fit the staging area (direct path), frames entirely out of view."""
+    imgs = np.stack([clip_small[i % len(clip_small)] for i in range(len(MATS))])
+    planes = np.ascontiguousarray(imgs[..., 1] if cn == 1 else imgs[..., :2])
+    out = gpu.warp_affine(planes, np.array(MATS, np.float32))
+    for i, M in enumerate(MATS):
+        assert np.array_equal(out[i], oracle.warp_affine(planes[i], M)), i
+
+
+@pytest.mark.parametrize("cn", [1, 2])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (17, 129), (240, 322), (33, 130), (270, 482), (64, 128), (65, 132), (96, 516), (200, 1024)])
+def test_warp_plane_kernel_ragged_sizes(gpu, oracle, shape, cn):
+    """Partial tiles in both directions, widths that leave the 4-pixel stores and the 16-byte staging chunks hanging over the
+    right edge, planes smaller than a tile."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1] + cn)
+    h, w = shape
+    Ms = np.array([[0.9998, 0.02, 1.3, -0.02, 0.9998, -0.6], [1, 0, 0, 0, 1, 0], [1, 0, -2.5, 0, 1, 3.75],
+                   [0.9999, -0.012, -4.0, 0.012, 0.9999, 2.0], [1.0, 0.0, 6.0, 0.0, 1.0, -5.0], [0.998, 0.06, 0.5, -0.06, 0.998, 0.25]], np.float32)
+    planes = rng.integers(0, 256, (len(Ms), h, w) if cn == 1 else (len(Ms), h, w, 2), dtype=np.uint8)
+    out = gpu.warp_affine(planes, Ms, batch=True)
+    for i in range(len(Ms)):
+        assert np.array_equal(out[i], oracle.warp_affine(planes[i], Ms[i])), (shape, i)
+
+
+def test_warp_plane_kernel_4k_luma(gpu, oracle):
+    """Four 3840x2160 luma planes with the small rotations of a stabilizer, checked in full."""
+    rng = np.random.default_rng(11)
+    world = synth.make_world(synth.SEED_CONFIG2, 1920, 1080)
+    base = synth.render_frame(world, 1920, 1080, (300 * 256, 280 * 256, 90))[..., 1]
+    big = np.ascontiguousarray(np.kron(base, np.ones((2, 2), np.uint8)))
+    planes = np.stack([np.roll(big, 3 * b, axis=1) for b in range(4)])
+    Ms = np.array([[np.cos(a), -np.sin(a), dx, np.sin(a), np.cos(a), dy]
+                   for a, dx, dy in zip(rng.normal(0, 0.004, 4), rng.normal(0, 8, 4), rng.normal(0, 8, 4))], np.float32)
+    out = gpu.warp_affine(planes, Ms)
+    for i in range(4):
+        assert np.array_equal(out[i], oracle.warp_affine(planes[i], Ms[i], threads=8)), i
+
+
 def test_warp_multi_frame_launch_full_hd(gpu, oracle):
     """Six 1920x1080 frames (6120 tiles: runs of several tiles per workgroup) with the small rotations of a
     stabilizer, checked in full."""

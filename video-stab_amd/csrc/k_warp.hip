@@ -779,12 +779,223 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
                              cb.bx0a, cb.by0, cb.bw, tid);
 }
 
+// ---- one- and two-channel planes of batched launches (NV12: Y and interleaved UV) ------------------------------------
+// The BGR table kernel above owes its rate to what a workgroup carries through its latency chain (scalar prologue ->
+// staging loads -> barrier -> blend): 6 KB of output.  A 128 x 16 tile of a Y plane is 2 KB, of a UV plane 4 KB, and the general
+// kernel stages them as one dword per pixel with per-group checks: 0.22 of the HBM peak at 3840 x 2160.  This kernel gives a
+// plane workgroup 8 KB of output - 128 x 64 pixels of one channel, 128 x 32 of two - and stages the source box as BYTES
+// (row pitch 144 / 288, at most 73 / 41 rows: 10.5 / 11.8 KB, eight workgroups per CU):
+//   staging   16-byte chunks, vector loads for chunks inside the frame, per-byte checked loads (zeros outside:
+//             BORDER_CONSTANT) for the few that cross its edge;
+//   taps      the two horizontal taps of a pixel are adjacent in the staged row: an 8-byte LDS read at the 4-byte
+//             aligned address below them and one v_alignbyte put [p(x), p(x+1)] (or [U0 V0 U1 V1]) into the low bytes of a
+//             dword, for the upper and the lower tap row;
+//   blend     v_dot4 against ((32-f) | f << 8) (one channel) or ((32-f) | f << 16, and << 8 for V) = the weights as one
+//             multiply-add of f; vertical lerp in fp32 on denormals as in the BGR kernel;
+//   output    lane L of a 32-lane row takes pixels L, L+32, L+64, L+96 (conflict-free LDS reads), the row is transposed
+//             through the per-wave buffer and leaves as one 4- / 8-byte store per lane.
+// It shares the per-frame coordinate tables with the other kernels (the tables know tiles of 16 rows: the corner terms of
+// a taller tile come from the records of its first and last 16 rows).  A box that does not fit the staging area (large
+// rotations or zooms) takes emit_rows' direct path, 16 rows at a time.
+template <int CN> struct PlaneCfg {
+    static constexpr int THP = 64 / CN;                  // rows of a tile
+    static constexpr int PB = 136 * CN + 8 * CN;         // staged row pitch in bytes (136 pixels + slack for the 8-byte tap read)
+    static constexpr int ROWS = THP + 9;                 // staged rows (rotations up to ~3.5 degrees)
+    static constexpr int CPR = PB / 16;                  // 16-byte chunks per staged row
+};
+
+template <int CN>
+__global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
+                                                        uint32_t swh, uint32_t dwh, uint32_t flags) {
+    typedef PlaneCfg<CN> P;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[P::ROWS * P::PB];
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[OBUF];
+    __shared__ int s_tab[2 * TW + 2 * P::THP];           // ad[128] bd[128] x0[THP] y0[THP]
+    __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
+    typedef const __attribute__((address_space(4))) int32_t* cptr;
+    typedef __attribute__((address_space(1))) uint8_t* gptr;
+    const int tid = threadIdx.x;
+    WarpCore c;
+    c.sstride = sstride; c.dstride = dstride;
+    c.sw = swh & 0xFFFFu; c.sh = swh >> 16; c.dw = dwh & 0xFFFFu; c.dh = dwh >> 16;
+    c.src_aligned = flags & 1u; c.dst_aligned = (flags >> 1) & 1u; c.border = flags >> 2;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * P::THP;
+    const int x1 = min(x0 + TW, c.dw) - 1, y1 = min(y0 + P::THP, c.dh) - 1;
+    const uint8_t* src;
+    uint8_t* dst;
+    int ad0, ad1, bd0, bd1, Xa, Xb, Ya, Yb;
+    {
+        cptr Ts = (cptr)(const int32_t*)(tabs + (size_t)blockIdx.z * tab_stride);
+        typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
+        typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+        const i32x8 cc = *(const __attribute__((address_space(4))) i32x8*)(Ts + TAB_COL * blockIdx.x);
+        const i32x4 r0 = *(const __attribute__((address_space(4))) i32x4*)(Ts + tab_row + 4 * (y0 / TH));
+        const i32x4 r1 = *(const __attribute__((address_space(4))) i32x4*)(Ts + tab_row + 4 * (y1 / TH));
+        src = (const uint8_t*)(gptr)((unsigned long long)(uint32_t)cc[0] | (unsigned long long)(uint32_t)cc[1] << 32);
+        dst = (uint8_t*)(gptr)((unsigned long long)(uint32_t)cc[2] | (unsigned long long)(uint32_t)cc[3] << 32);
+        ad0 = cc[4]; ad1 = cc[5]; bd0 = cc[6]; bd1 = cc[7];
+        Xa = r0[0]; Ya = r0[2]; Xb = r1[1]; Yb = r1[3];
+    }
+    if (tid >= NT - 32) {      // vertical weights (the table of the BGR kernel: only W0 / W1 are read here)
+        const uint32_t f = tid - (NT - 32);
+        const uint32_t wlo = (32u - f) | (f << 8);
+        *reinterpret_cast<uint4*>(lut + f * LUT_STRIDE) =
+            make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
+    }
+    // this lane's share of the coordinate terms: (ad, bd) of a column for the first 128 lanes, (X0, Y0) of a row for the next THP
+    int tv0 = 0, tv1 = 0;
+    {
+        gtab_t Tg = tabs + (size_t)blockIdx.z * tab_stride + tab_ad;
+        if (tid < TW) {
+            const int cx = min(x0 + tid, x1);
+            tv0 = Tg[cx]; tv1 = Tg[c.dw + cx];
+        } else if (tid < TW + P::THP) {
+            const int r = min(y0 + (tid - TW), y1);
+            tv0 = Tg[2 * c.dw + r]; tv1 = Tg[2 * c.dw + c.dh + r];
+        }
+    }
+    // source box of the tile (the maps are monotone in x and in y separately)
+    int bx0a, by0, bw, bh;
+    bool fit;
+    {
+        const int sx00 = (Xa + ad0) >> 10, sx01 = (Xa + ad1) >> 10, sx10 = (Xb + ad0) >> 10, sx11 = (Xb + ad1) >> 10;
+        const int sy00 = (Ya + bd0) >> 10, sy01 = (Ya + bd1) >> 10, sy10 = (Yb + bd0) >> 10, sy11 = (Yb + bd1) >> 10;
+        const int rx0 = min(min(sx00, sx01), min(sx10, sx11)), rx1 = max(max(sx00, sx01), max(sx10, sx11));
+        const int ry0 = min(min(sy00, sy01), min(sy10, sy11)), ry1 = max(max(sy00, sy01), max(sy10, sy11));
+        const bool saturated = rx0 < -32768 || ry0 < -32768 || rx1 > 32767 || ry1 > 32767;
+        const int bx0 = max(rx0, -32768), bx1 = min(rx1, 32767) + 1;
+        by0 = max(ry0, -32768);
+        const int by1 = min(ry1, 32767) + 1;
+        bx0a = bx0 & ~3;
+        bw = bx1 - bx0a + 1;
+        bh = by1 - by0 + 1;
+        fit = !saturated && bw <= 136 && bh <= P::ROWS && c.border == VS_BORDER_BLACK;
+    }
+    if (fit) {
+        // ---- staging: chunks of 16 bytes, (row, chunk) = (i / CPR, i % CPR); all loads of a lane first, then its stores
+        constexpr int NCH = (P::ROWS * P::CPR + NT - 1) / NT;
+        const int total = bh * P::CPR;
+        const long long rowbytes = (long long)c.sw * CN;
+        uint4 d[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const int i = tid + NT * k;
+            d[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < total) {
+                const int r = i / P::CPR, ch = i - r * P::CPR;
+                const int y = by0 + r;
+                const long long xb = (long long)bx0a * CN + 16 * ch;          // byte column of the chunk in the source row
+                if ((unsigned)y < (unsigned)c.sh) {
+                    const uint8_t* row = src + (size_t)y * c.sstride;
+                    if (xb >= 0 && xb + 16 <= rowbytes && c.src_aligned) {
+                        d[k] = *reinterpret_cast<const uint4*>(row + xb);       // 4-byte aligned: bx0a is a multiple of 4 pixels
+                    } else if (xb + 16 > 0 && xb < rowbytes) {
+                        uint32_t w[4] = {0u, 0u, 0u, 0u};
+                        for (int b = 0; b < 16; b++) {
+                            const long long xx = xb + b;
+                            if (xx >= 0 && xx < rowbytes) w[b >> 2] |= (uint32_t)row[xx] << (8 * (b & 3));
+                        }
+                        d[k] = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const int i = tid + NT * k;
+            if (i < total) *reinterpret_cast<uint4*>(tile + 16 * i) = d[k];       // row * PB + 16 * chunk = 16 * i
+        }
+    }
+    // the terms, relative to the staged box for the fast path
+    {
+        const int subx = fit ? bx0a << 10 : 0, suby = fit ? by0 << 10 : 0;
+        if (tid < TW) { s_tab[tid] = tv0; s_tab[TW + tid] = tv1; }
+        else if (tid < TW + P::THP) { s_tab[2 * TW + (tid - TW)] = tv0 - subx; s_tab[2 * TW + P::THP + (tid - TW)] = tv1 - suby; }
+    }
+    __syncthreads();
+    const int* s_ad = s_tab;
+    const int* s_bd = s_tab + TW;
+    const int* s_x0 = s_tab + 2 * TW;
+    const int* s_y0 = s_tab + 2 * TW + P::THP;
+    if (!fit) {
+        // direct path (emit_rows works on 16 rows): no staging
+        for (int j = 0; y0 + TH * j <= y1; j++)
+            emit_rows<CN, false>(c, src, dst, nullptr, s_ad, s_bd, s_x0 + TH * j, s_y0 + TH * j, x0, y0 + TH * j, x1, min(y0 + TH * j + TH - 1, y1),
+                                 bx0a, by0, bw, tid);
+        return;
+    }
+    // ---- output
+    const int L = tid & 31, ty = tid >> 5;
+    uint32_t* wb = obuf + (tid >> 6) * (2 * TW) + ((tid >> 5) & 1) * TW;
+    int ad[4], bd[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ad[i] = s_ad[L + 32 * i]; bd[i] = s_bd[L + 32 * i]; }
+    const bool whole = c.dst_aligned && x1 - x0 == TW - 1;
+    for (int r = 0; r < P::THP / TYN; r++) {
+        const int yl = ty + TYN * r;
+        const int X0 = s_x0[yl], Y0 = s_y0[yl];
+        uint32_t res[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int SX = X0 + ad[i], SY = Y0 + bd[i];                  // 1/1024 px, relative to the staged box
+            const int addr = __mul24(SY >> 10, P::PB) + (SX >> 10) * CN;  // byte of the upper-left tap
+            const uint32_t sh = (uint32_t)addr & 3u;
+            const uint2 t = *reinterpret_cast<const uint2*>(tile + (addr & ~3));
+            const uint2 b = *reinterpret_cast<const uint2*>(tile + (addr & ~3) + P::PB);
+            const uint32_t top = __builtin_amdgcn_alignbyte(t.y, t.x, sh), bot = __builtin_amdgcn_alignbyte(b.y, b.x, sh);
+            const uint32_t fx = ((uint32_t)SX >> 5) & 31u;
+            const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
+            if (CN == 1) {
+                const uint32_t wx = __umul24(fx, 255u) + 32u;             // (32 - fx) | fx << 8
+                res[i] = __float_as_uint(vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy)) & 255u;
+            } else {
+                const uint32_t wu = __umul24(fx, 65535u) + 32u;           // (32 - fx) | fx << 16: against bytes 0 and 2 (U0, U1)
+                const uint32_t wv = wu << 8;                              // against bytes 1 and 3 (V0, V1)
+                const float mu = vlerp(__builtin_amdgcn_udot4(top, wu, 0u, false), __builtin_amdgcn_udot4(bot, wu, 0u, false), wy);
+                const float mv = vlerp(__builtin_amdgcn_udot4(top, wv, 0u, false), __builtin_amdgcn_udot4(bot, wv, 0u, false), wy);
+                res[i] = __builtin_amdgcn_perm(__float_as_uint(mv), __float_as_uint(mu), 0x0C0C0400u);     // (U, V, 0, 0)
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) wb[L + 32 * i] = res[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint4 q = *reinterpret_cast<const uint4*>(&wb[4 * L]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int y = y0 + yl, x = x0 + 4 * L;
+        if (y > y1 || x > x1) continue;
+        uint8_t* dp = dst + (size_t)y * c.dstride + (size_t)x * CN;
+        if (whole || (c.dst_aligned && x + 3 <= x1)) {
+            if (CN == 1) {
+                __builtin_nontemporal_store(q.x | (q.y << 8) | (q.z << 16) | (q.w << 24), reinterpret_cast<uint32_t*>(dp));
+            } else {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_nontemporal_store(u32x2{q.x | (q.y << 16), q.z | (q.w << 16)}, reinterpret_cast<u32x2*>(dp));
+            }
+        } else {
+            const uint32_t o[4] = {q.x, q.y, q.z, q.w};
+            for (int i = 0; i < 4; i++) {
+                if (x + i > x1) break;
+                for (int k = 0; k < CN; k++) dp[i * CN + k] = (uint8_t)(o[i] >> (8 * k));
+            }
+        }
+    }
+}
+
 // Ints of table workspace per frame of dw x dh (see warp_tables_kernel).
 inline int tab_stride_of(int dw, int dh) { return tab_layout(dw, dh).stride; }
 
 // VS_WARP_TAB_KERNEL=0: BGR8 launches with tables take the general kernel as well (A/B measurements)
 bool tab_kernel_setting() {
     static const bool v = [] { const char* e = std::getenv("VS_WARP_TAB_KERNEL"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+// VS_WARP_PLANE_KERNEL=0: one- and two-channel launches with tables take the general kernel (A/B measurements)
+bool plane_kernel_setting() {
+    static const bool v = [] { const char* e = std::getenv("VS_WARP_PLANE_KERNEL"); return !(e && e[0] == '0'); }();
     return v;
 }
 
@@ -803,6 +1014,11 @@ void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, int what, hipStream_t s
         if (CN == 3 && packs && tab_kernel_setting()) {
             // 10 dwords of arguments: all of them among the 14 the hardware preloads into scalar registers
             hipLaunchKernelGGL(warp_tab_kernel, grid, dim3(NT), 0, st, (gtab_t)a.tabs, a.tab_stride, a.tab_row, a.tab_ad, (uint32_t)a.c.sstride,
+                               (uint32_t)a.c.dstride, (uint32_t)a.c.sw | (uint32_t)a.c.sh << 16, (uint32_t)a.c.dw | (uint32_t)a.c.dh << 16,
+                               (uint32_t)(a.c.src_aligned ? 1 : 0) | (uint32_t)(a.c.dst_aligned ? 2 : 0) | (uint32_t)a.c.border << 2);
+        } else if (CN != 3 && packs && a.c.border == VS_BORDER_BLACK && plane_kernel_setting()) {
+            const dim3 pg(grid.x, (a.c.dh + PlaneCfg<CN>::THP - 1) / PlaneCfg<CN>::THP, grid.z);
+            hipLaunchKernelGGL((warp_plane_kernel<(CN == 3 ? 1 : CN)>), pg, dim3(NT), 0, st, (gtab_t)a.tabs, a.tab_stride, a.tab_row, a.tab_ad, (uint32_t)a.c.sstride,
                                (uint32_t)a.c.dstride, (uint32_t)a.c.sw | (uint32_t)a.c.sh << 16, (uint32_t)a.c.dw | (uint32_t)a.c.dh << 16,
                                (uint32_t)(a.c.src_aligned ? 1 : 0) | (uint32_t)(a.c.dst_aligned ? 2 : 0) | (uint32_t)a.c.border << 2);
         } else {

@@ -307,10 +307,11 @@ class VsLib:
         self.check(self.lib.vs_dev_sync())
 
     # ---- stage operators, numpy in / numpy out (device round trip) ----------
-    def warp_affine(self, img, M):
-        """img: (h,w[,3]) or (b,h,w,3) uint8; M: (6,) or (b,6)."""
+    def warp_affine(self, img, M, batch=None):
+        """img: (h,w[,3]) or (b,h,w,3) uint8; M: (6,) or (b,6).  batch=True / False settles what a 3-d array is: b planes of
+        one channel, or one image of shape[2] channels."""
         img = np.ascontiguousarray(img)
-        batched = img.ndim == 4 or (img.ndim == 3 and img.shape[2] not in (1, 3))
+        batched = img.ndim == 4 or (img.ndim == 3 and (img.shape[2] not in (1, 3) if batch is None else batch))
         if img.ndim == 2:
             b, (h, w), cn = 1, img.shape, 1
         elif img.ndim == 3 and not batched:
