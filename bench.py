@@ -252,7 +252,7 @@ def config2(vs, device, args):
     ss.sync()
     dt = time.perf_counter() - t0
     fo = ss.frames_out() - f0
-    roof, _, _ = warp_roofline(ss, 2.0 * nv[0].nbytes, fo, "warp_affine_kernel<1> + <2> (Y and interleaved UV plane)")
+    roof, _, _ = warp_roofline(ss, 2.0 * nv[0].nbytes, fo, "warp_plane_kernel<1> + <2> (Y and interleaved UV plane)")
     out["nv12_stabilize"] = {"value": round(fo / dt, 1), "unit": "frames/s", "batch": BT, "timed_frames": fo, "roofline": roof}
     ss.close()
     # (b) the reference's order of operators on a 4K BGR frame: roll correction -> stabilize -> auto zoom/crop (each
