@@ -836,11 +836,12 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
         ad0 = cc[4]; ad1 = cc[5]; bd0 = cc[6]; bd1 = cc[7];
         Xa = r0[0]; Ya = r0[2]; Xb = r1[1]; Yb = r1[3];
     }
-    if (tid >= NT - 32) {      // vertical weights (the table of the BGR kernel: only W0 / W1 are read here)
+    if (tid >= NT - 32) {      // weight table, one 32-byte entry per 1/32-px fraction f: {wlo, -, W0, W1, wu, wv}
         const uint32_t f = tid - (NT - 32);
-        const uint32_t wlo = (32u - f) | (f << 8);
+        const uint32_t wlo = (32u - f) | (f << 8), wu = (32u - f) | (f << 16);
         *reinterpret_cast<uint4*>(lut + f * LUT_STRIDE) =
             make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
+        *reinterpret_cast<uint2*>(lut + f * LUT_STRIDE + 16) = make_uint2(wu, wu << 8);
     }
     // this lane's share of the coordinate terms: (ad, bd) of a column for the first 128 lanes, (X0, Y0) of a row for the next THP
     int tv0 = 0, tv1 = 0;
@@ -891,7 +892,8 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
                         d[k] = *reinterpret_cast<const uint4*>(row + xb);       // 4-byte aligned: bx0a is a multiple of 4 pixels
                     } else if (xb + 16 > 0 && xb < rowbytes) {
                         uint32_t w[4] = {0u, 0u, 0u, 0u};
-                        for (int b = 0; b < 16; b++) {
+#pragma unroll
+                        for (int b = 0; b < 16; b++) {          // (unrolled: w[] stays in registers)
                             const long long xx = xb + b;
                             if (xx >= 0 && xx < rowbytes) w[b >> 2] |= (uint32_t)row[xx] << (8 * (b & 3));
                         }
@@ -943,16 +945,18 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
             const uint2 t = *reinterpret_cast<const uint2*>(tile + (addr & ~3));
             const uint2 b = *reinterpret_cast<const uint2*>(tile + (addr & ~3) + P::PB);
             const uint32_t top = __builtin_amdgcn_alignbyte(t.y, t.x, sh), bot = __builtin_amdgcn_alignbyte(b.y, b.x, sh);
-            const uint32_t fx = ((uint32_t)SX >> 5) & 31u;
+            // the weights from the table, indexed with the fraction bits in place (coordinate & 0x3E0): LDS reads are free
+            // here, the kernel is VALU-bound
+            const uint8_t* lx = lut + (SX & 0x3E0);
             const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
             if (CN == 1) {
-                const uint32_t wx = __umul24(fx, 255u) + 32u;             // (32 - fx) | fx << 8
-                res[i] = __float_as_uint(vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy)) & 255u;
+                const uint32_t wx = *reinterpret_cast<const uint32_t*>(lx);                // (32 - fx) | fx << 8
+                // (the byte is picked out when the row is packed)
+                res[i] = __float_as_uint(vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy));
             } else {
-                const uint32_t wu = __umul24(fx, 65535u) + 32u;           // (32 - fx) | fx << 16: against bytes 0 and 2 (U0, U1)
-                const uint32_t wv = wu << 8;                              // against bytes 1 and 3 (V0, V1)
-                const float mu = vlerp(__builtin_amdgcn_udot4(top, wu, 0u, false), __builtin_amdgcn_udot4(bot, wu, 0u, false), wy);
-                const float mv = vlerp(__builtin_amdgcn_udot4(top, wv, 0u, false), __builtin_amdgcn_udot4(bot, wv, 0u, false), wy);
+                const uint2 w = *reinterpret_cast<const uint2*>(lx + 16);                  // wu: against bytes 0 and 2 (U0, U1); wv: 1 and 3
+                const float mu = vlerp(__builtin_amdgcn_udot4(top, w.x, 0u, false), __builtin_amdgcn_udot4(bot, w.x, 0u, false), wy);
+                const float mv = vlerp(__builtin_amdgcn_udot4(top, w.y, 0u, false), __builtin_amdgcn_udot4(bot, w.y, 0u, false), wy);
                 res[i] = __builtin_amdgcn_perm(__float_as_uint(mv), __float_as_uint(mu), 0x0C0C0400u);     // (U, V, 0, 0)
             }
         }
@@ -969,7 +973,8 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
         uint8_t* dp = dst + (size_t)y * c.dstride + (size_t)x * CN;
         if (whole || (c.dst_aligned && x + 3 <= x1)) {
             if (CN == 1) {
-                __builtin_nontemporal_store(q.x | (q.y << 8) | (q.z << 16) | (q.w << 24), reinterpret_cast<uint32_t*>(dp));
+                const uint32_t lo = __builtin_amdgcn_perm(q.y, q.x, 0x0C0C0400u), hi = __builtin_amdgcn_perm(q.w, q.z, 0x0C0C0400u);   // low bytes
+                __builtin_nontemporal_store(__builtin_amdgcn_perm(hi, lo, 0x05040100u), reinterpret_cast<uint32_t*>(dp));
             } else {
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 __builtin_nontemporal_store(u32x2{q.x | (q.y << 16), q.z | (q.w << 16)}, reinterpret_cast<u32x2*>(dp));
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
             const uint32_t o[4] = {q.x, q.y, q.z, q.w};
             for (int i = 0; i < 4; i++) {
                 if (x + i > x1) break;
-                for (int k = 0; k < CN; k++) dp[i * CN + k] = (uint8_t)(o[i] >> (8 * k));
+                for (int k = 0; k < CN; k++) dp[i * CN + k] = (uint8_t)(o[i] >> (8 * k));     // (one channel: the low byte of the float's bits)
             }
         }
     }
