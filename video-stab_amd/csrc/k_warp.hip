@@ -792,8 +792,8 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
 //             dword, for the upper and the lower tap row;
 //   blend     v_dot4 against ((32-f) | f << 8) (one channel) or ((32-f) | f << 16, and << 8 for V) = the weights as one
 //             multiply-add of f; vertical lerp in fp32 on denormals as in the BGR kernel;
-//   output    lane L of a 32-lane row takes pixels L, L+32, L+64, L+96 (conflict-free LDS reads), the row is transposed
-//             through the per-wave buffer and leaves as one 4- / 8-byte store per lane.
+//   output    lane L of a 32-lane row takes the consecutive pixels 4L .. 4L+3 (with a byte-wide box neighbouring lanes then
+//             read neighbouring LDS dwords) and stores its 4 / 8 bytes.
 // It shares the per-frame coordinate tables with the other kernels (the tables know tiles of 16 rows: the corner terms of
 // a taller tile come from the records of its first and last 16 rows).  A box that does not fit the staging area (large
 // rotations or zooms) takes emit_rows' direct path, 16 rows at a time.
@@ -809,8 +809,7 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
                                                         uint32_t swh, uint32_t dwh, uint32_t flags) {
     typedef PlaneCfg<CN> P;
     __shared__ __attribute__((aligned(16))) uint8_t tile[P::ROWS * P::PB];
-    __shared__ __attribute__((aligned(16))) uint32_t obuf[OBUF];
-    __shared__ int s_tab[2 * TW + 2 * P::THP];           // ad[128] bd[128] x0[THP] y0[THP]
+    __shared__ __attribute__((aligned(16))) int s_tab[2 * TW + 2 * P::THP];           // ad[128] bd[128] x0[THP] y0[THP]
     __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
     typedef const __attribute__((address_space(4))) int32_t* cptr;
     typedef __attribute__((address_space(1))) uint8_t* gptr;
@@ -836,12 +835,11 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
         ad0 = cc[4]; ad1 = cc[5]; bd0 = cc[6]; bd1 = cc[7];
         Xa = r0[0]; Ya = r0[2]; Xb = r1[1]; Yb = r1[3];
     }
-    if (tid >= NT - 32) {      // weight table, one 32-byte entry per 1/32-px fraction f: {wlo, -, W0, W1, wu, wv}
+    if (tid >= NT - 32) {      // vertical weights (the table of the BGR kernel: only W0 / W1 are read here)
         const uint32_t f = tid - (NT - 32);
-        const uint32_t wlo = (32u - f) | (f << 8), wu = (32u - f) | (f << 16);
+        const uint32_t wlo = (32u - f) | (f << 8);
         *reinterpret_cast<uint4*>(lut + f * LUT_STRIDE) =
             make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
-        *reinterpret_cast<uint2*>(lut + f * LUT_STRIDE + 16) = make_uint2(wu, wu << 8);
     }
     // this lane's share of the coordinate terms: (ad, bd) of a column for the first 128 lanes, (X0, Y0) of a row for the next THP
     int tv0 = 0, tv1 = 0;
@@ -926,13 +924,20 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
                                  bx0a, by0, bw, tid);
         return;
     }
-    // ---- output
+    // ---- output.  Lane L of a 32-lane row takes the four CONSECUTIVE pixels 4L .. 4L+3: with the box staged as bytes that puts
+    // neighbouring lanes on neighbouring LDS dwords (the BGR kernel, one dword per staged pixel, needs the stride-32 mapping and
+    // a transposition for that), and the lane's four results are its 4 / 8 output bytes.  The kernel is bound by LDS
+    // bandwidth (per pixel: two 8-byte tap reads and the 8 bytes of vertical weights), so nothing else goes through LDS: the
+    // horizontal weights are one multiply-add of the fraction.
     const int L = tid & 31, ty = tid >> 5;
-    uint32_t* wb = obuf + (tid >> 6) * (2 * TW) + ((tid >> 5) & 1) * TW;
     int ad[4], bd[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { ad[i] = s_ad[L + 32 * i]; bd[i] = s_bd[L + 32 * i]; }
-    const bool whole = c.dst_aligned && x1 - x0 == TW - 1;
+    {
+        const int4 a4 = *reinterpret_cast<const int4*>(s_ad + 4 * L), b4 = *reinterpret_cast<const int4*>(s_bd + 4 * L);
+        ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
+        bd[0] = b4.x; bd[1] = b4.y; bd[2] = b4.z; bd[3] = b4.w;
+    }
+    const int x = x0 + 4 * L;
+    const bool vec = c.dst_aligned && x + 3 <= x1;
     for (int r = 0; r < P::THP / TYN; r++) {
         const int yl = ty + TYN * r;
         const int X0 = s_x0[yl], Y0 = s_y0[yl];
@@ -945,45 +950,34 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
             const uint2 t = *reinterpret_cast<const uint2*>(tile + (addr & ~3));
             const uint2 b = *reinterpret_cast<const uint2*>(tile + (addr & ~3) + P::PB);
             const uint32_t top = __builtin_amdgcn_alignbyte(t.y, t.x, sh), bot = __builtin_amdgcn_alignbyte(b.y, b.x, sh);
-            // the weights from the table, indexed with the fraction bits in place (coordinate & 0x3E0): LDS reads are free
-            // here, the kernel is VALU-bound
-            const uint8_t* lx = lut + (SX & 0x3E0);
+            const uint32_t fx = ((uint32_t)SX >> 5) & 31u;
             const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
             if (CN == 1) {
-                const uint32_t wx = *reinterpret_cast<const uint32_t*>(lx);                // (32 - fx) | fx << 8
-                // (the byte is picked out when the row is packed)
+                const uint32_t wx = __umul24(fx, 255u) + 32u;             // (32 - fx) | fx << 8
                 res[i] = __float_as_uint(vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy));
             } else {
-                const uint2 w = *reinterpret_cast<const uint2*>(lx + 16);                  // wu: against bytes 0 and 2 (U0, U1); wv: 1 and 3
-                const float mu = vlerp(__builtin_amdgcn_udot4(top, w.x, 0u, false), __builtin_amdgcn_udot4(bot, w.x, 0u, false), wy);
-                const float mv = vlerp(__builtin_amdgcn_udot4(top, w.y, 0u, false), __builtin_amdgcn_udot4(bot, w.y, 0u, false), wy);
+                const uint32_t wu = __umul24(fx, 65535u) + 32u;           // (32 - fx) | fx << 16: against bytes 0 and 2 (U0, U1)
+                const uint32_t wv = wu << 8;                              // against bytes 1 and 3 (V0, V1)
+                const float mu = vlerp(__builtin_amdgcn_udot4(top, wu, 0u, false), __builtin_amdgcn_udot4(bot, wu, 0u, false), wy);
+                const float mv = vlerp(__builtin_amdgcn_udot4(top, wv, 0u, false), __builtin_amdgcn_udot4(bot, wv, 0u, false), wy);
                 res[i] = __builtin_amdgcn_perm(__float_as_uint(mv), __float_as_uint(mu), 0x0C0C0400u);     // (U, V, 0, 0)
             }
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) wb[L + 32 * i] = res[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint4 q = *reinterpret_cast<const uint4*>(&wb[4 * L]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int y = y0 + yl, x = x0 + 4 * L;
+        const int y = y0 + yl;
         if (y > y1 || x > x1) continue;
         uint8_t* dp = dst + (size_t)y * c.dstride + (size_t)x * CN;
-        if (whole || (c.dst_aligned && x + 3 <= x1)) {
+        if (vec) {
             if (CN == 1) {
-                const uint32_t lo = __builtin_amdgcn_perm(q.y, q.x, 0x0C0C0400u), hi = __builtin_amdgcn_perm(q.w, q.z, 0x0C0C0400u);   // low bytes
+                const uint32_t lo = __builtin_amdgcn_perm(res[1], res[0], 0x0C0C0400u), hi = __builtin_amdgcn_perm(res[3], res[2], 0x0C0C0400u);   // low bytes
                 __builtin_nontemporal_store(__builtin_amdgcn_perm(hi, lo, 0x05040100u), reinterpret_cast<uint32_t*>(dp));
             } else {
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                __builtin_nontemporal_store(u32x2{q.x | (q.y << 16), q.z | (q.w << 16)}, reinterpret_cast<u32x2*>(dp));
+                __builtin_nontemporal_store(u32x2{res[0] | (res[1] << 16), res[2] | (res[3] << 16)}, reinterpret_cast<u32x2*>(dp));
             }
         } else {
-            const uint32_t o[4] = {q.x, q.y, q.z, q.w};
             for (int i = 0; i < 4; i++) {
                 if (x + i > x1) break;
-                for (int k = 0; k < CN; k++) dp[i * CN + k] = (uint8_t)(o[i] >> (8 * k));     // (one channel: the low byte of the float's bits)
+                for (int k = 0; k < CN; k++) dp[i * CN + k] = (uint8_t)(res[i] >> (8 * k));     // (one channel: the low byte of the float's bits)
             }
         }
     }
