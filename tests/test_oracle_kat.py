@@ -331,3 +331,21 @@ def test_threaded_stages_do_not_depend_on_the_thread_count(oracle):
     assert len(one) == len(many) > 6
     for a, b in zip(one, many):
         assert np.array_equal(a, b)
+
+
+def test_oracle_snapshot(oracle):
+    """The oracle is the parity target of every GPU test: its outputs on fixed inputs are pinned by digest
+    (tests/golden/oracle_snapshot.json, made by tests/golden/make_oracle_snapshot.py), so that an edit of oracle/ that
+    changes results cannot go unnoticed.  A deliberate correction regenerates the file in the same commit."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_snapshot", os.path.join(here, "make_oracle_snapshot.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "oracle_snapshot.json")))
+    got = mod.snapshot(oracle)
+    assert sorted(got) == sorted(want)
+    changed = [k for k in want if got[k] != want[k]]
+    assert not changed, "oracle outputs changed for: %s" % ", ".join(changed)
