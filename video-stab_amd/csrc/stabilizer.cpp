@@ -102,6 +102,8 @@ struct vs_stab {
     hipStream_t st_det = nullptr;
     hipStream_t st_warp = nullptr;  // deferred (batched) warps, high priority
     bool shared_streams = false;    // the four streams belong to the per-device pool
+    hipEvent_t ev_dev_warp = nullptr;   // the pool's: recorded behind the last batched warp of ANY instance on this device
+    bool* dev_warp_valid = nullptr;
     std::string err;
     // geometry, fixed by the first frame
     bool allocated = false;
@@ -784,6 +786,7 @@ int launch_ready(vs_stab* s) {
         rc = ready_launches(s, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL);
     }
     if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
+    if (s->ev_dev_warp && hipEventRecord(s->ev_dev_warp, st) == hipSuccess) *s->dev_warp_valid = true;
     for (int i = 0; i < R.n; i++) {
         const int slot = R.slots[i];
         if (slot < 0) continue;          // zero-copy: the frame is the caller's
@@ -953,7 +956,11 @@ int run_batch(vs_stab* s) {
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(k - 2) % 4], 0));
         if (s->bdet_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(k - 2) % 4], 0));
     }
-    if (s->last_warp_set >= 0 && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr) {
+    if (s->ev_dev_warp && *s->dev_warp_valid && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr && std::getenv("VS_STAB_OWN_WARP_GUARD") == nullptr) {
+        // several instances share the streams: the last batched warp of ANY of them (the instances' launches interleave in
+        // the shared queues, so that is the one in front of this batch's kernels)
+        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_dev_warp, 0));
+    } else if (s->last_warp_set >= 0 && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr) {
         // keep the HBM-bound warp alone on the GPU even when the host runs batches ahead: this batch's gray /
         // pyramid / detection kernels start after the warps issued during the previous run_batch (batch k-2's)
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_warp[s->last_warp_set], 0));
@@ -1282,6 +1289,8 @@ int create_events(vs_stab* s) {
 namespace {
 struct StreamPool {
     hipStream_t st = nullptr, pre = nullptr, det = nullptr, warp = nullptr;
+    hipEvent_t ev_warp = nullptr;       // behind the last batched warp of any instance
+    bool warp_valid = false;
     int refs = 0;
 };
 std::mutex g_pool_mutex;
@@ -1316,9 +1325,12 @@ hipError_t acquire_streams(vs_stab* s) {
     if (p.refs == 0) {
         hipError_t e = make_streams(&p.st, &p.pre, &p.det, &p.warp);
         if (e != hipSuccess) return e;
+        if (hipEventCreateWithFlags(&p.ev_warp, hipEventDisableTiming) != hipSuccess) p.ev_warp = nullptr;
+        p.warp_valid = false;
     }
     p.refs++;
     s->st = p.st; s->st_pre = p.pre; s->st_det = p.det; s->st_warp = p.warp;
+    s->ev_dev_warp = p.ev_warp; s->dev_warp_valid = &p.warp_valid;
     s->shared_streams = true;
     return hipSuccess;
 }
@@ -1335,6 +1347,7 @@ void release_streams(vs_stab* s) {
     StreamPool& p = g_pools[s->device];
     if (--p.refs == 0) {
         (void)hipStreamDestroy(p.st); (void)hipStreamDestroy(p.pre); (void)hipStreamDestroy(p.det); (void)hipStreamDestroy(p.warp);
+        if (p.ev_warp) (void)hipEventDestroy(p.ev_warp);
         p = StreamPool();
     }
 }
