@@ -205,6 +205,23 @@ def test_virtual_canvas_temporal_fill(gpu, oracle, scale):
         assert worst == 0
 
 
+@pytest.mark.parametrize("extra", [dict(temporal_buffer_size=0), dict(temporal_buffer_size=1), dict(temporal_buffer_size=2),
+                                   dict(border_size=10, border_type=capi.BORDER_FADE, fade_alpha=0.4, fade_duration=3),
+                                   dict(canvas_blend_weight=0.0), dict(edge_blend_radius=0), dict(canvas_scale_factor=1.3, edge_blend_radius=400),
+                                   dict(crop_n_zoom=1, border_size=12)])
+def test_virtual_canvas_corner_settings(gpu, oracle, extra):
+    """Temporal buffers too short to fill from (0, 1) and just long enough (2); a fade border under the canvas (the canvas
+    replaces the warped frame, so the fade cannot be seen); a zero blend weight (nothing is ever the best fill); edge radii
+    of zero and larger than any region; crop-and-zoom, behind whose returns the reference never reaches the canvas."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 14, 192, 144, 10)
+    kw = dict(dict(adaptive_canvas_size=0, canvas_scale_factor=1.2, temporal_buffer_size=3), **extra)
+    outs, _ = _canvas_run(gpu, oracle, clip, **kw)
+    assert len(outs) == 10
+    for a, b in outs:
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        assert np.count_nonzero(d) <= max(2e-4 * d.size, 32), np.count_nonzero(d)
+
+
 def test_virtual_canvas_adaptive_scale_follows_the_motion(gpu, oracle):
     """calculateOptimalCanvasSize (:2281-2314): the scale is chosen once, from the largest of the last 30 transforms."""
     clip = synth.make_clip(synth.SEED_CONFIG1 + 13, 256, 192, 10, pan_q8=16 * 256)      # 60 analysis pixels per frame
