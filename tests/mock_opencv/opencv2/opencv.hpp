@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #define CV_8U 0
@@ -54,5 +55,26 @@ private:
     int type_ = CV_8UC3;
     std::shared_ptr<std::vector<unsigned char>> buf_;
 };
+
+// ---- capture side (tests/test_host_shims.py): a synthetic cv::VideoCapture and the little of imgproc vs::CamCap calls.
+// Source grammar: "mock:<w>x<h>:<frames>[:fail=<a>-<b>]" - frame k is filled with (k % 251); the reads numbered a..b
+// (counted per source string, across re-opens) fail.  A camera index opens "mock:64x48:1000000".  Anything else does not open.
+enum { CAP_ANY = 0, CAP_GSTREAMER = 1800, CAP_FFMPEG = 1900 };
+enum { CAP_PROP_FRAME_WIDTH = 3, CAP_PROP_FRAME_HEIGHT = 4, CAP_PROP_FPS = 5 };
+enum { COLOR_BGR2GRAY = 6, COLOR_BGR2HSV = 40, COLOR_BGR2YUV = 82 };
+class VideoCapture {
+public:
+    bool open(int, int = CAP_ANY) { return open(std::string("mock:64x48:1000000")); }
+    bool open(const std::string &src, int = CAP_ANY);
+    bool isOpened() const { return opened_; }
+    void release() { opened_ = false; }
+    bool read(Mat &m);
+    double get(int prop) const { return !opened_ ? 0.0 : prop == CAP_PROP_FRAME_WIDTH ? w_ : prop == CAP_PROP_FRAME_HEIGHT ? h_ : prop == CAP_PROP_FPS ? 25.0 : 0.0; }
+private:
+    bool opened_ = false;
+    int w_ = 0, h_ = 0, frames_ = 0, fail_a_ = -1, fail_b_ = -1;
+    std::string src_;
+};
+void cvtColor(const Mat &src, Mat &dst, int code);
 }  // namespace cv
 #endif
