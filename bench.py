@@ -190,16 +190,17 @@ def traffic_from_counters(vs, roof, frame_bytes):
 
 def host_api_rate(vs, device, params, frames, n_timed=240):
     """vs_stab_push: host frame in, host frame out (what vs::Stabilizer::stabilize(cv::Mat) calls) - PCIe both ways.
-    Three forms: pageable frames (numpy arrays as they come), page-locked frames (vs_host_alloc), and page-locked frames
-    with the host pipeline (vs_stab_set_host_pipeline: a call returns the previous call's frame)."""
+    Frames in pageable memory (numpy arrays as they come: what a cv::Mat holds) or page-locked (vs_host_alloc); the
+    synchronous call or the host pipeline (vs_stab_set_host_pipeline, VS_STAB_HOST_PIPELINE=1 for the C++ class: a call
+    returns the previous call's frame, its download runs beside this call's upload)."""
     order = clip_order(len(frames), 64 + n_timed)
 
-    def run(pinned, pipeline):
+    def run(pinned, pipeline, fresh_out=False):
         s = vs.stabilizer(params, device=device)
         if pipeline:
             s.set_host_pipeline(True)
         src = frames
-        out = None
+        out = None if fresh_out else np.empty_like(frames[0])
         bufs = []
         if pinned:
             bufs = [capi.HostBuf(vs, f.shape) for f in frames] + [capi.HostBuf(vs, frames[0].shape)]
@@ -218,14 +219,17 @@ def host_api_rate(vs, device, params, frames, n_timed=240):
         s.close()
         for b in bufs:
             b.free()
-        return round(n_out / dt, 1), round(dt / max(n_out, 1) * 1e3, 4)
-    pg, pn, pp = run(False, False), run(True, False), run(True, True)
-    return {"value": pg[0], "unit": "frames/s", "ms_per_frame": pg[1],
-            "what": "vs_stab_push, %d calls: host frame in, stabilized host frame out per call (H2D + D2H inside the call), pageable numpy frames" % n_timed,
-            "page_locked": {"value": pn[0], "ms_per_frame": pn[1], "what": "the same with frames in page-locked memory (vs_host_alloc)"},
-            "page_locked_host_pipeline": {"value": pp[0], "ms_per_frame": pp[1],
-                                          "what": "page-locked frames and vs_stab_set_host_pipeline: a call returns the frame the previous call "
-                                                  "computed; its download overlaps this call's upload, the device work runs behind the call"}}
+        return {"value": round(n_out / dt, 1), "ms_per_frame": round(dt / max(n_out, 1) * 1e3, 4)}
+    piped = run(False, True)
+    return {"value": piped["value"], "unit": "frames/s", "ms_per_frame": piped["ms_per_frame"],
+            "what": "vs_stab_push with the host pipeline, %d calls: PAGEABLE host frame in, stabilized frame into the caller's "
+                    "(pageable) buffer per call - H2D + D2H inside the call, the download of the previous result issued by the "
+                    "instance's helper thread beside this call's upload" % n_timed,
+            "pageable_host_pipeline_fresh_output": dict(run(False, True, True), what="the same, a newly allocated output array per call (first-touch page faults inside the call)"),
+            "pageable_synchronous": dict(run(False, False), what="the synchronous call (a call returns the frame it made due): upload, device work and download in a row"),
+            "pageable_synchronous_fresh_output": dict(run(False, False, True), what="the same, a newly allocated output array per call (round 1's figure: 1 985)"),
+            "page_locked_synchronous": dict(run(True, False), what="synchronous call, frames in page-locked memory (vs_host_alloc)"),
+            "page_locked_host_pipeline": dict(run(True, True), what="host pipeline, frames in page-locked memory")}
 
 
 def config2(vs, device, args):

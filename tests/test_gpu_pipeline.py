@@ -831,6 +831,39 @@ def test_host_pipeline_returns_the_same_frames_one_call_later(gpu):
     pin_in.free(); pin_out.free()
 
 
+def test_host_pipeline_helper_threads_of_several_instances(gpu):
+    """Pageable output buffers: the download of the previous result is issued by the instance's helper thread, beside the
+    caller's upload.  Four pipelined instances fed in turn (four helper threads alive at once), made and destroyed twice:
+    every stream gets the frames of its own synchronous run."""
+    clips = [synth.make_clip(synth.SEED_CONFIG1 + 50 + g, 640, 360, 18) for g in range(4)]
+    p = gpu.params(smoothing_radius=5)
+    refs = []
+    for clip in clips:
+        s = gpu.stabilizer(p)
+        refs.append([r for r in (s.push(f) for f in clip) if r is not None])
+        s.close()
+    for _ in range(2):
+        stabs = [gpu.stabilizer(p) for _ in clips]
+        for s in stabs:
+            s.set_host_pipeline(True)
+        outs = [np.empty_like(clips[0][0]) for _ in clips]          # pageable, reused: a late download would show
+        got = [[] for _ in clips]
+        for k in range(18):
+            for g, s in enumerate(stabs):
+                r = s.push(clips[g][k], out=outs[g])
+                if r is not None:
+                    got[g].append(r.copy())
+        for g, s in enumerate(stabs):
+            r = s.flush(clips[g][0])                                 # the frame the last push computed
+            assert r is not None
+            got[g].append(r)
+            s.close()
+        for g in range(4):
+            assert len(got[g]) == len(refs[g]) == 14
+            for a, b in zip(got[g], refs[g]):
+                assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("extra", [dict(border_size=16, border_type=capi.BORDER_REFLECT), dict(border_size=9, border_type=capi.BORDER_REPLICATE),
                                    dict(border_size=12, border_type=capi.BORDER_WRAP), dict(border_size=16, border_type=capi.BORDER_REFLECT_101),
                                    dict(border_size=8, border_type=capi.BORDER_BLACK), dict(border_size=20, crop_n_zoom=1)])

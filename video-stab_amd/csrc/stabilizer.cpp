@@ -30,11 +30,13 @@
 #include <cstdlib>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
 
 #include "canvas.h"
+#include "host_helper.h"
 #include "traj_state.h"
 #include "vs_common.h"
 
@@ -176,6 +178,7 @@ struct vs_stab {
     uint8_t* d_hold[2] = {nullptr, nullptr};
     int hold_cur = 0, hold_w = 0, hold_h = 0;
     hipEvent_t ev_hold = nullptr;
+    std::unique_ptr<HostHelper> helper;     // issues the download when the caller's output buffer is pageable (push_host_pipelined)
     uint8_t* d_all = nullptr;           // one allocation for the small buffers
     vs_counters counters;
     // cross-stream dependencies
@@ -1472,9 +1475,35 @@ static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, si
     for (auto& hld : s->d_hold)
         if (!hld) S_HIP(s, hipMalloc((void**)&hld, s->out_bytes));
     const bool have_prev = s->hold_valid;
+    // A copy to or from PAGEABLE memory (the frames of a cv::Mat) keeps its caller inside hipMemcpy for the whole transfer -
+    // about 0.2 ms per direction at 1080p, through the runtime's bounce buffers -, so download and upload issued from this
+    // thread run one after the other: 2 520 frames/s against 4 730 with page-locked frames.  With a pageable output buffer the
+    // download is therefore issued by the instance's helper thread, beside this thread's upload (VS_STAB_HOST_HELPER=0: from
+    // this thread, as before).  (Staging both directions through page-locked buffers of our own with a pool of copy threads
+    // was measured first and lost to the runtime's path: scratch/README.md.)
+    static const bool use_helper = [] { const char* e = std::getenv("VS_STAB_HOST_HELPER"); return !(e && e[0] == '0'); }();
+    struct Join {           // the helper's job refers to the caller's buffer: no way out of this call without waiting for it
+        HostHelper* h = nullptr;
+        ~Join() { if (h) (void)h->wait(); }
+        int wait() { HostHelper* t = h; h = nullptr; return t ? t->wait() : 0; }
+    } join;
     if (have_prev) {       // the held result: on its way while this call's frame comes in
         S_HIP(s, hipStreamWaitEvent(s->st_warp, s->ev_hold, 0));
-        S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_hold[s->hold_cur ^ 1], orow, orow, orows, hipMemcpyDeviceToHost, s->st_warp));
+        const uint8_t* d_src = s->d_hold[s->hold_cur ^ 1];
+        if (use_helper && !host_ptr_page_locked(out)) {
+            if (!s->helper) s->helper.reset(new HostHelper);
+            const int dev = s->device;
+            hipStream_t stw = s->st_warp;
+            s->helper->start([=]() -> int {
+                hipError_t e = hipSetDevice(dev);
+                if (e == hipSuccess) e = hipMemcpy2DAsync(out, out_stride, d_src, orow, orow, orows, hipMemcpyDeviceToHost, stw);
+                if (e == hipSuccess) e = hipStreamSynchronize(stw);
+                return (int)e;
+            });
+            join.h = s->helper.get();
+        } else {
+            S_HIP(s, hipMemcpy2DAsync(out, out_stride, d_src, orow, orow, orows, hipMemcpyDeviceToHost, s->st_warp));
+        }
     }
     int slot;
     S_TRY(s, take_slot(s, &slot));
@@ -1482,7 +1511,8 @@ static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, si
     int now = 0;
     int rc = push_common(s, slot, nullptr, s->d_hold[s->hold_cur], orow, &now, false);
     S_HIP(s, hipStreamSynchronize(s->st_pre));        // the caller's frame has been consumed
-    if (have_prev) S_HIP(s, hipStreamSynchronize(s->st_warp));
+    if (join.h) S_HIP(s, (hipError_t)join.wait());
+    else if (have_prev) S_HIP(s, hipStreamSynchronize(s->st_warp));
     if (rc != VS_OK) return rc;
     s->hold_valid = now != 0;
     if (now) {
