@@ -230,7 +230,7 @@ struct vs_stab {
     size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0;
     uint8_t *d_lk_table[2] = {nullptr, nullptr}, *d_rs_table[2] = {nullptr, nullptr}, *d_gf_table = nullptr, *d_tail_table[2] = {nullptr, nullptr};
     ImgPair* d_pairs = nullptr;
-    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
+    hipEvent_t ev_bpre = nullptr, ev_bpre_nms = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
     bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
     int last_det_batch = -1;
     // what the debug getters read (last analysed frame)
@@ -788,7 +788,14 @@ int launch_ready(vs_stab* s) {
         StageScope t(s, VS_STAGE_WARP, st);
         rc = ready_launches(s, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL);
     }
-    if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
+    // (the batched warps run on `main`, like the tail that rewrites their maps: the instance's own event is only needed when
+    // it is the guard of the next batch's analysis kernels, i.e. without the pool's event)
+    static const bool own_guard = std::getenv("VS_STAB_OWN_WARP_GUARD") != nullptr || std::getenv("VS_STAB_ALL_EVENTS") != nullptr;
+    if (!s->ev_dev_warp || own_guard) {
+        if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
+    } else {
+        s->warp_valid[R.set] = false;
+    }
     if (s->ev_dev_warp && hipEventRecord(s->ev_dev_warp, st) == hipSuccess) *s->dev_warp_valid = true;
     for (int i = 0; i < R.n; i++) {
         const int slot = R.slots[i];
@@ -1098,12 +1105,22 @@ int run_batch(vs_stab* s) {
     s->bdet_valid[k % 4] = ndet > 0;
     // ---- main: tracking and hypothesis scoring of all frames, one launch each
     hipStream_t st = s->st;
-    S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
-    if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
     const bool wait_det = s->last_det_batch >= 0 && s->last_det_batch >= k - 1;
     const bool early = wait_det && s->last_det_batch == k && std::getenv("VS_STAB_WARP_AFTER_SELECT") == nullptr;
-    if (early) S_HIP(s, hipStreamWaitEvent(st, s->ev_bnms, 0));
-    else if (wait_det) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
+    // Every wait and every event record is a packet of its own in the hardware queue (about 4 us each between two kernels
+    // of `main`, the batch's critical chain): `pre`, which has slack at its end, waits for the detector's NMS and `main`
+    // waits for `pre` alone - one packet instead of two in front of the warps (VS_STAB_ALL_EVENTS=1: as before)
+    static const bool lean = std::getenv("VS_STAB_ALL_EVENTS") == nullptr;
+    if (early && lean) {
+        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bnms, 0));
+        S_HIP(s, hipEventRecord(s->ev_bpre_nms, s->st_pre));
+        S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre_nms, 0));
+    } else {
+        S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
+    }
+    if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
+    if (early && !lean) S_HIP(s, hipStreamWaitEvent(st, s->ev_bnms, 0));
+    else if (!early && wait_det) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
     // `main` has now waited for this batch's gray / pyramid work and the wide launches of its detection: the warps of the
     // PREVIOUS batch go out here, before this batch's tracking, with nothing but the corner selection (16 workgroups)
     // beside them on the GPU
@@ -1261,7 +1278,7 @@ void destroy_events(vs_stab* s) {
     for (auto& e : s->ev_slot) kill(e);
     kill(s->ev_first); kill(s->ev_hold);
     kill(s->ev_emit); kill(s->ev_warp[0]); kill(s->ev_warp[1]);
-    kill(s->ev_bpre); kill(s->ev_bgray); kill(s->ev_bnms);
+    kill(s->ev_bpre); kill(s->ev_bpre_nms); kill(s->ev_bgray); kill(s->ev_bnms);
     for (auto& e : s->ev_bdet) kill(e);
     for (auto& e : s->ev_blk) kill(e);
 }
@@ -1276,6 +1293,7 @@ int create_events(vs_stab* s) {
     S_HIP(s, mk(s->ev_first)); S_HIP(s, mk(s->ev_hold));
     S_HIP(s, mk(s->ev_emit)); S_HIP(s, mk(s->ev_warp[0])); S_HIP(s, mk(s->ev_warp[1]));
     S_HIP(s, mk(s->ev_bpre));
+    S_HIP(s, mk(s->ev_bpre_nms));
     S_HIP(s, mk(s->ev_bgray));
     S_HIP(s, mk(s->ev_bnms));
     for (auto& e : s->ev_bdet) S_HIP(s, mk(e));
