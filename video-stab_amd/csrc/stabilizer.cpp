@@ -230,8 +230,7 @@ struct vs_stab {
     size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0;
     uint8_t *d_lk_table[2] = {nullptr, nullptr}, *d_rs_table[2] = {nullptr, nullptr}, *d_gf_table = nullptr, *d_tail_table[2] = {nullptr, nullptr};
     ImgPair* d_pairs = nullptr;
-    hipEvent_t ev_bpre[4] = {}, ev_bpre_nms = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
-    bool blk_valid[4] = {false, false, false, false};     // ev_blk[i] was recorded for the batch that last used index i
+    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
     bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
     int last_det_batch = -1;
     // what the debug getters read (last analysed frame)
@@ -412,7 +411,6 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     s->d_pts.assign(nkp, nullptr); s->d_npts.assign(nkp, nullptr); s->pts_cap.assign(nkp, 0);
     s->items.assign(B, vs_stab::ItemBufs());
     s->bq.clear(); s->batch_id = 0; s->kp_cur = 0; s->kp_next = 1; s->last_det_batch = -1; s->ready.valid = false; s->last_warp_set = -1;
-    for (bool& v : s->blk_valid) v = false;
     for (auto& v : s->bdet_valid) v = false;
     // (the frame queue ring - 128 frames, 3.2 GB at 4K BGR8 - is allocated by the first push that copies a frame in: a
     // stream that only ever hands over device frames in zero-copy mode never needs it)
@@ -790,14 +788,7 @@ int launch_ready(vs_stab* s) {
         StageScope t(s, VS_STAGE_WARP, st);
         rc = ready_launches(s, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL);
     }
-    // (the batched warps run on `main`, like the tail that rewrites their maps: the instance's own event is only needed when
-    // it is the guard of the next batch's analysis kernels, i.e. without the pool's event)
-    static const bool own_guard = std::getenv("VS_STAB_OWN_WARP_GUARD") != nullptr || std::getenv("VS_STAB_ALL_EVENTS") != nullptr;
-    if (!s->ev_dev_warp || own_guard) {
-        if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
-    } else {
-        s->warp_valid[R.set] = false;
-    }
+    if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
     if (s->ev_dev_warp && hipEventRecord(s->ev_dev_warp, st) == hipSuccess) *s->dev_warp_valid = true;
     for (int i = 0; i < R.n; i++) {
         const int slot = R.slots[i];
@@ -957,14 +948,7 @@ int run_batch(vs_stab* s) {
     const int k = s->batch_id++;
     // host images of this batch's tables: the set batch k-4 used (its tail, the last reader of anything uploaded from it, has run
     // by now unless the host is four batches ahead of the GPU - then it waits here)
-    if (k >= 4) {
-        if (s->blk_valid[k % 4]) {
-            S_HIP(s, hipEventSynchronize(s->ev_blk[k % 4]));
-        } else {        // no event behind that tail (see the end of this function): the uploads from the set ran on `pre` and `det`
-            S_HIP(s, hipEventSynchronize(s->ev_bpre[k % 4]));
-            if (s->bdet_valid[k % 4]) S_HIP(s, hipEventSynchronize(s->ev_bdet[k % 4]));
-        }
-    }
+    if (k >= 4) S_HIP(s, hipEventSynchronize(s->ev_blk[k % 4]));
     uint8_t* hset = s->h_tables + (size_t)(k % 4) * s->h_set_bytes;
     ImgPair* h_pairs = reinterpret_cast<ImgPair*>(hset + s->ho_pairs);
     uint8_t *h_lk = hset + s->ho_lk, *h_rs = hset + s->ho_rs, *h_tail = hset + s->ho_tail, *h_gf = hset + s->ho_gf;
@@ -972,12 +956,10 @@ int run_batch(vs_stab* s) {
     // ---- pre: gray images and pyramids of all frames of the batch, one launch per stage and level
     if (k >= 2) {
         // ring reuse: these slots were read by the analysis two batches ago (npyr = 2*batch + 2)
-        // (without that event the warps of batch k-2, which came after its tail on `main`, are waited for below)
-        if (s->blk_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(k - 2) % 4], 0));
+        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(k - 2) % 4], 0));
         if (s->bdet_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(k - 2) % 4], 0));
     }
-    const bool pool_guard = s->ev_dev_warp && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr && std::getenv("VS_STAB_OWN_WARP_GUARD") == nullptr;
-    if (pool_guard && *s->dev_warp_valid) {
+    if (s->ev_dev_warp && *s->dev_warp_valid && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr && std::getenv("VS_STAB_OWN_WARP_GUARD") == nullptr) {
         // several instances share the streams: the last batched warp of ANY of them (the instances' launches interleave in
         // the shared queues, so that is the one in front of this batch's kernels)
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_dev_warp, 0));
@@ -1079,7 +1061,7 @@ int run_batch(vs_stab* s) {
                                                 s->lw[l], s->lw[l], s->lh[l], l < L ? s->lw[l + 1] : 0, s->st_pre));
         }
     }
-    S_HIP(s, hipEventRecord(s->ev_bpre[k % 4], s->st_pre));
+    S_HIP(s, hipEventRecord(s->ev_bpre, s->st_pre));
     // ---- det: every frame of the batch that re-detects, one launch per GFTT stage
     int ndet = 0;
     for (int i = 0; i < n; i++) {
@@ -1099,12 +1081,9 @@ int run_batch(vs_stab* s) {
         S_HIP(s, hipMemcpyAsync(s->d_gf_table, h_gf, gftt_item_bytes() * ndet, hipMemcpyHostToDevice, s->st_det));
         // keypoint buffers are recycled after B + 4 detections (two batches): the tracking of the batch before
         // the previous one must have read them (the GFTT scratch is only touched on this stream)
-        if (k >= 2) {
-            if (s->blk_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 2) % 4], 0));
-            else if (pool_guard && *s->dev_warp_valid) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_dev_warp, 0));   // behind that batch's warps
-        }
+        if (k >= 2) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 2) % 4], 0));
         S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 1));
-        S_HIP(s, hipStreamWaitEvent(s->st_det, std::getenv("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre[k % 4] : s->ev_bgray, 0));
+        S_HIP(s, hipStreamWaitEvent(s->st_det, std::getenv("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
         {
             StageScope t(s, VS_STAGE_GFTT, s->st_det);
             S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 2));   // :740-744: block size 3
@@ -1119,22 +1098,12 @@ int run_batch(vs_stab* s) {
     s->bdet_valid[k % 4] = ndet > 0;
     // ---- main: tracking and hypothesis scoring of all frames, one launch each
     hipStream_t st = s->st;
+    S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
+    if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
     const bool wait_det = s->last_det_batch >= 0 && s->last_det_batch >= k - 1;
     const bool early = wait_det && s->last_det_batch == k && std::getenv("VS_STAB_WARP_AFTER_SELECT") == nullptr;
-    // Every wait and every event record is a packet of its own in the hardware queue (about 4 us each between two kernels
-    // of `main`, the batch's critical chain): `pre`, which has slack at its end, waits for the detector's NMS and `main`
-    // waits for `pre` alone - one packet instead of two in front of the warps (VS_STAB_ALL_EVENTS=1: as before)
-    static const bool lean = std::getenv("VS_STAB_ALL_EVENTS") == nullptr;
-    if (early && lean) {
-        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bnms, 0));
-        S_HIP(s, hipEventRecord(s->ev_bpre_nms, s->st_pre));
-        S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre_nms, 0));
-    } else {
-        S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre[k % 4], 0));
-    }
-    if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
-    if (early && !lean) S_HIP(s, hipStreamWaitEvent(st, s->ev_bnms, 0));
-    else if (!early && wait_det) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
+    if (early) S_HIP(s, hipStreamWaitEvent(st, s->ev_bnms, 0));
+    else if (wait_det) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
     // `main` has now waited for this batch's gray / pyramid work and the wide launches of its detection: the warps of the
     // PREVIOUS batch go out here, before this batch's tracking, with nothing but the corner selection (16 workgroups)
     // beside them on the GPU
@@ -1161,16 +1130,12 @@ int run_batch(vs_stab* s) {
             StageScope t(s, VS_STAGE_TRAJ, st);
             S_TRY(s, launch_ransac_tail_batch(s->d_rs_table[dset], s->d_tail_table[dset], n, s->d_M, st));
         }
+        // the keypoint and pyramid buffers of this batch may be recycled (two batches on) once the tail, which still reads
+        // the points and their counts, has run
+        S_HIP(s, hipEventRecord(s->ev_blk[k % 4], st));
         // the warps of this batch wait for the next run_batch (or a drain)
         vs_stab::ReadyWarps& R = s->ready;
         R.n = (int)s->pend.size(); R.set = set; R.stride = s->pend_stride; R.valid = R.n > 0;
-        // The keypoint and pyramid buffers of this batch may be recycled (two batches on) once the tail, which still reads
-        // the points and their counts, has run.  When warps follow the tail on this stream and the pool's event is recorded
-        // behind them - the event the analysis kernels of batch k+2 wait for anyway - that event says so, and the record
-        // between the tail and the coordinate tables (one more packet on the critical chain, 6 us) is left out.
-        const bool by_warp = lean && R.valid && pool_guard;
-        if (!by_warp) S_HIP(s, hipEventRecord(s->ev_blk[k % 4], st));
-        s->blk_valid[k % 4] = !by_warp;
         for (int i = 0; i < R.n; i++) { R.srcs[i] = s->pend[i].src; R.dsts[i] = s->pend[i].dst; R.slots[i] = s->pend[i].slot; }
         s->pend.clear();
         if (R.valid) s->pend_set = set ^ 1;
@@ -1296,8 +1261,7 @@ void destroy_events(vs_stab* s) {
     for (auto& e : s->ev_slot) kill(e);
     kill(s->ev_first); kill(s->ev_hold);
     kill(s->ev_emit); kill(s->ev_warp[0]); kill(s->ev_warp[1]);
-    for (auto& e : s->ev_bpre) kill(e);
-    kill(s->ev_bpre_nms); kill(s->ev_bgray); kill(s->ev_bnms);
+    kill(s->ev_bpre); kill(s->ev_bgray); kill(s->ev_bnms);
     for (auto& e : s->ev_bdet) kill(e);
     for (auto& e : s->ev_blk) kill(e);
 }
@@ -1311,8 +1275,7 @@ int create_events(vs_stab* s) {
     for (auto& e : s->ev_slot) S_HIP(s, mk(e));
     S_HIP(s, mk(s->ev_first)); S_HIP(s, mk(s->ev_hold));
     S_HIP(s, mk(s->ev_emit)); S_HIP(s, mk(s->ev_warp[0])); S_HIP(s, mk(s->ev_warp[1]));
-    for (auto& e : s->ev_bpre) S_HIP(s, mk(e));
-    S_HIP(s, mk(s->ev_bpre_nms));
+    S_HIP(s, mk(s->ev_bpre));
     S_HIP(s, mk(s->ev_bgray));
     S_HIP(s, mk(s->ev_bnms));
     for (auto& e : s->ev_bdet) S_HIP(s, mk(e));
