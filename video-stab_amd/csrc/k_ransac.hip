@@ -242,6 +242,46 @@ __device__ __forceinline__ void ransac_score(const RansacArgs& a, const int k) {
 
 __global__ __launch_bounds__(64) void ransac_score_kernel(RansacArgs a) { ransac_score(a, blockIdx.x); }
 
+// The same votes, SC_HYP hypotheses per wave: four lanes share a hypothesis and take every fourth point each, their counts
+// meet in two DPP adds.  A wave compacts the correspondences once for 16 hypotheses instead of once per hypothesis, and a
+// batch of 32 frames x 500 hypotheses is 1024 waves - one per SIMD - instead of 16 000: the launch is as long as one wave's
+// chain (compaction, the closed-form model, m / 4 inlier tests).  (The votes are integers: who counts them does not change
+// them.)
+constexpr int SC_HYP = 16;
+
+__device__ __forceinline__ void ransac_score16(const RansacArgs& a, const int kgroup) {
+    extern __shared__ float2 s_pts[];          // [2][a.n]: compacted from / to
+    float2* sf = s_pts;
+    float2* st = s_pts + a.n;
+    const int lane = threadIdx.x;
+    const int n = device_count(a);
+    const int m = compact_to_lds(a, n, sf, st, lane);
+    __syncthreads();
+    if (kgroup == 0 && a.status) {
+        for (int i = lane; i < m; i += 64) {
+            a.vp[2 * i] = sf[i].x; a.vp[2 * i + 1] = sf[i].y;
+            a.vc[2 * i] = st[i].x; a.vc[2 * i + 1] = st[i].y;
+        }
+        if (lane == 0) *a.d_m = m;
+    }
+    if (m < a.min_points || m <= 2 || m > a.table_max_m) return;
+    const int k = kgroup * SC_HYP + (lane >> 2), q = lane & 3;
+    const bool valid = k < a.iters;
+    const uint32_t pr = a.pairs[(size_t)m * a.iters + (valid ? k : 0)];
+    const int i0 = pr & 0xFFFFu, i1 = pr >> 16;
+    const Model M = kernel2(sf[i0].x, sf[i0].y, sf[i1].x, sf[i1].y, st[i0].x, st[i0].y, st[i1].x, st[i1].y);
+    float F[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) F[i] = (float)M.m[i];
+    int good = 0;
+    for (int i = q; i < m; i += 4) good += is_inlier(F, sf[i].x, sf[i].y, st[i].x, st[i].y, a.t) ? 1 : 0;
+    good += __builtin_amdgcn_update_dpp(0, good, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    good += __builtin_amdgcn_update_dpp(0, good, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    if (valid && q == 0) a.counts[k] = good;
+}
+
+__global__ __launch_bounds__(64) void ransac_score16_kernel(RansacArgs a) { ransac_score16(a, blockIdx.x); }
+
 __device__ __forceinline__ double wave_butterfly_sum(double v) {
     // fixed combine order (mirrored by oracle/vso_ransac.cpp): s[l] += s[l ^ off], off = 32..1
 #pragma unroll
@@ -363,6 +403,15 @@ __global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) { ransa
 // Several frames per launch: blockIdx.y selects the frame's argument block in a device table, blockIdx.x the hypothesis.
 __global__ __launch_bounds__(64) void ransac_score_batch_kernel(const RansacArgs* __restrict__ table) {
     ransac_score(table[blockIdx.y], blockIdx.x);
+}
+__global__ __launch_bounds__(64) void ransac_score16_batch_kernel(const RansacArgs* __restrict__ table) {
+    ransac_score16(table[blockIdx.y], blockIdx.x);
+}
+
+// VS_RANSAC_WAVE_PER_HYPOTHESIS=1: one wave per hypothesis, the scoring before this was measured
+bool score16_setting() {
+    static const bool v = std::getenv("VS_RANSAC_WAVE_PER_HYPOTHESIS") == nullptr;
+    return v;
 }
 
 // The selections of a batch, one wave (workgroup) per frame, launched right behind the scoring: they do not depend on
@@ -556,8 +605,12 @@ int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_m
         set_last_error("ransac_score_batch: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
-    hipLaunchKernelGGL(ransac_score_batch_kernel, dim3(iters, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
-                       static_cast<const RansacArgs*>(d_table));
+    if (score16_setting())
+        hipLaunchKernelGGL(ransac_score16_batch_kernel, dim3((iters + SC_HYP - 1) / SC_HYP, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
+                           static_cast<const RansacArgs*>(d_table));
+    else
+        hipLaunchKernelGGL(ransac_score_batch_kernel, dim3(iters, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
+                           static_cast<const RansacArgs*>(d_table));
     hipLaunchKernelGGL(ransac_select_batch_kernel, dim3(items), dim3(64), 0, st, static_cast<const RansacArgs*>(d_table), items - 1);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
@@ -603,7 +656,9 @@ int launch_ransac(const float* d_from, const float* d_to, const uint8_t* d_statu
     RansacArgs a;
     fill_ransac_args(a, d_from, d_to, d_status, n, d_n, d_vp, d_vc, d_m, min_points, thr, iters, tab, d_counts, d_model,
                      d_inliers, d_info, traj, tp, dbg, have_prev_gray);
-    if (n > 2 || d_status)
+    if ((n > 2 || d_status) && score16_setting())
+        hipLaunchKernelGGL(ransac_score16_kernel, dim3((iters + SC_HYP - 1) / SC_HYP), dim3(64), (size_t)(n > 0 ? n : 1) * 16, st, a);
+    else if (n > 2 || d_status)
         hipLaunchKernelGGL(ransac_score_kernel, dim3(iters), dim3(64), (size_t)(n > 0 ? n : 1) * 16, st, a);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, st, a);
     VS_HIP_TRY(hipGetLastError());
