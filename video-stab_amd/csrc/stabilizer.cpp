@@ -1490,18 +1490,25 @@ static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, si
     if (have_prev) {       // the held result: on its way while this call's frame comes in
         S_HIP(s, hipStreamWaitEvent(s->st_warp, s->ev_hold, 0));
         const uint8_t* d_src = s->d_hold[s->hold_cur ^ 1];
+        bool helped = false;
         if (use_helper && !host_ptr_page_locked(out)) {
-            if (!s->helper) s->helper.reset(new HostHelper);
-            const int dev = s->device;
-            hipStream_t stw = s->st_warp;
-            s->helper->start([=]() -> int {
-                hipError_t e = hipSetDevice(dev);
-                if (e == hipSuccess) e = hipMemcpy2DAsync(out, out_stride, d_src, orow, orow, orows, hipMemcpyDeviceToHost, stw);
-                if (e == hipSuccess) e = hipStreamSynchronize(stw);
-                return (int)e;
-            });
-            join.h = s->helper.get();
-        } else {
+            try {           // (no exception leaves the C ABI: without a helper thread the download goes out from this one)
+                if (!s->helper) s->helper.reset(new HostHelper);
+                const int dev = s->device;
+                hipStream_t stw = s->st_warp;
+                s->helper->start([=]() -> int {
+                    hipError_t e = hipSetDevice(dev);
+                    if (e == hipSuccess) e = hipMemcpy2DAsync(out, out_stride, d_src, orow, orow, orows, hipMemcpyDeviceToHost, stw);
+                    if (e == hipSuccess) e = hipStreamSynchronize(stw);
+                    return (int)e;
+                });
+                join.h = s->helper.get();
+                helped = true;
+            } catch (...) {
+                s->helper.reset();
+            }
+        }
+        if (!helped) {
             S_HIP(s, hipMemcpy2DAsync(out, out_stride, d_src, orow, orow, orows, hipMemcpyDeviceToHost, s->st_warp));
         }
     }
