@@ -240,17 +240,20 @@ def config2(vs, device, args):
     p = make_params(vs, max_corners=400)
     # (a) the stream as a decoder hands it over: NV12 surfaces, batch mode
     nv = [synth.bgr_to_nv12(f) for f in bgr]
-    BT = 16
+    # batches of 32 like configs[1], and the same kind of run-in (40 batches: the device's clocks are still rising during the
+    # first ones - 16-frame batches behind 2 warm-up batches, the first form of this measurement, read 45 k instead of 61 k
+    # frames/s; scratch/config2_sweep.py).  VS_BENCH_4K_* override the three numbers.
+    BT = int(os.environ.get("VS_BENCH_4K_BATCH", "32"))
     ss = StreamSet(vs, device, p, [nv], W, H, capi.FMT_NV12, BT, BT, True)
     ss.push(64)
     ss.sync()
-    ss.push(2 * BT)
+    ss.push(int(os.environ.get("VS_BENCH_4K_WARM", "40")) * BT)
     for s in ss.stabs:
         s.set_profiling(1)
         s.stage_times()
     ss.sync()
     f0 = ss.frames_out()
-    nb = 8
+    nb = int(os.environ.get("VS_BENCH_4K_TIMED", "40"))
     t0 = time.perf_counter()
     ss.push(nb * BT)
     ss.sync()

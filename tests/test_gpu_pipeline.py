@@ -554,6 +554,43 @@ def test_batch_mode_nv12(gpu, size, batch):
     s1.close(); s2.close()
 
 
+def test_batch_mode_nv12_at_4k_with_the_bench_batch(gpu):
+    """BASELINE configs[2] as bench.py runs it: 3840x2160 NV12, 400 corners, batches of 32 zero-copy surfaces (Y and UV plane
+    through warp_plane_kernel).  Same surfaces as the per-frame pipeline over 70 pushes (two full batches and a drain), flush
+    included."""
+    w, h, n = 3840, 2160, 70
+    base = [synth.bgr_to_nv12(f) for f in synth.make_clip(synth.SEED_CONFIG3 + 11, w, h, 8)]
+    order = [(i % 14) if (i % 14) < 8 else 14 - (i % 14) for i in range(n)]       # ping-pong: neighbours differ by one step
+    p = gpu.params(smoothing_radius=6, max_corners=400)
+    s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
+    s2.set_batch(32)
+    s2.set_zero_copy(True)
+    fb = base[0].nbytes
+    d_in = capi.DevBuf(gpu, fb * len(base))
+    for i, f in enumerate(base):
+        d_in.upload(f, i * fb)
+    d_ref, d_got = capi.DevBuf(gpu, fb * n), capi.DevBuf(gpu, fb * n)
+    k1 = k2 = 0
+    for i in range(n):
+        src = d_in.ptr + order[i] * fb
+        k1 += s1.push_dev(src, w, h, w, capi.FMT_NV12, d_ref.ptr + k1 * fb, w)
+        k2 += s2.push_dev(src, w, h, w, capi.FMT_NV12, d_got.ptr + k2 * fb, w)
+    while s1.flush_dev(d_ref.ptr + k1 * fb, w):
+        k1 += 1
+    while s2.flush_dev(d_got.ptr + k2 * fb, w):
+        k2 += 1
+    s1.sync(); s2.sync()
+    assert k1 == k2 == n
+    for i in range(0, n, 10):                       # ten surfaces at a time: 124 MB per side on the host
+        m = min(10, n - i)
+        a = d_ref.download((m, h * 3 // 2, w), np.uint8, offset=i * fb)
+        b = d_got.download((m, h * 3 // 2, w), np.uint8, offset=i * fb)
+        assert np.array_equal(a, b), i
+    s1.close(); s2.close()
+    for d in (d_in, d_ref, d_got):
+        d.free()
+
+
 @pytest.mark.parametrize("mode", ["per_frame_copy", "per_frame_zero_copy", "batch_zero_copy"])
 def test_nv12_decoder_surfaces(gpu, mode):
     """Decoder hand-off: NV12 surfaces with a padded pitch and the UV plane at
