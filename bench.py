@@ -362,7 +362,7 @@ def main():
     BT = ss.BT
     # setup, not a step: past the 29-frame warm-up of smoothingRadius 30 (every later push produces a frame), and ~0.1 s of the
     # same work so that the device's clocks and the allocator's first touches are not part of the W warm-up steps' job
-    preroll = 64 + 200 * BT
+    preroll = 64 + int(os.environ.get("VS_BENCH_PREROLL_BATCHES", "200")) * BT
 
     def sync_all():
         ss.sync()
