@@ -112,8 +112,9 @@ class StreamSet:
             for i, f in enumerate(frames):
                 buf.upload(f, i * self.fb)
             self.d_in.append(buf)
-        self.BT = max(1, min(32, batch))
+        self.BT = max(1, min(64, batch))
         self.WB = max(1, min(32, warp_batch if self.BT == 1 else self.BT))
+        self.WB_frames = self.BT if self.BT > 1 else self.WB       # frames between one pair of warp-stage events
         self.NOUT = max(2 * self.WB, 3 * self.BT)    # a result stays untouched until its batch and the next one have been issued
         self.d_out = [[capi.DevBuf(vs, self.fb) for _ in range(self.NOUT)] for _ in frames_per_stream]
         self.stabs = [vs.stabilizer(params, device=device) for _ in frames_per_stream]
@@ -159,14 +160,15 @@ def warp_roofline(ss, alg_bytes_per_frame, frames_out_timed, kernel):
         for k in range(8):
             stage_ms[k] += ms[k]
             stage_n[k] += n[k]
-    launches = max(stage_n[7], 1)
+    # (a batch of more than 32 frames is warped by ceil(batch / 32) launches back to back inside one pair of events)
+    launches = max(stage_n[7], 1) * max(1, (ss.WB_frames + 31) // 32)
     frames_per_launch = frames_out_timed / launches
     avg_ms = stage_ms[7] / launches
     byts = alg_bytes_per_frame * frames_per_launch
     achieved = byts / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": byts,
-            "frames_per_launch": round(frames_per_launch, 3), "avg_launch_us": round(avg_ms * 1e3, 3), "launches": stage_n[7]}
+            "frames_per_launch": round(frames_per_launch, 3), "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches}
     return roof, stage_ms, stage_n
 
 

@@ -264,11 +264,12 @@ void vs_host_free(void* p);
  * every push issues its own warp.  The host entry points (vs_stab_push / vs_stab_flush)
  * always deliver their result before returning. */
 int vs_stab_set_warp_batch(vs_stab* s, int frames);
-/* Batch mode for vs_stab_push_dev / vs_stab_flush_dev: the analysis of `frames` (1..32)
+/* Batch mode for vs_stab_push_dev / vs_stab_flush_dev: the analysis of `frames` (1..64)
  * consecutive pushes - goodFeaturesToTrack, calcOpticalFlowPyrLK and the RANSAC
  * hypothesis scoring, all latency-bound on one frame - runs as ONE launch per stage over
  * the whole group; the ordered part (hypothesis selection + trajectory append, smoothing)
- * stays per frame, and the warps go out together as with vs_stab_set_warp_batch(frames).
+ * stays per frame, and the warps go out together as with vs_stab_set_warp_batch(frames)
+ * (at most 32 frames per warp launch: a batch of 64 is two launches back to back).
  * Results are bit-identical to frames = 1 and complete after vs_stab_sync(); every push must
  * be given its own d_out until then.  Must be chosen before the first frame (or after
  * vs_stab_clean).  BGR8, GRAY8 and NV12 frames; border/crop modes and adaptive smoothing

@@ -346,7 +346,7 @@ def test_deferred_warp_batches_match_immediate_output(gpu, batch):
         s.close()
 
 
-@pytest.mark.parametrize("batch,radius,n", [(2, 7, 30), (8, 7, 45), (16, 12, 61), (5, 30, 80), (32, 9, 100), (27, 5, 70)])
+@pytest.mark.parametrize("batch,radius,n", [(2, 7, 30), (8, 7, 45), (16, 12, 61), (5, 30, 80), (32, 9, 100), (27, 5, 70), (64, 9, 200), (50, 20, 170)])
 def test_batch_mode_matches_per_frame_pipeline(gpu, batch, radius, n):
     """vs_stab_set_batch: GFTT / LK / RANSAC scoring of `batch` frames per launch; outputs (flush included),
     the last frame's debug record and the counters equal the per-frame pipeline's."""
@@ -524,12 +524,12 @@ def test_pipeline_4k_nv12_config3_against_oracle(gpu, oracle):
         oracle.lib.vso_set_threads(1)
 
 
-@pytest.mark.parametrize("size,batch", [((320, 240), 8), ((640, 360), 16)])
+@pytest.mark.parametrize("size,batch", [((320, 240), 8), ((640, 360), 16), ((320, 240), 64)])
 def test_batch_mode_nv12(gpu, size, batch):
     """NV12 surfaces in batch mode (Y plane analysed and warped, interleaved chroma warped with the halved
     translation): same surfaces as the per-frame pipeline, flush included."""
     w, h = size
-    n = 44
+    n = max(44, 2 * batch + 12)           # two full batches (of 64: four warp launches of 32) and a drain
     clip = [synth.bgr_to_nv12(f) for f in synth.make_clip(synth.SEED_CONFIG3 + 5, w, h, n)]
     p = gpu.params(smoothing_radius=6, max_corners=400)
     s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
@@ -791,7 +791,7 @@ def test_keypoint_buffers_are_not_recycled_under_the_ransac_kernels(gpu, oracle,
 
 @pytest.mark.parametrize("extra", [dict(), dict(smoothing_method=capi.SMOOTH_GAUSSIAN, gaussian_sigma=2.0),
                                    dict(smoothing_method=capi.SMOOTH_KALMAN), dict(drone_high_freq_mode=1)])
-@pytest.mark.parametrize("batch", [1, 32])
+@pytest.mark.parametrize("batch", [1, 32, 64])
 def test_long_stream_wraps_the_trajectory_rings(gpu, oracle, extra, batch):
     """340 frames: the 256-entry device rings of transforms / path (traj_state.h) wrap, the incremental Kalman walk and the
     Gaussian reflect window run past the wrap; per-frame pipeline and batch mode (flush included) against the oracle, whose
@@ -903,16 +903,19 @@ def test_host_pipeline_helper_threads_of_several_instances(gpu):
 
 @pytest.mark.parametrize("extra", [dict(border_size=16, border_type=capi.BORDER_REFLECT), dict(border_size=9, border_type=capi.BORDER_REPLICATE),
                                    dict(border_size=12, border_type=capi.BORDER_WRAP), dict(border_size=16, border_type=capi.BORDER_REFLECT_101),
-                                   dict(border_size=8, border_type=capi.BORDER_BLACK), dict(border_size=20, crop_n_zoom=1)])
+                                   dict(border_size=8, border_type=capi.BORDER_BLACK), dict(border_size=20, crop_n_zoom=1),
+                                   dict(border_size=16, border_type=capi.BORDER_REFLECT, batch=40), dict(border_size=20, crop_n_zoom=1, batch=64)])
 def test_batch_mode_with_border_pad_and_crop_n_zoom(gpu, extra):
     """copyMakeBorder in front of the warp (Stabilizer.cpp:981-990) and crop-and-zoom behind it (:1108-1124) in batch mode:
     the frames of the per-frame pipeline, flush included."""
     clip = synth.make_clip(synth.SEED_CONFIG1 + 37, 320, 240, 24)
-    n = 45
+    extra = dict(extra)
+    batch = extra.pop("batch", 8)          # more than 32: the batch's warps are two launches, each with its share of the tables
+    n = 45 if batch == 8 else 2 * batch + 20
     order = [i % 24 if (i // 24) % 2 == 0 else 23 - i % 24 for i in range(n)]
     p = gpu.params(smoothing_radius=7, **extra)
     s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
-    s2.set_batch(8)
+    s2.set_batch(batch)
     oh, ow, _ = s1.out_shape(320, 240, capi.FMT_BGR8)
     fb, ob = clip[0].nbytes, oh * ow * 3
     d_in = capi.DevBuf(gpu, fb * 24)

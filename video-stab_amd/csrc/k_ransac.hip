@@ -440,7 +440,7 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     __shared__ TrajState l_state;
     __shared__ TrajParams l_tp;
     __shared__ vs_debug_frame l_dbg;
-    constexpr int TB = 32;           // frames per tail (= BATCH_MAX of stabilizer.cpp)
+    constexpr int TB = 64;           // frames per tail (= BATCH_MAX of stabilizer.cpp)
     __shared__ double l_model[TB][6];
     __shared__ double l_minv[TB][12];
     __shared__ float l_M[12];
@@ -626,7 +626,7 @@ void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_ou
 int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, hipStream_t st) {
     if (!d_table || !d_tail || items < 1 || !d_M_out) { set_last_error("ransac_tail_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
     const int threads = 64 * (items < 1 ? 1 : (items > 16 ? 16 : items));
-    if (items > 32) { set_last_error("ransac_tail_batch: at most 32 frames"); return VS_ERR_INVALID_ARG; }
+    if (items > 64) { set_last_error("ransac_tail_batch: at most 64 frames"); return VS_ERR_INVALID_ARG; }
     hipLaunchKernelGGL(ransac_tail_batch_kernel, dim3(1), dim3(threads), 0, st, static_cast<const RansacArgs*>(d_table),
                        static_cast<const TailItem*>(d_tail), items, d_M_out);
     VS_HIP_TRY(hipGetLastError());

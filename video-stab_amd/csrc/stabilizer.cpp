@@ -80,11 +80,13 @@ int launch_resize_linear(const uint8_t* d_src, size_t sstride, int sw, int sh, i
                          size_t dstride, int dw, int dh, hipStream_t st);
 
 constexpr int FRAME_RING = 128;     // <= 35 queued frames (clamp(smoothingRadius,5,35)) + slack so that a
-                                    // slot is reused several frames after the warp that released it
+                                    // slot is reused several frames after the warp that released it; in batch mode
+                                    // also the batch being collected and the one whose warps are still to come
+constexpr int FRAME_RING_MAX = 192; // the same for batches of more than 32 frames (s->ring_frames)
 constexpr int MAX_PYR = 8;
 constexpr int NPYR = 3;             // pyramid buffers: frame k writes k%3 while LK(k-1) still reads (k-1)%3,(k-2)%3
 constexpr int WARP_BATCH_MAX = 32;   // = the warp kernel's frames per launch (k_warp.hip MAXB)
-constexpr int BATCH_MAX = 32;        // frames analysed per launch in batch mode (vs_stab_set_batch)
+constexpr int BATCH_MAX = 64;        // frames analysed per launch in batch mode (vs_stab_set_batch)
 constexpr int EVR = 4;              // per-frame event ring
 
 struct Pyramid {
@@ -186,8 +188,9 @@ struct vs_stab {
     hipEvent_t ev_lk[EVR] = {}, ev_det[EVR] = {};
     bool det_valid[EVR] = {false, false, false, false};
     hipEvent_t ev_first = nullptr;
-    hipEvent_t ev_slot[FRAME_RING] = {};
-    bool slot_valid[FRAME_RING] = {};
+    hipEvent_t ev_slot[FRAME_RING_MAX] = {};
+    bool slot_valid[FRAME_RING_MAX] = {};
+    int ring_frames = FRAME_RING;
     hipEvent_t pts_event[2] = {nullptr, nullptr};   // recorded by the detection that filled pts[i]
     bool pts_pending[2] = {false, false};
     // deferred output (vs_stab_set_warp_batch): warps of consecutive outputs wait for each other and
@@ -415,7 +418,8 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     // (the frame queue ring - 128 frames, 3.2 GB at 4K BGR8 - is allocated by the first push that copies a frame in: a
     // stream that only ever hands over device frames in zero-copy mode never needs it)
     s->free_slots.clear();
-    for (int i = 0; i < FRAME_RING; i++) { s->free_slots.push_back(i); s->slot_valid[i] = false; }
+    s->ring_frames = (s->batch_active && B > 32) ? FRAME_RING_MAX : FRAME_RING;
+    for (int i = 0; i < s->ring_frames; i++) { s->free_slots.push_back(i); s->slot_valid[i] = false; }
     s->ncap = std::max(s->p.max_corners, 1);
     const int ncap = s->ncap;
     // carve the small buffers out of one allocation (256-byte aligned pieces)
@@ -448,7 +452,7 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     size_t o_MinvB[2] = {take((size_t)BATCH_MAX * 96), take((size_t)BATCH_MAX * 96)};
     int tow, toh;
     out_size(s, w, h, &tow, &toh);
-    const size_t tab_bytes = warp_tabs_ints(std::max(w, tow), std::max(h, toh), WARP_BATCH_MAX) * sizeof(int32_t);
+    const size_t tab_bytes = warp_tabs_ints(std::max(w, tow), std::max(h, toh), BATCH_MAX) * sizeof(int32_t);
     size_t o_tabs[5];
     for (auto& o : o_tabs) o = take(tab_bytes);
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
@@ -736,7 +740,7 @@ int ready_launches(vs_stab* s, int what) {
     int rc = VS_OK;
     for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes WARP_BATCH_MAX frames per launch
         const int m = std::min(WARP_BATCH_MAX, R.n - i0);
-        const bool tabs = m >= 4 && R.n <= WARP_BATCH_MAX;                  // (one table set per batch)
+        const bool tabs = m >= 4;                                           // (the table set of a batch holds BATCH_MAX frames)
         if (what == VS_WARP_TABLES_ONLY && !tabs) continue;
         const int w = tabs ? what : VS_WARP_ALL;
         if (pad || crop) {
@@ -755,14 +759,14 @@ int ready_launches(vs_stab* s, int what) {
             }
             if (rc == VS_OK)
                 rc = launch_warp_affine_list(srcs, dsts, m, pad ? prow : s->src_pitch, pw, ph, pad ? R.stride : prow, pw, ph, s->cn,
-                                             s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] : nullptr, st, w);
+                                             s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] + i0 * warp_tabs_ints(pw, ph, 1) : nullptr, st, w);
             for (int i = 0; crop && what != VS_WARP_TABLES_ONLY && i < m && rc == VS_OK; i++)
                 rc = launch_resize_linear(dsts[i] + ((size_t)bsz * s->w + bsz) * s->cn, prow, s->w - 2 * bsz, s->h - 2 * bsz, s->cn,
                                           R.dsts[i0 + i], R.stride, s->orig_w, s->orig_h, st);
             continue;
         }
         rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->src_pitch, s->w, s->h, R.stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] : nullptr, st, w);
+                                     s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] + i0 * warp_tabs_ints(s->w, s->h, 1) : nullptr, st, w);
         if (rc == VS_OK && s->fmt == VS_FMT_NV12) {
             // interleaved chroma plane: half size, two channels, the map with the halved translation
             const uint8_t* us[WARP_BATCH_MAX];
@@ -772,7 +776,7 @@ int ready_launches(vs_stab* s, int what) {
                 ud[i] = R.dsts[i0 + i] + dst_uv(s, R.dsts[i0 + i], R.stride);
             }
             rc = launch_warp_affine_list(us, ud, m, s->src_pitch, s->w / 2, s->h / 2, R.stride, s->w / 2, s->h / 2, 2,
-                                         s->d_MinvB[R.set] + 12 * i0 + 6, 12, tabs ? s->d_tabs[2 + R.set] : nullptr, st, w);
+                                         s->d_MinvB[R.set] + 12 * i0 + 6, 12, tabs ? s->d_tabs[2 + R.set] + i0 * warp_tabs_ints(s->w / 2, s->h / 2, 1) : nullptr, st, w);
         }
     }
     if (rc != VS_OK) s->err = get_last_error();
@@ -1232,7 +1236,7 @@ int push_common(vs_stab* s, int slot, const uint8_t* zc_frame, uint8_t* d_out, s
 }
 
 int take_slot(vs_stab* s, int* slot) {
-    if (!s->d_ring) S_HIP(s, hipMalloc((void**)&s->d_ring, s->frame_bytes * FRAME_RING));
+    if (!s->d_ring) S_HIP(s, hipMalloc((void**)&s->d_ring, s->frame_bytes * s->ring_frames));
     if (s->free_slots.empty()) return fail(s, VS_ERR_CAPACITY, "frame ring exhausted");
     *slot = s->free_slots.front();
     s->free_slots.pop_front();
