@@ -12,7 +12,7 @@ data-path collective - torch.distributed only provides the barrier and the
 max-over-ranks of the timed region.
 
 A STEP = one pass of the hot path over one batch of synthetic input: `--batch`
-(32) consecutive stabilize() calls (vs_stab_push_dev) per stream on frames that
+(64) consecutive stabilize() calls (vs_stab_push_dev) per stream on frames that
 are already resident in HBM - the unit the batch mode issues its launches in, so
 that any K is a whole number of steady-state batches.  `value` is frames/s.
 Prints ONE JSON line on rank 0; at N = 1 it also carries the PCIe-inclusive rate
@@ -242,10 +242,10 @@ def config2(vs, device, args):
     p = make_params(vs, max_corners=400)
     # (a) the stream as a decoder hands it over: NV12 surfaces, batch mode
     nv = [synth.bgr_to_nv12(f) for f in bgr]
-    # batches of 32 like configs[1], and the same kind of run-in (40 batches: the device's clocks are still rising during the
-    # first ones - 16-frame batches behind 2 warm-up batches, the first form of this measurement, read 45 k instead of 61 k
-    # frames/s; scratch/config2_sweep.py).  VS_BENCH_4K_* override the three numbers.
-    BT = int(os.environ.get("VS_BENCH_4K_BATCH", "32"))
+    # batches of 64 like configs[1], and the same kind of run-in (40 batches: the device's clocks are still rising during the
+    # first ones - 16-frame batches behind 2 warm-up batches, the first form of this measurement, read 45 k frames/s where
+    # batches of 32 behind 40 read 61 k and batches of 64 67 k; scratch/config2_sweep.py).  VS_BENCH_4K_* override the three numbers.
+    BT = int(os.environ.get("VS_BENCH_4K_BATCH", "64"))
     ss = StreamSet(vs, device, p, [nv], W, H, capi.FMT_NV12, BT, BT, True)
     ss.push(64)
     ss.sync()
@@ -311,8 +311,9 @@ def main():
     ap.add_argument("--profile-stages", action="store_true", help="time every stage (adds event records)")
     ap.add_argument("--zero-copy", type=int, default=1,
                     help="frames are read where they lie in HBM instead of being copied into the instance's queue")
-    ap.add_argument("--batch", type=int, default=32,
-                    help="frames per step: the analysis stages of this many consecutive pushes run as one launch each (1 = per-frame pipeline)")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="frames per step (at most 64): the analysis stages of this many consecutive pushes run as one launch each "
+                         "(1 = per-frame pipeline); the warps of a step go out 32 frames per launch")
     ap.add_argument("--warp-batch", type=int, default=8,
                     help="per-frame pipeline only (--batch 1): results of this many consecutive pushes are warped by one launch")
     ap.add_argument("--config", default=None,

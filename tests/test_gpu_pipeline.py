@@ -555,15 +555,15 @@ def test_batch_mode_nv12(gpu, size, batch):
 
 
 def test_batch_mode_nv12_at_4k_with_the_bench_batch(gpu):
-    """BASELINE configs[2] as bench.py runs it: 3840x2160 NV12, 400 corners, batches of 32 zero-copy surfaces (Y and UV plane
-    through warp_plane_kernel).  Same surfaces as the per-frame pipeline over 70 pushes (two full batches and a drain), flush
-    included."""
-    w, h, n = 3840, 2160, 70
+    """BASELINE configs[2] as bench.py runs it: 3840x2160 NV12, 400 corners, batches of 64 zero-copy surfaces (Y and UV plane
+    through warp_plane_kernel, 32 surfaces per launch).  Same surfaces as the per-frame pipeline over 140 pushes (two full
+    batches and a drain), flush included."""
+    w, h, n = 3840, 2160, 140
     base = [synth.bgr_to_nv12(f) for f in synth.make_clip(synth.SEED_CONFIG3 + 11, w, h, 8)]
     order = [(i % 14) if (i % 14) < 8 else 14 - (i % 14) for i in range(n)]       # ping-pong: neighbours differ by one step
     p = gpu.params(smoothing_radius=6, max_corners=400)
     s1, s2 = gpu.stabilizer(p), gpu.stabilizer(p)
-    s2.set_batch(32)
+    s2.set_batch(64)
     s2.set_zero_copy(True)
     fb = base[0].nbytes
     d_in = capi.DevBuf(gpu, fb * len(base))
