@@ -429,10 +429,16 @@ __global__ __launch_bounds__(64) void ransac_select_batch_kernel(const RansacArg
 struct TailItem {
     int out_due, out_idx;
     double* Minv_out;
+    int ncnt, pad;               // written by the tail: transforms appended after this push (read by the release kernel)
 };
 
+// RELEASE_APART: the kernel ends with the appends (phases 1 and 2a) and leaves the releases - smoothing around the frame each
+// due push lets go, its matrix and inverse map - to ransac_release_batch_kernel, one workgroup per push: on the one CU of
+// this kernel sixteen waves share four SIMDs and a batch of 64 releases took 60 of the tail's 130 us.  (Not for the Kalman
+// smoother, whose filter state advances from release to release.)
+template <bool RELEASE_APART>
 __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArgs* __restrict__ table,
-                                                                 const TailItem* __restrict__ tail, int n, float* M_out) {
+                                                                 TailItem* __restrict__ tail, int n, float* M_out) {
     // The ordered part below is a chain of small dependent steps executed by one lane; run from global
     // memory every step would pay an HBM round trip (and every barrier would wait for the stores of the
     // step before).  The stream's trajectory state, the parameters, the per-frame inputs and all results
@@ -517,6 +523,14 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     int last_due = -1;
     for (int i = 0; i < n; i++) if (l_due[i]) last_due = i;
     __syncthreads();
+    if (RELEASE_APART) {
+        for (int i = tid; i < (int)(sizeof(TrajState) / 4); i += blockDim.x)
+            reinterpret_cast<uint32_t*>(g_state)[i] = reinterpret_cast<const uint32_t*>(&l_state)[i];
+        for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)
+            reinterpret_cast<uint32_t*>(g_dbg)[i] = reinterpret_cast<const uint32_t*>(&l_dbg)[i];
+        if (tid < n) tail[tid].ncnt = l_ncnt[tid];
+        return;
+    }
     // phase 2b: smooth around the frame that push i releases -> its transform (dx, dy, da).  The release of push i must
     // see exactly the transforms appended up to push i (:380-389): it is given that length, and the later entries of the
     // rings lie beyond everything it reads (ring of 256, at most 32 pushes ahead).  Box and Gaussian smoothing keep no
@@ -555,6 +569,22 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     if (tid < 12) M_out[tid] = l_M[tid];
     for (int f = wave; f < n; f += nwaves)
         if (lane < 12 && l_due[f]) tail[f].Minv_out[lane] = l_minv[f][lane];
+}
+
+// The releases of a batch whose appends ransac_tail_batch_kernel<true> has made: workgroup f = push f.  Each sees the
+// trajectory as long as it was after its push (TailItem::ncnt); the last due one leaves its record and matrix behind,
+// like the last release of the one-kernel tail.
+__global__ __launch_bounds__(64) void ransac_release_batch_kernel(const RansacArgs* __restrict__ table, const TailItem* __restrict__ tail,
+                                                                  int n, float* M_out) {
+    __shared__ vs_debug_frame l_dbg_unused;
+    __shared__ float l_M[12];
+    const int f = blockIdx.x;
+    const TailItem t = tail[f];
+    if (!t.out_due) return;
+    int last_due = -1;
+    for (int i = 0; i < n; i++) if (tail[i].out_due) last_due = i;
+    const bool last = f == last_due;
+    traj_emit_device(table[0].traj, table[0].tp, t.out_idx, last ? M_out : l_M, t.Minv_out, last ? table[0].dbg : &l_dbg_unused, nullptr, t.ncnt);
 }
 
 }  // namespace
@@ -620,15 +650,23 @@ size_t tail_item_bytes() { return sizeof(TailItem); }
 
 void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out) {
     TailItem& t = *static_cast<TailItem*>(host_item);
-    t.out_due = out_due; t.out_idx = out_idx; t.Minv_out = d_Minv_out;
+    t.out_due = out_due; t.out_idx = out_idx; t.Minv_out = d_Minv_out; t.ncnt = 0; t.pad = 0;
 }
 
-int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, hipStream_t st) {
+int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, int smoothing_method, hipStream_t st) {
     if (!d_table || !d_tail || items < 1 || !d_M_out) { set_last_error("ransac_tail_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
     const int threads = 64 * (items < 1 ? 1 : (items > 16 ? 16 : items));
     if (items > 64) { set_last_error("ransac_tail_batch: at most 64 frames"); return VS_ERR_INVALID_ARG; }
-    hipLaunchKernelGGL(ransac_tail_batch_kernel, dim3(1), dim3(threads), 0, st, static_cast<const RansacArgs*>(d_table),
-                       static_cast<const TailItem*>(d_tail), items, d_M_out);
+    // (VS_TAIL_ONE_KERNEL=1: releases inside the tail kernel, as measured before)
+    static const bool apart = std::getenv("VS_TAIL_ONE_KERNEL") == nullptr;
+    const RansacArgs* tb = static_cast<const RansacArgs*>(d_table);
+    TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
+    if (apart && smoothing_method != VS_SMOOTH_KALMAN) {
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out);
+        hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, items, d_M_out);
+    } else {
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out);
+    }
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

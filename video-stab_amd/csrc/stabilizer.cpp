@@ -63,7 +63,7 @@ int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_m
 int launch_ransac_select_item(const void* host_item, hipStream_t st);
 size_t tail_item_bytes();
 void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out);
-int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, hipStream_t st);
+int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, int smoothing_method, hipStream_t st);
 size_t gftt_item_bytes();
 int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
                    double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
@@ -1132,7 +1132,7 @@ int run_batch(vs_stab* s) {
         }
         {
             StageScope t(s, VS_STAGE_TRAJ, st);
-            S_TRY(s, launch_ransac_tail_batch(s->d_rs_table[dset], s->d_tail_table[dset], n, s->d_M, st));
+            S_TRY(s, launch_ransac_tail_batch(s->d_rs_table[dset], s->d_tail_table[dset], n, s->d_M, p.smoothing_method, st));
         }
         // the keypoint and pyramid buffers of this batch may be recycled (two batches on) once the tail, which still reads
         // the points and their counts, has run

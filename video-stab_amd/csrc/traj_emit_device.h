@@ -262,12 +262,14 @@ __device__ __forceinline__ void traj_emit_lds_wave0(TrajState* s, const TrajPara
     traj_emit_wave0<true>(s, p, idx, nullptr, nullptr, dbg, s->path, s->transforms, mg, dr, n, istart, t3);
 }
 
+// n_seen >= 0: the number of transforms this release is to see (the rings may already hold later ones: batch mode)
 __device__ __forceinline__ void traj_emit_device(TrajState* s, const TrajParams& p, int idx, float* __restrict__ M_out,
-                                                 double* __restrict__ Minv_out, vs_debug_frame* dbg, float* t_out = nullptr) {
+                                                 double* __restrict__ Minv_out, vs_debug_frame* dbg, float* t_out = nullptr,
+                                                 int n_seen = -1) {
     // The history rings are mirrored into LDS by all lanes and the per-sample transcendental work of
     // the intent analysis is spread over lanes.
     __shared__ float l_path[TRAJ_RING][3], l_tr[TRAJ_RING][3];
-    const int n = s->n;
+    const int n = n_seen >= 0 ? n_seen : s->n;
     for (int i = threadIdx.x; i < TRAJ_RING * 3; i += blockDim.x) {
         (&l_path[0][0])[i] = (&s->path[0][0])[i];
         (&l_tr[0][0])[i] = (&s->transforms[0][0])[i];
