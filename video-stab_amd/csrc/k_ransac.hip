@@ -464,14 +464,16 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     for (int i = tid; i < (int)(sizeof(TrajParams) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(&l_tp)[i] = reinterpret_cast<const uint32_t*>(&table[0].tp)[i];
     if (tid < 12) l_M[tid] = M_out[tid];
-    // phase 1: per-frame inputs of the ordered part: wave i serves frame i
+    // phase 1: per-frame inputs of the ordered part: sixteen lanes serve a frame, so that the dependent global loads of all
+    // 64 frames of a batch are one round (a wave per frame took four rounds on the 16 waves of this workgroup)
     const int nwaves = blockDim.x >> 6;
     // (the selections themselves ran behind the scoring launch, one workgroup per frame: ransac_select_batch_kernel)
-    for (int f = wave; f < n; f += nwaves) {
+    for (int f = tid >> 4; f < n; f += blockDim.x >> 4) {
         const RansacArgs& a = table[f];
-        if (lane < 6) l_model[f][lane] = a.model[lane];
-        if (lane < 4) l_info[f][lane] = a.info[lane];
-        if (lane == 0) {
+        const int l16 = tid & 15;
+        if (l16 < 6) l_model[f][l16] = a.model[l16];
+        if (l16 >= 8 && l16 < 12) l_info[f][l16 - 8] = a.info[l16 - 8];
+        if (l16 == 15) {
             l_nprev[f] = device_count(a); l_hpg[f] = a.have_prev_gray;
             l_due[f] = tail[f].out_due; l_oidx[f] = tail[f].out_idx;
             // :644-662 for this frame (identity when the estimation failed or was skipped): the arctangent leaves the
