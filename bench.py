@@ -15,13 +15,23 @@ A STEP = one pass of the hot path over one batch of synthetic input: `--batch`
 (64) consecutive stabilize() calls (vs_stab_push_dev) per stream on frames that
 are already resident in HBM - the unit the batch mode issues its launches in, so
 that any K is a whole number of steady-state batches.  `value` is frames/s.
+
+The input of a stream is a closed-loop clip of `--clip-frames` (128) DISTINCT
+frames rendered on the device (796 MB at 1080p: three times the 256 MB Infinity
+Cache) and played in a cycle, so the warp reads every source frame from HBM;
+the results go to a ring of 3 x batch output frames (1.2 GB).  The timed region
+of exactly K steps is repeated `--regions` (9) times, each bracketed by barrier +
+device sync; `value` is the MEDIAN region (all of them are in `regions`).
+
 Prints ONE JSON line on rank 0; at N = 1 it also carries the PCIe-inclusive rate
 of the host-pointer entry point, BASELINE configs[2] (3840x2160) and the CPU
-baseline.
+baseline.  `--workload configs2` makes the 4K NV12 stream the measured workload
+(profiling runs of its kernels).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,6 +43,9 @@ sys.path.insert(0, os.path.join(ROOT, "video-stab_amd"))
 from vsamd import capi, dist as vsdist, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
+# algorithmic bytes of the WHOLE step per 1080p BGR8 frame (downscale+gray, pyramid, GFTT every 2nd frame,
+# LK gathers, warp)
+WHOLE_STEP_BYTES_1080P = 22.7e6
 
 
 def make_params(vs, config=None, **over):
@@ -51,7 +64,7 @@ def make_params(vs, config=None, **over):
 
 
 def clip_order(n_frames, n_steps):
-    """Ping-pong through the clip so consecutive frames always differ by one camera step."""
+    """Ping-pong through a (short, host-side) clip so consecutive frames always differ by one camera step."""
     fwd = list(range(n_frames)) + list(range(n_frames - 2, 0, -1))
     return [fwd[i % len(fwd)] for i in range(n_steps)]
 
@@ -92,43 +105,39 @@ def cpu_baseline(width, height, frames, order_fn):
     o.lib.vso_set_threads(1)
     return {
         "value": round(timed / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": "%d steady-state stabilize() calls on the same %dx%d clip, oracle/ single thread" % (timed, width, height),
+        "sample": "%d steady-state stabilize() calls on %d frames of the same %dx%d clip, oracle/ single thread" % (
+            timed, len(frames), width, height),
         "all_cores": {"value": round(60 / dt_mt, 3), "cores": nthr, "host_cores": ncores,
                       "note": "same port, threaded stages spread over %d threads" % nthr},
     }
 
 
 class StreamSet:
-    """S stabilizer instances in batch mode on one GPU, each with a resident clip and a ring of output frames."""
+    """S stabilizer instances in batch mode on one GPU, each with a resident clip (one DevBuf of `clip_frames` packed frames,
+    played in a cycle) and a ring of output frames."""
 
-    def __init__(self, vs, device, params, frames_per_stream, w, h, fmt, batch, warp_batch, zero_copy):
+    def __init__(self, vs, device, params, clips, clip_frames, w, h, fmt, batch, warp_batch, zero_copy):
         self.vs, self.w, self.h, self.fmt = vs, w, h, fmt
-        self.fb = frames_per_stream[0][0].nbytes
+        self.fb = w * h * 3 if fmt == capi.FMT_BGR8 else w * h * 3 // 2
         self.stride = w * 3 if fmt == capi.FMT_BGR8 else w
-        self.clip_frames = len(frames_per_stream[0])
-        self.d_in = []
-        for frames in frames_per_stream:
-            buf = capi.DevBuf(vs, self.fb * len(frames))
-            for i, f in enumerate(frames):
-                buf.upload(f, i * self.fb)
-            self.d_in.append(buf)
+        self.clip_frames = clip_frames
+        self.d_in = clips
         self.BT = max(1, min(64, batch))
         self.WB = max(1, min(32, warp_batch if self.BT == 1 else self.BT))
         self.WB_frames = self.BT if self.BT > 1 else self.WB       # frames between one pair of warp-stage events
         self.NOUT = max(2 * self.WB, 3 * self.BT)    # a result stays untouched until its batch and the next one have been issued
-        self.d_out = [[capi.DevBuf(vs, self.fb) for _ in range(self.NOUT)] for _ in frames_per_stream]
-        self.stabs = [vs.stabilizer(params, device=device) for _ in frames_per_stream]
+        self.d_out = [[capi.DevBuf(vs, self.fb) for _ in range(self.NOUT)] for _ in clips]
+        self.stabs = [vs.stabilizer(params, device=device) for _ in clips]
         for s in self.stabs:
             s.set_batch(self.BT)
             s.set_zero_copy(bool(zero_copy))
             s.set_warp_batch(self.WB)
         self.i = 0
-        self.order = clip_order(self.clip_frames, 1 << 17)
 
     def push(self, n):
         """n consecutive pushes per stream."""
         for _ in range(n):
-            fi = self.order[self.i % len(self.order)]
+            fi = self.i % self.clip_frames
             for j, s in enumerate(self.stabs):
                 s.push_dev(self.d_in[j].ptr + fi * self.fb, self.w, self.h, self.stride, self.fmt,
                            self.d_out[j][self.i % self.NOUT].ptr, self.stride)
@@ -141,59 +150,129 @@ class StreamSet:
     def frames_out(self):
         return sum(s.counters().frames_out for s in self.stabs)
 
-    def close(self):
+    def stage_totals(self):
+        n_st = capi.STAGE_COUNT
+        ms, n = [0.0] * n_st, [0] * n_st
+        for s in self.stabs:
+            a, b = s.stage_times()
+            for k in range(n_st):
+                ms[k] += a[k]
+                n[k] += b[k]
+        return ms, n
+
+    def host_frames(self, j, count):
+        """The first `count` frames of stream j's clip as numpy arrays (the CPU baseline and the host entry points)."""
+        shape = (self.h, self.w, 3) if self.fmt == capi.FMT_BGR8 else (self.h * 3 // 2, self.w)
+        return [self.d_in[j].download(shape, np.uint8, i * self.fb) for i in range(min(count, self.clip_frames))]
+
+    def close(self, free_clips=True):
         for s in self.stabs:
             s.close()
-        for b in self.d_in:
-            b.free()
+        if free_clips:
+            for b in self.d_in:
+                b.free()
         for bs in self.d_out:
             for b in bs:
                 b.free()
 
 
-def warp_roofline(ss, alg_bytes_per_frame, frames_out_timed, kernel):
-    """Warp stage of the timed region: HIP-event time of its launches on the stream they run on."""
-    stage_ms = [0.0] * 8
-    stage_n = [0] * 8
-    for s in ss.stabs:
-        ms, n = s.stage_times()
-        for k in range(8):
-            stage_ms[k] += ms[k]
-            stage_n[k] += n[k]
+def timed_regions(ss, comm, steps, regions):
+    """`regions` timed regions of exactly `steps` steps each, every one bracketed by barrier + device sync on both sides;
+    elapsed = max over ranks.  Returns the list of elapsed seconds."""
+    def sync_all():
+        ss.sync()
+        comm.device_sync()
+    out = []
+    for _ in range(regions):
+        sync_all()
+        comm.barrier()
+        sync_all()
+        t0 = time.perf_counter()
+        ss.push(steps * ss.BT)
+        sync_all()
+        comm.barrier()
+        sync_all()
+        out.append(comm.max_over_ranks(time.perf_counter() - t0))
+    return out
+
+
+def warp_roofline(ss, alg_bytes_per_frame, frames_out_timed, kernel, stage_ms, stage_n):
+    """Warp kernel(s) of the timed regions: HIP-event time of their launches on the stream they run on."""
     # (a batch of more than 32 frames is warped by ceil(batch / 32) launches back to back inside one pair of events)
-    launches = max(stage_n[7], 1) * max(1, (ss.WB_frames + 31) // 32)
+    launches = max(stage_n[capi.STAGE_WARP], 1) * max(1, (ss.WB_frames + 31) // 32)
     frames_per_launch = frames_out_timed / launches
-    avg_ms = stage_ms[7] / launches
+    avg_ms = stage_ms[capi.STAGE_WARP] / launches
     byts = alg_bytes_per_frame * frames_per_launch
     achieved = byts / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": byts,
             "frames_per_launch": round(frames_per_launch, 3), "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches}
-    return roof, stage_ms, stage_n
 
 
-def traffic_from_counters(vs, roof, frame_bytes):
-    """HBM bytes per launch from the PMC passes kept in profiles/warp_traffic.json - only when that file was measured on
+def tables_pass(ss, roof, steps):
+    """The coordinate-table kernel (warp_tables_kernel) is queued right behind the batch tail, outside the warp stage's
+    event pair; its time is measured here, in a region of its own (profiling mode 3: one more event pair per batch on the
+    critical stream, so not inside the headline regions) and folded into `stage_frac` = algorithmic bytes over
+    warp + tables time."""
+    for s in ss.stabs:
+        s.set_profiling(3)
+        s.stage_times()
+    ss.push(steps * ss.BT)
+    ss.sync()
+    ms, n = ss.stage_totals()
+    for s in ss.stabs:
+        s.set_profiling(1)
+    if n[capi.STAGE_WARP_TABLES] == 0 or n[capi.STAGE_WARP] == 0:
+        roof["tables_note"] = "no table launches (per-frame pipeline)"
+        return
+    # a batch's tables are built by one event-bracketed group of launches (one per 32 frames and plane), like its warps
+    per_launch = max(1, (ss.WB_frames + 31) // 32)
+    tab_us = ms[capi.STAGE_WARP_TABLES] / n[capi.STAGE_WARP_TABLES] * 1e3 / per_launch
+    warp_us = ms[capi.STAGE_WARP] / n[capi.STAGE_WARP] * 1e3 / per_launch
+    roof["tables_us_per_launch"] = round(tab_us, 3)
+    roof["warp_us_in_tables_pass"] = round(warp_us, 3)
+    stage_gbps = roof["bytes_per_launch"] / ((roof["avg_launch_us"] + tab_us) * 1e-6) / 1e9
+    roof["stage_frac"] = round(stage_gbps / HBM_PEAK_GBPS, 4)
+    roof["stage_note"] = ("frac = the warp kernel(s) alone (avg_launch_us); stage_frac = warp kernel(s) + the coordinate-table "
+                          "kernel (warp_tables_kernel: tables_us_per_launch, measured in a separate region)")
+
+
+def traffic_from_counters(vs, roof, key):
+    """HBM bytes per launch from the PMC passes kept in profiles/warp_traffic.json - only when that entry was measured on
     THIS build of the kernels (vs_build_tag); otherwise the field stays null and says why."""
     pmc = os.path.join(ROOT, "profiles", "warp_traffic.json")
     try:
-        t = json.load(open(pmc))
+        t = json.load(open(pmc)).get(key)
     except Exception:
-        roof["traffic_note"] = "no counter file"
+        t = None
+    if not t:
+        roof["traffic_note"] = "no counter entry '%s' in profiles/warp_traffic.json" % key
         return
     tag = vs.lib.vs_build_tag().decode()
     if t.get("build_tag") != tag:
-        roof["traffic_note"] = "stale: profiles/warp_traffic.json was measured on build %s, this is %s" % (t.get("build_tag"), tag)
+        roof["traffic_note"] = "stale: profiles/warp_traffic.json[%s] was measured on build %s, this is %s" % (key, t.get("build_tag"), tag)
         return
-    per_frame = t["hbm_bytes_per_launch"] / t["frames_per_launch"] * (frame_bytes / (1920 * 1080 * 3.0))
-    roof["traffic"] = round(per_frame * roof["frames_per_launch"])
-    roof["traffic_note"] = "FETCH_SIZE x2 + WRITE_SIZE of %s (%d-frame launches), scaled to this launch" % (t.get("source"), t["frames_per_launch"])
+    scale = roof["frames_per_launch"] / t["frames_per_launch"]
+    roof["traffic"] = round(t["hbm_bytes_per_launch"] * scale)
+    roof["traffic_read"] = round(t["read_bytes_per_launch"] * scale)
+    roof["traffic_write"] = round(t["write_bytes_per_launch"] * scale)
+    roof["traffic_note"] = "FETCH_SIZE x2 + WRITE_SIZE of %s (%d-frame launches, %s MB of distinct input), scaled to this launch" % (
+        t.get("source"), t["frames_per_launch"], t.get("distinct_input_MB", "?"))
+
+
+def copy_yardstick(vs, nbytes):
+    """What a plain device copy of the same number of bytes reaches on this device (vs_dev_copy_rate: 16 bytes per lane,
+    streaming stores, HIP events around 20 back-to-back launches over buffers that together exceed the Infinity Cache)."""
+    import ctypes as C
+    rate = C.c_double(0.0)
+    vs.check(vs.lib.vs_dev_copy_rate(C.c_size_t(int(nbytes)), 20, C.byref(rate)))
+    return round(rate.value, 1)
 
 
 def host_api_rate(vs, device, params, frames, n_timed=240):
     """vs_stab_push: host frame in, host frame out (what vs::Stabilizer::stabilize(cv::Mat) calls) - PCIe both ways.
     Frames in pageable memory (numpy arrays as they come: what a cv::Mat holds) or page-locked (vs_host_alloc); the
-    synchronous call or the host pipeline (vs_stab_set_host_pipeline, VS_STAB_HOST_PIPELINE=1 for the C++ class: a call
+    synchronous call or the host pipeline (vs_stab_set_host_pipeline; Parameters::hostPipeline for the C++ class: a call
     returns the previous call's frame, its download runs beside this call's upload)."""
     order = clip_order(len(frames), 64 + n_timed)
 
@@ -234,49 +313,79 @@ def host_api_rate(vs, device, params, frames, n_timed=240):
             "page_locked_host_pipeline": dict(run(True, True), what="host pipeline, frames in page-locked memory")}
 
 
-def config2(vs, device, args):
+def cpp_class_rate(device):
+    """vs::Stabilizer::stabilize(cv::Mat) measured through the C++ class itself (tests/cpp/wrapper_smoke.cpp built against
+    the test cv::Mat, `--time`): default construction (synchronous) and the pipelined call."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "wrapper_time")
+    if not os.path.exists(exe):
+        return {"note": "tests/cpp/_build/wrapper_time not built (make -C tests/cpp)"}
+    try:
+        r = subprocess.run([exe, str(device)], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"note": "wrapper_time failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+    except Exception as e:       # noqa: BLE001 - a missing extra must not lose the headline line
+        return {"note": "wrapper_time: %r" % (e,)}
+
+
+def run_stream_workload(comm, ss, steps, warmup, regions, preroll_batches, profile_stages, alg_bytes_per_frame, kernel):
+    """Setup (not a step): past the 29-frame warm-up of smoothingRadius 30 (every later push produces a frame) and
+    `preroll_batches` batches of the same work so that the device's clocks and the allocator's first touches are not part
+    of the W warm-up steps; then W warm-up steps and the timed regions."""
+    BT = ss.BT
+    ss.push(64 + preroll_batches * BT)
+    ss.sync()
+    comm.device_sync()
+    ss.push(warmup * BT)
+    for s in ss.stabs:
+        s.set_profiling(2 if profile_stages else 1)
+        s.stage_times()          # drop anything recorded so far
+    frames_before = ss.frames_out()
+    elapsed = timed_regions(ss, comm, steps, regions)
+    frames_out_timed = ss.frames_out() - frames_before
+    assert frames_out_timed == steps * BT * len(ss.stabs) * regions, "timed steps did not all produce frames"
+    stage_ms, stage_n = ss.stage_totals()
+    roof = warp_roofline(ss, alg_bytes_per_frame, frames_out_timed, kernel, stage_ms, stage_n)
+    return elapsed, roof, stage_ms, stage_n
+
+
+def config2(vs, comm, device, args, full=True):
     """BASELINE configs[2]: 3840x2160, 400 corners, RollCorrection + AutoZoomCrop enabled."""
     W, H = 3840, 2160
     out = {"workload": "configs[2]: 1 stream 3840x2160, 400 corners, 3-level LK 21x21; frames resident in HBM"}
-    bgr = synth.make_clip(synth.SEED_CONFIG3, W, H, 6)
     p = make_params(vs, max_corners=400)
-    # (a) the stream as a decoder hands it over: NV12 surfaces, batch mode
-    nv = [synth.bgr_to_nv12(f) for f in bgr]
-    # batches of 64 like configs[1], and the same kind of run-in (40 batches: the device's clocks are still rising during the
-    # first ones - 16-frame batches behind 2 warm-up batches, the first form of this measurement, read 45 k frames/s where
-    # batches of 32 behind 40 read 61 k and batches of 64 67 k; scratch/config2_sweep.py).  VS_BENCH_4K_* override the three numbers.
+    # (a) the stream as a decoder hands it over: NV12 surfaces, batch mode.  64 distinct surfaces (796 MB) in a cycle.
+    NF = int(os.environ.get("VS_BENCH_4K_CLIP", "64"))
+    clip = synth.make_clip_dev(vs, synth.SEED_CONFIG3, W, H, NF, nv12=True)
     BT = int(os.environ.get("VS_BENCH_4K_BATCH", "64"))
-    ss = StreamSet(vs, device, p, [nv], W, H, capi.FMT_NV12, BT, BT, True)
-    ss.push(64)
-    ss.sync()
-    ss.push(int(os.environ.get("VS_BENCH_4K_WARM", "40")) * BT)
-    for s in ss.stabs:
-        s.set_profiling(1)
-        s.stage_times()
-    ss.sync()
-    f0 = ss.frames_out()
-    nb = int(os.environ.get("VS_BENCH_4K_TIMED", "40"))
-    t0 = time.perf_counter()
-    ss.push(nb * BT)
-    ss.sync()
-    dt = time.perf_counter() - t0
-    fo = ss.frames_out() - f0
-    roof, _, _ = warp_roofline(ss, 2.0 * nv[0].nbytes, fo, "warp_plane_kernel<1> + <2> (Y and interleaved UV plane)")
-    out["nv12_stabilize"] = {"value": round(fo / dt, 1), "unit": "frames/s", "batch": BT, "timed_frames": fo, "roofline": roof}
+    ss = StreamSet(vs, device, p, [clip], NF, W, H, capi.FMT_NV12, BT, BT, True)
+    steps = int(os.environ.get("VS_BENCH_4K_TIMED", "20"))
+    regions = int(os.environ.get("VS_BENCH_4K_REGIONS", str(args.regions)))
+    fb = W * H * 3 // 2
+    elapsed, roof, _, _ = run_stream_workload(comm, ss, steps, 4, regions, int(os.environ.get("VS_BENCH_4K_WARM", "40")),
+                                              False, 2.0 * fb, "warp_plane_kernel<1> + <2> (Y and interleaved UV plane)")
+    med = statistics.median(elapsed)
+    tables_pass(ss, roof, steps)
+    traffic_from_counters(vs, roof, "configs2")
+    roof["distinct_input_MB"] = round(NF * fb / 1e6, 1)
+    out["nv12_stabilize"] = {"value": round(steps * BT / med, 1), "unit": "frames/s", "batch": BT, "steps": steps,
+                             "regions": [round(steps * BT / e, 1) for e in elapsed], "roofline": roof}
     ss.close()
+    if not full:
+        return out
     # (b) the reference's order of operators on a 4K BGR frame: roll correction -> stabilize -> auto zoom/crop (each
     # call finished before the next: the reference's loop is synchronous, examples/roll-correction-file.cpp:58-70)
-    fb = bgr[0].nbytes
-    d_f = capi.DevBuf(vs, fb * len(bgr))
-    for i, f in enumerate(bgr):
-        d_f.upload(f, i * fb)
+    NB = 8
+    bclip = synth.make_clip_dev(vs, synth.SEED_CONFIG3, W, H, NB)
+    fb = W * H * 3
     d_r, d_s, d_z = capi.DevBuf(vs, fb), capi.DevBuf(vs, fb), capi.DevBuf(vs, fb)   # (the zoom stage returns the frame as it is when it finds no crop)
     rc, az = vs.roll_correction(), vs.auto_zoom_crop()
     st = vs.stabilizer(p, device=device)
-    order = clip_order(len(bgr), 40 + 100)
 
     def one(i):
-        rc.correct_dev(d_f.ptr + order[i] * fb, W, H, W * 3, d_r.ptr, W * 3)
+        rc.correct_dev(bclip.ptr + (i % NB) * fb, W, H, W * 3, d_r.ptr, W * 3)
         rc.sync()
         k = st.push_dev(d_r.ptr, W, H, W * 3, capi.FMT_BGR8, d_s.ptr, W * 3)
         st.sync()
@@ -292,7 +401,7 @@ def config2(vs, device, args):
     out["roll_stabilize_zoomcrop_bgr"] = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n, 1) * 1e3, 3),
                                           "what": "autoCorrectRoll -> stabilize -> autoZoomCrop per 4K BGR frame, one frame at a time"}
     st.close()
-    for b in (d_f, d_r, d_s, d_z):
+    for b in (bclip, d_r, d_s, d_z):
         b.free()
     return out
 
@@ -300,15 +409,19 @@ def config2(vs, device, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40, help="timed steps; a step = one batch of --batch frames per stream")
-    ap.add_argument("--warmup", type=int, default=8, help="untimed steps in front of them")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps per region; a step = one batch of --batch frames per stream")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps in front of the first region")
+    ap.add_argument("--regions", type=int, default=9, help="the timed region of --steps steps is repeated this often; value = the median")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU (batch mode)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--clip-frames", type=int, default=12)
+    ap.add_argument("--clip-frames", type=int, default=128,
+                    help="distinct frames per stream, played in a cycle (a multiple of 4; 128 x 6.2 MB = 796 MB at 1080p)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and configs[2] measurements")
     ap.add_argument("--profile-stages", action="store_true", help="time every stage (adds event records)")
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2"],
+                    help="configs2: the 3840x2160 NV12 stream of BASELINE configs[2] alone (profiling runs of its kernels)")
     ap.add_argument("--zero-copy", type=int, default=1,
                     help="frames are read where they lie in HBM instead of being copied into the instance's queue")
     ap.add_argument("--batch", type=int, default=64,
@@ -320,11 +433,11 @@ def main():
                     help="a config.yaml of the reference's apps: its 'stabilizer' section replaces the configs[1] "
                          "parameters (not the headline workload any more: no cpu_baseline, the workload string says so)")
     ap.add_argument("--fanout", action="store_true",
-                    help="N > 1 only: rank 0 owns ingest - it generates the clips of ALL streams and scatters them to the "
+                    help="N > 1 only: rank 0 owns ingest - it renders the clips of ALL streams and scatters them to the "
                          "owning ranks (RCCL send/recv over xGMI) before the timed region; timed separately, reported as `fanout`")
     args = ap.parse_args()
 
-    comm = vsdist.Comm()           # nccl (= RCCL) when WORLD_SIZE > 1, nothing otherwise
+    comm = vsdist.Comm()           # nccl (= RCCL) when WORLD_SIZE > 1 (or VS_DIST_FORCE=1), nothing otherwise
     rank, local_rank, world = comm.rank, comm.local_rank, comm.world
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
@@ -337,76 +450,78 @@ def main():
         local_rank = int(os.environ["VS_BENCH_DEVICE"])
     vs.check(vs.lib.vs_dev_set_device(local_rank))
 
+    if args.workload == "configs2":
+        out = config2(vs, comm, local_rank, args, full=False)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        comm.close()
+        return
+
     W, H = args.width, args.height
     fb = W * H * 3
     S = args.streams
+    NF = args.clip_frames
     # synthetic clips: global stream g (owned by rank g % world) uses seed base + g
     my_streams = vsdist.streams_of_rank(rank, n_gpus, S * n_gpus)
     assert len(my_streams) == S
     fanout = None
-    clips = [synth.make_clip(synth.SEED_CONFIG2 + g, W, H, args.clip_frames) for g in my_streams]
     if args.fanout and world > 1:
-        # ingest on rank 0: the frame payloads travel to the owning GPUs with one scatter, timed on its own
+        # ingest on rank 0: it renders every stream's clip on its own GPU; the frame payloads travel to the
+        # owning GPUs with one scatter, timed on its own
         payloads = None
         if rank == 0:
-            payloads = [np.concatenate([np.stack(synth.make_clip(synth.SEED_CONFIG2 + g, W, H, args.clip_frames)).reshape(-1)
-                                        for g in vsdist.streams_of_rank(r, n_gpus, S * n_gpus)]) for r in range(world)]
-        nbytes = fb * args.clip_frames * S
+            payloads = []
+            for r in range(world):
+                parts = []
+                for g in vsdist.streams_of_rank(r, n_gpus, S * n_gpus):
+                    c = synth.make_clip_dev(vs, synth.SEED_CONFIG2 + g, W, H, NF)
+                    parts.append(c.download((NF * fb,), np.uint8))
+                    c.free()
+                payloads.append(np.concatenate(parts))
+        nbytes = fb * NF * S
         recv, secs = comm.fan_out(payloads, nbytes)
-        got = (recv.cpu().numpy() if comm.device == "cuda" else recv.numpy()).reshape(S, args.clip_frames, H, W, 3)
-        clips = [list(got[j]) for j in range(S)]
+        clips = []
+        for j in range(S):
+            c = capi.DevBuf(vs, NF * fb)
+            if comm.device == "cuda":       # device to device: out of the tensor RCCL filled, into the stream's clip
+                vs.check(vs.lib.vs_dev_memcpy_d2d(c.ptr, recv.data_ptr() + j * NF * fb, NF * fb))
+            else:
+                c.upload(recv.numpy()[j * NF * fb:(j + 1) * NF * fb])
+            clips.append(c)
         sent = nbytes * (world - 1)
         fanout = {"bytes": sent, "ms": round(secs * 1e3, 3), "GBps": round(sent / secs / 1e9, 2) if secs > 0 else None,
                   "what": "scatter of %d frames per stream from rank 0 to %d ranks (torch.distributed.scatter, %s)" % (
-                      args.clip_frames, world - 1, "RCCL" if comm.device == "cuda" else "gloo, host memory")}
+                      NF, world - 1, "RCCL" if comm.device == "cuda" else "gloo, host memory")}
+    else:
+        clips = [synth.make_clip_dev(vs, synth.SEED_CONFIG2 + g, W, H, NF) for g in my_streams]
 
     params = make_params(vs, args.config)
-    ss = StreamSet(vs, local_rank, params, clips, W, H, capi.FMT_BGR8, args.batch, args.warp_batch, args.zero_copy)
+    ss = StreamSet(vs, local_rank, params, clips, NF, W, H, capi.FMT_BGR8, args.batch, args.warp_batch, args.zero_copy)
     BT = ss.BT
-    # setup, not a step: past the 29-frame warm-up of smoothingRadius 30 (every later push produces a frame), and ~0.1 s of the
-    # same work so that the device's clocks and the allocator's first touches are not part of the W warm-up steps' job
-    preroll = 64 + int(os.environ.get("VS_BENCH_PREROLL_BATCHES", "200")) * BT
-
-    def sync_all():
-        ss.sync()
-        comm.device_sync()
-
-    ss.push(preroll)
-    sync_all()
-    ss.push(args.warmup * BT)
-    for s in ss.stabs:
-        s.set_profiling(2 if args.profile_stages else 1)
-        s.stage_times()          # drop anything recorded so far
-    sync_all()
-    comm.barrier()
-    sync_all()
-    frames_before = ss.frames_out()
-    t0 = time.perf_counter()
-    ss.push(args.steps * BT)
-    sync_all()
-    comm.barrier()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    elapsed = comm.max_over_ranks(elapsed)
-
-    frames_out_timed = ss.frames_out() - frames_before
-    assert frames_out_timed == args.steps * BT * S, "timed steps did not all produce frames"
-    roof, stage_ms, stage_n = warp_roofline(ss, 2.0 * fb, frames_out_timed,
-                                            "warp_tab_kernel (+ warp_tables_kernel)" if BT >= 4 else "warp_affine_kernel<3>")
+    elapsed, roof, stage_ms, stage_n = run_stream_workload(
+        comm, ss, args.steps, args.warmup, args.regions, int(os.environ.get("VS_BENCH_PREROLL_BATCHES", "200")),
+        args.profile_stages, 2.0 * fb, "warp_tab_kernel" if BT >= 4 else "warp_affine_kernel<3>")
+    med = statistics.median(elapsed)
     # throughput counters of every rank (the only inter-GPU traffic of the path)
     per_rank = comm.gather_counters([rank, args.steps * BT * S, ss.frames_out()])
 
+    out = None
     if rank == 0:
-        traffic_from_counters(vs, roof, fb)
+        tables_pass(ss, roof, args.steps)
+        traffic_from_counters(vs, roof, "configs1")
+        roof["copy_yardstick_GBps"] = copy_yardstick(vs, roof["bytes_per_launch"] / 2)
+        roof["distinct_input_MB"] = round(NF * fb / 1e6, 1)
         total_frames = args.steps * BT * S * n_gpus
+        whole_bytes = WHOLE_STEP_BYTES_1080P * (W * H) / (1920.0 * 1080.0)
+        whole = whole_bytes * total_frames / med / 1e9
         out = {
             "metric": "stabilized frames/sec @1080p (whole job; warp-stage HBM GB/s in roofline)",
-            "value": round(total_frames / elapsed, 2),
+            "value": round(total_frames / med, 2),
             "unit": "frames/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "ms_per_step": round(med / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -418,23 +533,31 @@ def main():
                        ("custom: %d stream(s)/GPU %dx%d BGR8, stabilizer parameters from %s; frames resident in HBM"
                         % (S, W, H, os.path.basename(args.config))),
                        "streams_per_gpu": S, "frames_per_step": BT, "step": "one batch of %d stabilize() calls per stream" % BT,
+                       "clip": "%d distinct frames per stream rendered on the device, played in a cycle" % NF,
                        "warp_batch": ss.WB, "zero_copy": bool(args.zero_copy),
                        "timed_frames_per_rank": [int(r[1]) for r in per_rank], "build": vs.lib.vs_build_tag().decode()},
+            "regions": {"count": args.regions, "value": "median", "frames_per_s": [round(total_frames / e, 1) for e in elapsed]},
             "roofline": roof,
+            "whole_step": {"bytes_per_frame": round(whole_bytes), "achieved": round(whole, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(whole / HBM_PEAK_GBPS, 4),
+                           "note": "SURVEY 8d: algorithmic bytes of the whole step (gray, pyramid, GFTT every 2nd frame, LK gathers, "
+                                   "warp) x frames / elapsed"},
         }
         if fanout is not None:
             out["fanout"] = fanout
         if args.profile_stages:
-            names = ["copy_in", "gray", "pyramid", "lk", "ransac", "traj", "gftt", "warp"]
-            out["stage_us_per_launch"] = {names[k]: round(stage_ms[k] / max(stage_n[k], 1) * 1e3, 2) for k in range(8)}
-            out["stage_launches"] = {names[k]: stage_n[k] for k in range(8)}
+            names = ["copy_in", "gray", "pyramid", "lk", "ransac", "traj", "gftt", "warp", "warp_tables"]
+            out["stage_us_per_launch"] = {names[k]: round(stage_ms[k] / max(stage_n[k], 1) * 1e3, 2) for k in range(capi.STAGE_COUNT)}
+            out["stage_launches"] = {names[k]: stage_n[k] for k in range(capi.STAGE_COUNT)}
+    host_frames = ss.host_frames(0, 32) if rank == 0 and n_gpus == 1 and not args.config else []
     ss.close()
     if rank == 0:
         if n_gpus == 1 and not args.no_extras and not args.config:
-            out["with_pcie"] = host_api_rate(vs, local_rank, params, clips[0])
-            out["configs"] = {"configs[2]": config2(vs, local_rank, args)}
+            out["with_pcie"] = host_api_rate(vs, local_rank, params, host_frames[:12])
+            out["with_pcie"]["cpp_class"] = cpp_class_rate(local_rank)
+            out["configs"] = {"configs[2]": config2(vs, comm, local_rank, args)}
         if n_gpus == 1 and not args.no_cpu_baseline and not args.config:
-            out["cpu_baseline"] = cpu_baseline(W, H, clips[0], clip_order)
+            out["cpu_baseline"] = cpu_baseline(W, H, host_frames, clip_order)
         print(json.dumps(out), flush=True)
     comm.close()
 

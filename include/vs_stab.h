@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define VS_STAB_ABI_VERSION 1
+/* 2: VS_STAGE_COUNT grew to 9 (VS_STAGE_WARP_TABLES: the arrays of vs_stab_get_stage_times), vs_params_c.host_pipeline took the
+ *    last reserved slot, vs_stab_enable_graph is gone (round 2), vs_batch_* and vs_dev_copy_rate / vs_dev_memcpy_d2d added. */
+#define VS_STAB_ABI_VERSION 2
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -297,7 +299,8 @@ int vs_stab_set_nv12_layout(vs_stab* s, size_t in_uv_offset, size_t out_uv_offse
 
 /* Per-stage device timing with HIP events recorded on the instance stream
  * (SURVEY.md section 5 "Tracing").  mode 0 = off, 1 = warp stage only,
- * 2 = every stage.  vs_stab_get_stage_times() synchronises, adds the elapsed
+ * 2 = every stage, 3 = warp stage and the coordinate tables of batched warps.
+ * vs_stab_get_stage_times() synchronises, adds the elapsed
  * time of every event pair recorded since the last call into total_ms[stage]
  * / launches[stage] (arrays of VS_STAGE_COUNT) and resets. */
 enum {
@@ -309,7 +312,8 @@ enum {
     VS_STAGE_TRAJ = 5,      /* trajectory append + emit                        */
     VS_STAGE_GFTT = 6,
     VS_STAGE_WARP = 7,      /* warpAffine kernel(s) only                       */
-    VS_STAGE_COUNT = 8
+    VS_STAGE_WARP_TABLES = 8, /* batch mode: coordinate tables of a batch's warps (queued behind the batch tail) */
+    VS_STAGE_COUNT = 9
 };
 int vs_stab_set_profiling(vs_stab* s, int mode);
 int vs_stab_get_stage_times(vs_stab* s, double* total_ms, int64_t* launches);
@@ -321,7 +325,12 @@ int vs_dev_free(void* d_ptr);
 int vs_dev_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int vs_dev_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 int vs_dev_memset(void* d_dst, int value, size_t bytes);
+int vs_dev_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
 int vs_dev_sync(void);
+/* Bandwidth yardstick for roofline reports: GB/s (read + written bytes) of a plain device copy of `bytes` bytes - 16 bytes
+ * per lane, streaming stores - timed with HIP events around `iters` back-to-back launches that walk through buffers of
+ * together more than 512 MB, so no launch finds its input in the Infinity Cache. */
+int vs_dev_copy_rate(size_t bytes, int iters, double* gbytes_per_s);
 const char* vs_last_error(void);           /* thread-local, op-level calls    */
 
 /* ---- stage operators on device buffers (stream = hipStream_t or NULL) ------
@@ -341,6 +350,11 @@ int vs_op_warp_affine_nv12(const void* d_src, size_t src_stride, void* d_dst,
                            size_t dst_stride, int w, int h, const float* M,
                            int batch, size_t src_frame_bytes, size_t dst_frame_bytes,
                            void* stream);
+/* std::cos / std::sin / std::atan2 on float as the reference calls them (Stabilizer.cpp:662, 902-908, 1689: the host libm's
+ * cosf / sinf / atan2f), evaluated by the DEVICE build of the library's restatement: the sum over i in [start, start + count) of
+ * a 64-bit mix of (i, bits of f(argument i)) - fn 0 cosf, 1 sinf, 2 atanf: argument i = the float with bit pattern (uint32_t)i;
+ * fn 3 atan2f: pair i of a fixed generator.  tests/test_libm.py compares it with the same sum over the host libm's values. */
+int vs_op_libm_checksum(int fn, uint64_t start, uint64_t count, uint64_t* result);
 /* cv::resize(INTER_LINEAR) + cv::cvtColor(BGR2GRAY) - Stabilizer.cpp:304-305,
  * 448-450.  fmt BGR8 (resize then gray), GRAY8 / NV12 (luma plane resize). */
 int vs_op_resize_gray(const void* d_src, size_t src_stride, int sw, int sh, int fmt,

@@ -1,0 +1,11 @@
+#!/bin/bash
+# ab_plane.sh <outdir>: bench.py --workload configs2 with the first and the second plane kernel, alternating (same box)
+OUT=$1; mkdir -p $OUT
+for rep in 1 2; do for v in 1 3; do
+  VS_WARP_PLANE_KERNEL=$v python3 bench.py --workload configs2 > $OUT/c2_plane${v}_$rep.json 2>> $OUT/err.log
+  python3 - <<PY
+import json
+b=json.load(open("$OUT/c2_plane${v}_$rep.json"))["nv12_stabilize"]
+print("plane_kernel=$v rep $rep: %.0f f/s warp %.1f us frac %.4f" % (b["value"], b["roofline"]["avg_launch_us"], b["roofline"]["frac"]))
+PY
+done; done

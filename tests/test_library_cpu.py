@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(vs):
 
 
 def test_abi_version_and_build_info(vs):
-    assert vs.lib.vs_abi_version() == 1
+    assert vs.lib.vs_abi_version() == 2
     info = vs.lib.vs_build_info().decode()
     assert "gfx950" in info
 

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
             if (l_nprev[f] > 0 && a.have_prev_gray) {
                 float T[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
                 if (a.info[0]) for (int i = 0; i < 6; i++) T[i] = (float)a.model[i];
-                t3[0] = T[2]; t3[1] = T[5]; t3[2] = atan2f(T[3], T[0]);
+                t3[0] = T[2]; t3[1] = T[5]; t3[2] = vslibm::atan2f_ref(T[3], T[0]);
             }
             l_trf[f][0] = t3[0]; l_trf[f][1] = t3[1]; l_trf[f][2] = t3[2];
         }

@@ -12,7 +12,11 @@
 // path_); the Kalman filter is advanced incrementally (it is a forward
 // recursion, so resuming from the stored state reproduces the reference's
 // from-scratch run bit for bit).
+#include <algorithm>
+#include <string>
+
 #include "vs_common.h"
+#include "vs_libm.h"
 #include "traj_state.h"
 #include "traj_device.h"
 #include "traj_emit_device.h"
@@ -29,6 +33,52 @@ __global__ __launch_bounds__(64) void traj_emit_kernel(TrajState* s, TrajParams 
 __global__ void spin_kernel(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+// Checksum of a libm restatement (vs_libm.h) over a range of arguments, for the parity test against the host's libm
+// (tests/test_libm.py): fn 0 cosf, 1 sinf, 2 atanf - argument i is the float with bit pattern (uint32)(start + i) -, 3 atan2f -
+// argument pair i from libm_pair().  The sum of mix(i, result bits) over the range, NaN results as one pattern.
+__host__ __device__ inline uint64_t libm_mix(uint64_t i, uint32_t bits) {
+    uint64_t z = (i * 0x9E3779B97F4A7C15ull) ^ (uint64_t)bits;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline void libm_pair(uint64_t i, float* y, float* x) {
+    uint64_t v = libm_mix(i, 0x5EEDu);
+    if (i & 1) { *y = vslibm::u2f((uint32_t)v); *x = vslibm::u2f((uint32_t)(v >> 32)); return; }      // any two bit patterns
+    // shaped like the stabilizer's arguments: (sin, cos) of a small rotation times a scale near 1, or pixel translations
+    float xx = 0.9f + 0.2f * ((float)(v & 0xFFFFFFu) / 16777216.0f);
+    float yy = ((float)((v >> 24) & 0xFFFFFFu) / 16777216.0f - 0.5f) * (((v >> 48) & 1) ? 0.5f : 0.02f);
+    if ((v >> 49) & 1) { xx = (xx - 1.0f) * 200.0f; yy *= 100.0f; }
+    *y = yy; *x = xx;
+}
+__global__ __launch_bounds__(256) void libm_checksum_kernel(int fn, uint64_t start, uint64_t count, unsigned long long* out) {
+    uint64_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t idx = start + i;
+        float r;
+        if (fn == 3) { float y, x; libm_pair(idx, &y, &x); r = vslibm::atan2f_ref(y, x); }
+        else {
+            const float x = vslibm::u2f((uint32_t)idx);
+            r = fn == 0 ? vslibm::cosf_ref(x) : (fn == 1 ? vslibm::sinf_ref(x) : vslibm::atanf_ref(x));
+        }
+        acc += libm_mix(idx, r != r ? 0x7FC00000u : vslibm::f2u(r));
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)acc);
+}
+
+// Bandwidth yardstick (vs_dev_copy_rate): a plain copy, 16 bytes per lane, four in flight per lane, streaming stores.
+typedef uint32_t copy_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_rate_kernel(const copy_u32x4* __restrict__ src, copy_u32x4* __restrict__ dst, size_t n16) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x);
+    const size_t stride = (size_t)gridDim.x * 256;
+    copy_u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i0 + k * stride < n16) v[k] = src[i0 + k * stride];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i0 + k * stride < n16) __builtin_nontemporal_store(v[k], &dst[i0 + k * stride]);
 }
 
 __global__ void traj_reset_kernel(TrajState* s, int smoothing_radius) {
@@ -146,6 +196,55 @@ int launch_make_border(const uint8_t* src, size_t sstride, int w, int h, int cn,
     dim3 grid((w + 2 * b + 255) / 256, h + 2 * b);
     hipLaunchKernelGGL(make_border_kernel, grid, dim3(256), 0, st, src, sstride, w, h, cn, dst, dstride, b, border);
     VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// vs_dev_copy_rate: `iters` back-to-back copies of `bytes` bytes between HIP events; source and destination walk through
+// rings of buffers that together exceed 512 MB, so that no copy finds its source in the 256 MB Infinity Cache.
+int run_copy_rate(size_t bytes, int iters, double* gbps) {
+    const size_t n16 = bytes / 16, b = n16 * 16;
+    const int ring = (int)std::max<size_t>(2, ((size_t)640 << 20) / b + 1);
+    uint8_t *src = nullptr, *dst = nullptr;
+    VS_HIP_TRY(hipMalloc((void**)&src, b * ring));
+    if (hipMalloc((void**)&dst, b * ring) != hipSuccess) { (void)hipFree(src); set_last_error("vs_dev_copy_rate: out of device memory"); return VS_ERR_HIP; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMemset(src, 0x5a, b * ring);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const unsigned grid = (unsigned)((n16 + 4 * 256 - 1) / (4 * 256));
+    float ms = 0.f;
+    if (e == hipSuccess) {
+        for (int i = 0; i < 3; i++)
+            hipLaunchKernelGGL(copy_rate_kernel, dim3(grid), dim3(256), 0, nullptr, (const copy_u32x4*)(src + b * (i % ring)), (copy_u32x4*)(dst + b * (i % ring)), n16);
+        e = hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters; i++)
+            hipLaunchKernelGGL(copy_rate_kernel, dim3(grid), dim3(256), 0, nullptr, (const copy_u32x4*)(src + b * ((i + 3) % ring)), (copy_u32x4*)(dst + b * ((i + 3) % ring)), n16);
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(dst);
+    if (e != hipSuccess) { set_last_error(std::string("vs_dev_copy_rate: ") + hipGetErrorString(e)); return VS_ERR_HIP; }
+    *gbps = ms > 0.f ? 2.0 * (double)b * iters / (ms * 1e-3) / 1e9 : 0.0;
+    return VS_OK;
+}
+
+int run_libm_checksum(int fn, uint64_t start, uint64_t count, uint64_t* result) {
+    unsigned long long* d = nullptr;
+    VS_HIP_TRY(hipMalloc((void**)&d, sizeof *d));
+    hipError_t e = hipMemset(d, 0, sizeof *d);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)std::min<uint64_t>((count + 255) / 256, 8192);
+        hipLaunchKernelGGL(libm_checksum_kernel, dim3(grid ? grid : 1), dim3(256), 0, nullptr, fn, start, count, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) { set_last_error(std::string("vs_op_libm_checksum: ") + hipGetErrorString(e)); return VS_ERR_HIP; }
+    *result = h;
     return VS_OK;
 }
 

@@ -275,7 +275,8 @@ struct StageScope {
         return e;
     }
     StageScope(vs_stab* s_, int stage_, hipStream_t st_) : s(s_), stage(stage_), st(st_) {
-        if (s->prof_mode == 2 || (s->prof_mode == 1 && stage == VS_STAGE_WARP)) {
+        if (s->prof_mode == 2 || (s->prof_mode == 1 && stage == VS_STAGE_WARP) ||
+            (s->prof_mode == 3 && (stage == VS_STAGE_WARP || stage == VS_STAGE_WARP_TABLES))) {
             a = get(s); b = get(s);
             if (a && b && hipEventRecord(a, st) == hipSuccess) on = true;
         }
@@ -1146,6 +1147,7 @@ int run_batch(vs_stab* s) {
         // the maps of these warps exist once the tail has run: their coordinate tables are built right behind it
         R.tabs_built = false;
         if (R.valid && std::getenv("VS_STAB_TABLES_WITH_WARP") == nullptr) {
+            StageScope t(s, VS_STAGE_WARP_TABLES, st);
             S_TRY(s, ready_launches(s, VS_WARP_TABLES_ONLY));
             R.tabs_built = true;
         }
@@ -1745,7 +1747,7 @@ const char* vs_stab_last_error(const vs_stab* s) { return s ? s->err.c_str() : "
 void* vs_stab_stream(vs_stab* s) { return s ? (void*)s->st : nullptr; }
 
 int vs_stab_set_profiling(vs_stab* s, int mode) {
-    if (!s || mode < 0 || mode > 2) return VS_ERR_INVALID_ARG;
+    if (!s || mode < 0 || mode > 3) return VS_ERR_INVALID_ARG;
     s->prof_mode = mode;
     return VS_OK;
 }

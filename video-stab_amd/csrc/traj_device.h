@@ -7,6 +7,7 @@
 
 #include "traj_state.h"
 #include "vs_common.h"
+#include "vs_libm.h"
 
 namespace vsd {
 
@@ -27,7 +28,7 @@ __device__ __forceinline__ void traj_append_device(TrajState* s, const TrajParam
             for (int i = 0; i < 6; i++) { T[i] = (float)model[i]; dbg->model[i] = model[i]; }
         }
         dbg->ransac_best_iter = info[1]; dbg->ransac_iters_run = info[2]; dbg->n_inliers = info[3];
-        tr[0] = T[2]; tr[1] = T[5]; tr[2] = atan2f(T[3], T[0]);   // :660-662
+        tr[0] = T[2]; tr[1] = T[5]; tr[2] = vslibm::atan2f_ref(T[3], T[0]);   // :660-662
         if (p.drone) {
             // applyDeadZoneFreeze :2605-2655 (updateMotionAccumulator :2667-2682)
             const float magnitude = hf_mag(tr);

@@ -16,6 +16,7 @@
 
 #include "traj_state.h"
 #include "vs_common.h"
+#include "vs_libm.h"
 
 namespace vsd {
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ void traj_matrix_lane(const float* t3, float* __restr
         for (int i = 0; i < 6; i++) M_out[6 + i] = M_out[i];
     } else {
         const float dx = t3[0], dy = t3[1], da = t3[2];
-        const float cs = cosf(da), sn = sinf(da);
+        const float cs = vslibm::cosf_ref(da), sn = vslibm::sinf_ref(da);     // glibc's cosf / sinf, bit for bit (vs_libm.h)
         M_out[0] = cs; M_out[1] = -sn; M_out[2] = dx;
         M_out[3] = sn; M_out[4] = cs; M_out[5] = dy;
         // chroma plane of an NV12 surface: same rotation, translation halved
@@ -249,7 +250,7 @@ __device__ __forceinline__ void traj_intent_samples(const float (*l_tr)[3], int 
     if (lane < 15 && i < idx && i < n) {
         const float t0 = l_tr[i & (TRAJ_RING - 1)][0], t1 = l_tr[i & (TRAJ_RING - 1)][1];
         mg = sqrtf(t0 * t0 + t1 * t1);
-        dr = atan2f(t1, t0);
+        dr = vslibm::atan2f_ref(t1, t0);
     }
 }
 

@@ -28,6 +28,8 @@ int ensure_device() {
 int launch_warp_affine_hostM(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                              uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
                              const float* h_M, int batch, hipStream_t st);
+int run_copy_rate(size_t bytes, int iters, double* gbps);
+int run_libm_checksum(int fn, uint64_t start, uint64_t count, uint64_t* result);
 int run_estimate_affine_partial2d(const float* d_from, const float* d_to, int n, double thr,
                                   int max_iters, double* d_model, uint8_t* d_inliers,
                                   int32_t* d_info, hipStream_t st);
@@ -162,6 +164,21 @@ int vs_dev_sync(void) {
     VS_TRY(ensure_device());
     VS_HIP_TRY(hipDeviceSynchronize());
     return VS_OK;
+}
+int vs_dev_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
+    VS_TRY(ensure_device());
+    VS_HIP_TRY(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+    return VS_OK;
+}
+int vs_op_libm_checksum(int fn, uint64_t start, uint64_t count, uint64_t* result) {
+    if (fn < 0 || fn > 3 || !result || count == 0) return VS_ERR_INVALID_ARG;
+    VS_TRY(ensure_device());
+    return vsd::run_libm_checksum(fn, start, count, result);
+}
+int vs_dev_copy_rate(size_t bytes, int iters, double* gbytes_per_s) {
+    if (!gbytes_per_s || bytes < 4096 || iters < 1 || iters > 1000) return VS_ERR_INVALID_ARG;
+    VS_TRY(ensure_device());
+    return vsd::run_copy_rate(bytes, iters, gbytes_per_s);
 }
 
 // ---- stage operators -----------------------------------------------------------

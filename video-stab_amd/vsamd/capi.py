@@ -20,6 +20,7 @@ i32p = C.POINTER(C.c_int32)
 FMT_BGR8, FMT_NV12, FMT_GRAY8 = 0, 1, 2
 BORDER_BLACK, BORDER_REFLECT, BORDER_REFLECT_101, BORDER_REPLICATE, BORDER_WRAP, BORDER_FADE = range(6)
 SMOOTH_BOX, SMOOTH_GAUSSIAN, SMOOTH_KALMAN = range(3)
+STAGE_WARP, STAGE_WARP_TABLES, STAGE_COUNT = 7, 8, 9      # vs_stab.h VS_STAGE_*
 
 
 class VsParams(C.Structure):
@@ -212,6 +213,8 @@ class VsLib:
         L.vs_dev_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
         L.vs_dev_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
         L.vs_dev_memset.argtypes = [vp, C.c_int, C.c_size_t]
+        L.vs_dev_memcpy_d2d.argtypes = [vp, vp, C.c_size_t]
+        L.vs_dev_copy_rate.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.vs_op_warp_affine.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                         C.c_int, f32p, C.c_int, vp]
         L.vs_op_warp_affine_nv12.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, f32p, C.c_int,
@@ -869,9 +872,9 @@ class Stabilizer:
         self.vs.check(self.lib.vs_stab_set_profiling(self.h, int(mode)), self.h)
 
     def stage_times(self):
-        """(total_ms[8], launches[8]) accumulated since the last call (synchronises)."""
-        ms = (C.c_double * 8)()
-        n = (C.c_int64 * 8)()
+        """(total_ms[STAGE_COUNT], launches[STAGE_COUNT]) accumulated since the last call (synchronises)."""
+        ms = (C.c_double * STAGE_COUNT)()
+        n = (C.c_int64 * STAGE_COUNT)()
         self.vs.check(self.lib.vs_stab_get_stage_times(self.h, ms, n), self.h)
         return list(ms), list(n)
 

@@ -131,3 +131,78 @@ def bgr_to_nv12(frame):
     uv[:, 0::2] = sub(u)
     uv[:, 1::2] = sub(v)
     return np.clip(np.vstack([yp, uv]), 0, 255).astype(np.uint8)
+
+
+# ---- long clips rendered on the device (bench.py: more distinct input than the 256 MB Infinity Cache holds) -----------
+def loop_script(seed, n_frames, pan_q8=512, jitter_q8=384, rot_1e5=200):
+    """Per-frame camera pose of a CLOSED pan path: n/4 frames right, down, left, up at pan_q8 per frame (the same jitter
+    and rotation model as motion_script), so that the clip can be played in a cycle without a cut - frame 0 follows frame
+    n-1 by one camera step - and no frame is read again before all the others have been."""
+    assert n_frames % 4 == 0 and n_frames >= 8
+    rng = XorShift64Star(seed ^ 0xA5A5A5A5)
+    q = n_frames // 4
+    px, py = 256 * 256, 256 * 256
+    poses = []
+    for k in range(n_frames):
+        if k > 0:
+            side = (k - 1) // q
+            px += (pan_q8, 0, -pan_q8, 0)[side]
+            py += (0, pan_q8, 0, -pan_q8)[side]
+
+        def gauss(std):
+            s = sum(rng.randint(-1000, 1000) for _ in range(4))
+            return (s * std) // 1155
+        jx, jy, ja = gauss(jitter_q8), gauss(jitter_q8), gauss(rot_1e5)
+        poses.append((px + jx, py + jy, (ja * 65536) // 100000))
+    return poses
+
+
+def _pose_forward_matrix(pose, width, height, scale=1.0):
+    """Forward 2x3 matrix (cv::warpAffine's M) whose inverse samples the world at `pose`: frame(x, y) =
+    world(R (x - cx, y - cy) + (cx + ox, cy + oy)).  scale 0.5: the same pose in the coordinates of a half-size plane."""
+    ox, oy, s16 = pose
+    s = s16 / 65536.0
+    c = (1.0 - s * s) ** 0.5
+    cx, cy = width * 0.5 * scale, height * 0.5 * scale
+    tx, ty = cx + ox / 256.0 * scale, cy + oy / 256.0 * scale
+    inv = np.array([[c, -s, tx - c * cx + s * cy], [s, c, ty - s * cx - c * cy], [0, 0, 1]], np.float64)
+    return np.ascontiguousarray(np.linalg.inv(inv)[:2].reshape(6))
+
+
+def make_clip_dev(vs, seed, width, height, n_frames, nv12=False, **kw):
+    """A closed-loop clip of n_frames frames rendered ON THE DEVICE from the world texture (one upload) with the library's
+    own warp operator (vs_op_warp_affine_ex); returns one DevBuf holding the packed frames (BGR8, or NV12: Y plane then
+    the interleaved UV plane).  Synthetic input only - nothing is compared against these frames' provenance."""
+    import ctypes as C
+    from . import capi
+    world = make_world(seed, width, height)
+    hw, ww = world.shape[:2]
+    poses = loop_script(seed, n_frames, **kw)
+    f64p = C.POINTER(C.c_double)
+    if not nv12:
+        fb = width * height * 3
+        d_world = capi.DevBuf.from_array(vs, world)
+        clip = capi.DevBuf(vs, fb * n_frames)
+        for i, p in enumerate(poses):
+            M = _pose_forward_matrix(p, width, height)
+            vs.check(vs.lib.vs_op_warp_affine_ex(d_world.ptr, ww * 3, ww, hw, clip.ptr + i * fb, width * 3, width, height, 3,
+                                                 M.ctypes.data_as(f64p), capi.BORDER_BLACK, None))
+        vs.sync()
+        d_world.free()
+        return clip
+    wnv = bgr_to_nv12(world)
+    d_y = capi.DevBuf.from_array(vs, wnv[:hw])
+    d_uv = capi.DevBuf.from_array(vs, wnv[hw:])
+    fb = width * height * 3 // 2
+    clip = capi.DevBuf(vs, fb * n_frames)
+    for i, p in enumerate(poses):
+        M = _pose_forward_matrix(p, width, height)
+        Mh = _pose_forward_matrix(p, width, height, 0.5)
+        vs.check(vs.lib.vs_op_warp_affine_ex(d_y.ptr, ww, ww, hw, clip.ptr + i * fb, width, width, height, 1,
+                                             M.ctypes.data_as(f64p), capi.BORDER_BLACK, None))
+        vs.check(vs.lib.vs_op_warp_affine_ex(d_uv.ptr, ww, ww // 2, hw // 2, clip.ptr + i * fb + width * height, width,
+                                             width // 2, height // 2, 2, Mh.ctypes.data_as(f64p), capi.BORDER_BLACK, None))
+    vs.sync()
+    d_y.free()
+    d_uv.free()
+    return clip
