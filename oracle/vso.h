@@ -172,6 +172,9 @@ int  vso_enhance(const uint8_t* src, int w, int h, size_t stride, const vs_enh_p
 
 /* threads used by row/point-parallel stages of vso_stab_push (default 1) */
 void vso_set_threads(int n);
+/* the host libm's cosf / sinf / atanf (fn 0, 1, 2: argument i = the float with bit pattern (uint32_t)i) or atan2f (fn 3: pair i
+ * of the generator in vso_libm.cpp) over [start, start + count), as the checksum vs_op_libm_checksum forms on the device */
+uint64_t vso_libm_checksum(int fn, uint64_t start, uint64_t count, int threads);
 void vso_params_default(vs_params_c* p);
 
 #ifdef __cplusplus

@@ -65,6 +65,8 @@ class Oracle:
         lib.vso_adaptive_radius.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int]
         lib.vso_motion_intent.argtypes = [f32p, C.c_int, C.c_int]
         lib.vso_set_threads.argtypes = [C.c_int]
+        lib.vso_libm_checksum.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int]
+        lib.vso_libm_checksum.restype = C.c_uint64
         from vsamd.capi import VsRollParams
         self.VsRollParams = VsRollParams
         lib.vso_roll_params_default.argtypes = [C.POINTER(VsRollParams)]

@@ -215,6 +215,7 @@ class VsLib:
         L.vs_dev_memset.argtypes = [vp, C.c_int, C.c_size_t]
         L.vs_dev_memcpy_d2d.argtypes = [vp, vp, C.c_size_t]
         L.vs_dev_copy_rate.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        L.vs_op_libm_checksum.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.vs_op_warp_affine.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                         C.c_int, f32p, C.c_int, vp]
         L.vs_op_warp_affine_nv12.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, f32p, C.c_int,
