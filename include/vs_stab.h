@@ -274,8 +274,11 @@ int vs_stab_set_warp_batch(vs_stab* s, int frames);
  * (at most 32 frames per warp launch: a batch of 64 is two launches back to back).
  * Results are bit-identical to frames = 1 and complete after vs_stab_sync(); every push must
  * be given its own d_out until then.  Must be chosen before the first frame (or after
- * vs_stab_clean).  BGR8, GRAY8 and NV12 frames; border/crop modes and adaptive smoothing
- * keep the per-frame path. */
+ * vs_stab_clean).  BGR8, GRAY8 and NV12 frames; border padding and crop-and-zoom (BGR8
+ * only, like everywhere) run batched too; the "fade" border, the virtual canvas and
+ * adaptive smoothing keep the per-frame path (each of their outputs depends on the one
+ * before it or on a host decision).  Instances of one device share its HIP streams and
+ * are to be driven from ONE host thread. */
 int vs_stab_set_batch(vs_stab* s, int frames);
 /* Zero-copy input for vs_stab_push_dev: the frame is read where the caller put it (decoder
  * surface pool, resident clip) instead of being copied into the instance's queue - the

@@ -996,3 +996,18 @@ def test_eight_instances_on_one_gpu_keep_their_streams_apart(gpu):
         got = d_out[g].download((k[g], 240, 320, 3), np.uint8)
         assert k[g] == n and np.array_equal(got, alone[g]), g
         stabs[g].close()
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+@pytest.mark.parametrize("extra", [dict(border_size=8, border_type=capi.BORDER_REFLECT), dict(border_size=8, crop_n_zoom=1)])
+def test_nv12_with_a_border_is_refused_in_both_execution_models(gpu, batch, extra):
+    """Border padding and crop-and-zoom exist for BGR8 frames only (the reference pads / crops cv::Mat frames of three
+    channels); an NV12 stream with border_size > 0 is turned down by the first push - per frame and in batch mode alike, so
+    the two execution models cannot diverge on it."""
+    nv = synth.bgr_to_nv12(synth.make_clip(synth.SEED_CONFIG1 + 40, 64, 48, 1)[0])
+    s = gpu.stabilizer(gpu.params(smoothing_radius=5, **extra))
+    s.set_batch(batch)
+    d_in, d_out = capi.DevBuf.from_array(gpu, nv), capi.DevBuf(gpu, 4 * nv.nbytes)
+    with pytest.raises(capi.VsError, match="BGR8"):
+        s.push_dev(d_in.ptr, 64, 48, 64, capi.FMT_NV12, d_out.ptr, 64 + 16)
+    s.close()

@@ -19,6 +19,7 @@ HostHelper::HostHelper() {
 }
 
 HostHelper::~HostHelper() {
+    (void)wait();       // a job still posted or running would overwrite the "leave" state with "done" and the join below would never return
     {
         std::lock_guard<std::mutex> lk(m_);
         state_.store(3, std::memory_order_release);

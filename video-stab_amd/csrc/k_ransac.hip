@@ -535,7 +535,7 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     }
     // phase 2b: smooth around the frame that push i releases -> its transform (dx, dy, da).  The release of push i must
     // see exactly the transforms appended up to push i (:380-389): it is given that length, and the later entries of the
-    // rings lie beyond everything it reads (ring of 256, at most 32 pushes ahead).  Box and Gaussian smoothing keep no
+    // rings lie beyond everything it reads (ring of 256, at most 64 pushes - one batch - ahead).  Box and Gaussian smoothing keep no
     // state of their own, so the releases of a batch run on different waves; the Kalman recursion (:1416-1458) advances a
     // filter state from release to release and stays on wave 0, in order.  The debug record keeps the last release.
     if (l_tp.method == VS_SMOOTH_KALMAN) {

@@ -26,6 +26,7 @@
 // launch for the frames of a batch - see run_batch().  DESIGN.md section 5 has the schedule.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstring>
 #include <cstdlib>
 #include <deque>
@@ -107,7 +108,7 @@ struct vs_stab {
     hipStream_t st_warp = nullptr;  // deferred (batched) warps, high priority
     bool shared_streams = false;    // the four streams belong to the per-device pool
     hipEvent_t ev_dev_warp = nullptr;   // the pool's: recorded behind the last batched warp of ANY instance on this device
-    bool* dev_warp_valid = nullptr;
+    std::atomic<bool>* dev_warp_valid = nullptr;
     std::string err;
     // geometry, fixed by the first frame
     bool allocated = false;
@@ -794,7 +795,7 @@ int launch_ready(vs_stab* s) {
         rc = ready_launches(s, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL);
     }
     if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
-    if (s->ev_dev_warp && hipEventRecord(s->ev_dev_warp, st) == hipSuccess) *s->dev_warp_valid = true;
+    if (s->ev_dev_warp && hipEventRecord(s->ev_dev_warp, st) == hipSuccess) s->dev_warp_valid->store(true, std::memory_order_release);
     for (int i = 0; i < R.n; i++) {
         const int slot = R.slots[i];
         if (slot < 0) continue;          // zero-copy: the frame is the caller's
@@ -964,7 +965,7 @@ int run_batch(vs_stab* s) {
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(k - 2) % 4], 0));
         if (s->bdet_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(k - 2) % 4], 0));
     }
-    if (s->ev_dev_warp && *s->dev_warp_valid && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr && std::getenv("VS_STAB_OWN_WARP_GUARD") == nullptr) {
+    if (s->ev_dev_warp && s->dev_warp_valid->load(std::memory_order_acquire) && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr && std::getenv("VS_STAB_OWN_WARP_GUARD") == nullptr) {
         // several instances share the streams: the last batched warp of ANY of them (the instances' launches interleave in
         // the shared queues, so that is the one in front of this batch's kernels)
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_dev_warp, 0));
@@ -1299,7 +1300,8 @@ namespace {
 struct StreamPool {
     hipStream_t st = nullptr, pre = nullptr, det = nullptr, warp = nullptr;
     hipEvent_t ev_warp = nullptr;       // behind the last batched warp of any instance
-    bool warp_valid = false;
+    std::atomic<bool> warp_valid{false};    // (instances sharing the pool are driven from ONE host thread - INTEGRATION.md; the flag
+                                            //  alone is safe to read from another)
     int refs = 0;
 };
 std::mutex g_pool_mutex;
@@ -1335,7 +1337,7 @@ hipError_t acquire_streams(vs_stab* s) {
         hipError_t e = make_streams(&p.st, &p.pre, &p.det, &p.warp);
         if (e != hipSuccess) return e;
         if (hipEventCreateWithFlags(&p.ev_warp, hipEventDisableTiming) != hipSuccess) p.ev_warp = nullptr;
-        p.warp_valid = false;
+        p.warp_valid.store(false);
     }
     p.refs++;
     s->st = p.st; s->st_pre = p.pre; s->st_det = p.det; s->st_warp = p.warp;
@@ -1357,7 +1359,7 @@ void release_streams(vs_stab* s) {
     if (--p.refs == 0) {
         (void)hipStreamDestroy(p.st); (void)hipStreamDestroy(p.pre); (void)hipStreamDestroy(p.det); (void)hipStreamDestroy(p.warp);
         if (p.ev_warp) (void)hipEventDestroy(p.ev_warp);
-        p = StreamPool();
+        p.st = p.pre = p.det = p.warp = nullptr; p.ev_warp = nullptr; p.warp_valid.store(false); p.refs = 0;
     }
 }
 }  // namespace
@@ -1477,10 +1479,12 @@ static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, si
     out_size(s, w, h, &ow, &oh);
     const size_t orow = (size_t)ow * s->cn;
     const int orows = fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh;
-    if (!out || out_stride < orow) return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
+    const bool have_prev = s->hold_valid;
+    // (as in the synchronous call: the buffer is only looked at when a frame will be delivered into it; a held frame is
+    // always a full-size one - pass-through frames only come out of vs_stab_flush's synchronous part)
+    if (have_prev && (!out || out_stride < orow)) return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
     for (auto& hld : s->d_hold)
         if (!hld) S_HIP(s, hipMalloc((void**)&hld, s->out_bytes));
-    const bool have_prev = s->hold_valid;
     // A copy to or from PAGEABLE memory (the frames of a cv::Mat) keeps its caller inside hipMemcpy for the whole transfer -
     // about 0.2 ms per direction at 1080p, through the runtime's bounce buffers -, so download and upload issued from this
     // thread run one after the other: 2 520 frames/s against 4 730 with page-locked frames.  With a pageable output buffer the
@@ -1493,9 +1497,11 @@ static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, si
         ~Join() { if (h) (void)h->wait(); }
         int wait() { HostHelper* t = h; h = nullptr; return t ? t->wait() : 0; }
     } join;
+    const int held_w = s->hold_w, held_h = s->hold_h;
     if (have_prev) {       // the held result: on its way while this call's frame comes in
         S_HIP(s, hipStreamWaitEvent(s->st_warp, s->ev_hold, 0));
         const uint8_t* d_src = s->d_hold[s->hold_cur ^ 1];
+
         bool helped = false;
         if (use_helper && !host_ptr_page_locked(out)) {
             try {           // (no exception leaves the C ABI: without a helper thread the download goes out from this one)
@@ -1534,6 +1540,7 @@ static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, si
         s->hold_w = s->last_out_w; s->hold_h = s->last_out_h;
     }
     *produced = have_prev ? 1 : 0;
+    if (have_prev) { s->last_out_w = held_w; s->last_out_h = held_h; }     // vs_stab_last_out_dims: the frame that was handed out
     return VS_OK;
 }
 

@@ -31,7 +31,8 @@ class Comm:
         self.dist = None
         self.torch = None
         self.device = "cpu"
-        if self.world > 1:
+        # VS_DIST_FORCE=1: a process group at world size 1 as well (exercises the RCCL path on a one-GPU box: tests/test_dist_rccl.py)
+        if self.world > 1 or (os.environ.get("VS_DIST_FORCE") == "1" and "RANK" in os.environ):
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
