@@ -113,47 +113,74 @@ def cpu_baseline(width, height, frames, order_fn):
 
 
 class StreamSet:
-    """S stabilizer instances in batch mode on one GPU, each with a resident clip (one DevBuf of `clip_frames` packed frames,
-    played in a cycle) and a ring of output frames."""
+    """S streams in batch mode on one GPU, each with a resident clip (one DevBuf of `clip_frames` packed frames, played in a
+    cycle) and a ring of output frames.  S > 1: one vs_batch group (one launch per stage over the frames of all streams; a step
+    is `batch // S` frames per stream, so a step carries as many frames as the one-stream step) unless group=False (S
+    independent vs_stab instances, each with steps of `batch` frames: round 2's --streams)."""
 
-    def __init__(self, vs, device, params, clips, clip_frames, w, h, fmt, batch, warp_batch, zero_copy):
+    def __init__(self, vs, device, params, clips, clip_frames, w, h, fmt, batch, warp_batch, zero_copy, group=True):
         self.vs, self.w, self.h, self.fmt = vs, w, h, fmt
         self.fb = w * h * 3 if fmt == capi.FMT_BGR8 else w * h * 3 // 2
         self.stride = w * 3 if fmt == capi.FMT_BGR8 else w
         self.clip_frames = clip_frames
         self.d_in = clips
-        self.BT = max(1, min(64, batch))
-        self.WB = max(1, min(32, warp_batch if self.BT == 1 else self.BT))
-        self.WB_frames = self.BT if self.BT > 1 else self.WB       # frames between one pair of warp-stage events
-        self.NOUT = max(2 * self.WB, 3 * self.BT)    # a result stays untouched until its batch and the next one have been issued
+        S = len(clips)
+        self.grouped = bool(group) and S > 1 and batch > 1
+        self.BT = max(1, min(64, batch)) if not self.grouped else max(1, min(64, batch) // S)     # pushes per stream and step
+        self.WB = max(1, min(32, warp_batch if batch == 1 else self.BT * (S if self.grouped else 1)))
+        frames_per_step = self.BT * (S if self.grouped else 1)                # frames between one pair of warp-stage events
+        self.WB_frames = frames_per_step if batch > 1 else self.WB
+        self.NOUT = max(2 * self.WB, 3 * max(self.BT, 64 // S if self.grouped else self.BT))    # a result stays untouched until its step and the next have been issued
         self.d_out = [[capi.DevBuf(vs, self.fb) for _ in range(self.NOUT)] for _ in clips]
-        self.stabs = [vs.stabilizer(params, device=device) for _ in clips]
-        for s in self.stabs:
-            s.set_batch(self.BT)
-            s.set_zero_copy(bool(zero_copy))
-            s.set_warp_batch(self.WB)
+        if self.grouped:
+            self.group = vs.batch(params, S, self.BT, device=device)
+            self.group.set_zero_copy(bool(zero_copy))
+            self.stabs = [self.group.stream(j) for j in range(S)]
+            self.timed = [self.stabs[0]]                                      # a group books its stage times on its first member
+            # the pointer arrays of every clip position and output slot, marshalled once
+            self.fr_arrays = [self.group.pointer_array([b.ptr + fi * self.fb for b in self.d_in]) for fi in range(clip_frames)]
+            self.ou_arrays = [self.group.pointer_array([o[oi].ptr for o in self.d_out]) for oi in range(self.NOUT)]
+        else:
+            self.group = None
+            self.stabs = [vs.stabilizer(params, device=device) for _ in clips]
+            for s in self.stabs:
+                s.set_batch(self.BT)
+                s.set_zero_copy(bool(zero_copy))
+                s.set_warp_batch(self.WB)
+            self.timed = self.stabs
         self.i = 0
 
     def push(self, n):
         """n consecutive pushes per stream."""
         for _ in range(n):
             fi = self.i % self.clip_frames
-            for j, s in enumerate(self.stabs):
-                s.push_dev(self.d_in[j].ptr + fi * self.fb, self.w, self.h, self.stride, self.fmt,
-                           self.d_out[j][self.i % self.NOUT].ptr, self.stride)
+            oi = self.i % self.NOUT
+            if self.group is not None:
+                self.group.push_dev_arrays(self.fr_arrays[fi], self.w, self.h, self.stride, self.fmt, self.ou_arrays[oi], self.stride)
+            else:
+                for j, s in enumerate(self.stabs):
+                    s.push_dev(self.d_in[j].ptr + fi * self.fb, self.w, self.h, self.stride, self.fmt, self.d_out[j][oi].ptr, self.stride)
             self.i += 1
 
     def sync(self):
-        for s in self.stabs:
-            s.sync()
+        if self.group is not None:
+            self.group.sync()
+        else:
+            for s in self.stabs:
+                s.sync()
 
     def frames_out(self):
         return sum(s.counters().frames_out for s in self.stabs)
 
+    def set_profiling(self, mode):
+        for s in self.timed:
+            s.set_profiling(mode)
+            s.stage_times()          # drop anything recorded so far
+
     def stage_totals(self):
         n_st = capi.STAGE_COUNT
         ms, n = [0.0] * n_st, [0] * n_st
-        for s in self.stabs:
+        for s in self.timed:
             a, b = s.stage_times()
             for k in range(n_st):
                 ms[k] += a[k]
@@ -166,8 +193,11 @@ class StreamSet:
         return [self.d_in[j].download(shape, np.uint8, i * self.fb) for i in range(min(count, self.clip_frames))]
 
     def close(self, free_clips=True):
-        for s in self.stabs:
-            s.close()
+        if self.group is not None:
+            self.group.close()
+        else:
+            for s in self.stabs:
+                s.close()
         if free_clips:
             for b in self.d_in:
                 b.free()
@@ -214,14 +244,11 @@ def tables_pass(ss, roof, steps):
     event pair; its time is measured here, in a region of its own (profiling mode 3: one more event pair per batch on the
     critical stream, so not inside the headline regions) and folded into `stage_frac` = algorithmic bytes over
     warp + tables time."""
-    for s in ss.stabs:
-        s.set_profiling(3)
-        s.stage_times()
+    ss.set_profiling(3)
     ss.push(steps * ss.BT)
     ss.sync()
     ms, n = ss.stage_totals()
-    for s in ss.stabs:
-        s.set_profiling(1)
+    ss.set_profiling(1)
     if n[capi.STAGE_WARP_TABLES] == 0 or n[capi.STAGE_WARP] == 0:
         roof["tables_note"] = "no table launches (per-frame pipeline)"
         return
@@ -339,9 +366,7 @@ def run_stream_workload(comm, ss, steps, warmup, regions, preroll_batches, profi
     ss.sync()
     comm.device_sync()
     ss.push(warmup * BT)
-    for s in ss.stabs:
-        s.set_profiling(2 if profile_stages else 1)
-        s.stage_times()          # drop anything recorded so far
+    ss.set_profiling(2 if profile_stages else 1)
     frames_before = ss.frames_out()
     elapsed = timed_regions(ss, comm, steps, regions)
     frames_out_timed = ss.frames_out() - frames_before
@@ -413,6 +438,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps in front of the first region")
     ap.add_argument("--regions", type=int, default=9, help="the timed region of --steps steps is repeated this often; value = the median")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU (batch mode)")
+    ap.add_argument("--group", type=int, default=1,
+                    help="--streams > 1: 1 = the streams of a GPU as ONE vs_batch group (one launch per stage over the frames of all "
+                         "streams, steps of batch // streams frames per stream); 0 = independent vs_stab instances")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--clip-frames", type=int, default=128,
@@ -493,10 +521,13 @@ def main():
                   "what": "scatter of %d frames per stream from rank 0 to %d ranks (torch.distributed.scatter, %s)" % (
                       NF, world - 1, "RCCL" if comm.device == "cuda" else "gloo, host memory")}
     else:
-        clips = [synth.make_clip_dev(vs, synth.SEED_CONFIG2 + g, W, H, NF) for g in my_streams]
+        # (VS_BENCH_SAME_CLIP=1: every stream plays the clip of stream 0 - scheduling comparisons between stream counts without
+        # the differences in content: the candidate count of the corner detector varies by a factor of two between seeds)
+        same = os.environ.get("VS_BENCH_SAME_CLIP") == "1"
+        clips = [synth.make_clip_dev(vs, synth.SEED_CONFIG2 + (0 if same else g), W, H, NF) for g in my_streams]
 
     params = make_params(vs, args.config)
-    ss = StreamSet(vs, local_rank, params, clips, NF, W, H, capi.FMT_BGR8, args.batch, args.warp_batch, args.zero_copy)
+    ss = StreamSet(vs, local_rank, params, clips, NF, W, H, capi.FMT_BGR8, args.batch, args.warp_batch, args.zero_copy, group=args.group)
     BT = ss.BT
     elapsed, roof, stage_ms, stage_n = run_stream_workload(
         comm, ss, args.steps, args.warmup, args.regions, int(os.environ.get("VS_BENCH_PREROLL_BATCHES", "200")),
@@ -533,6 +564,7 @@ def main():
                        ("custom: %d stream(s)/GPU %dx%d BGR8, stabilizer parameters from %s; frames resident in HBM"
                         % (S, W, H, os.path.basename(args.config))),
                        "streams_per_gpu": S, "frames_per_step": BT, "step": "one batch of %d stabilize() calls per stream" % BT,
+                       "streams_grouped": ss.grouped,
                        "clip": "%d distinct frames per stream rendered on the device, played in a cycle" % NF,
                        "warp_batch": ss.WB, "zero_copy": bool(args.zero_copy),
                        "timed_frames_per_rank": [int(r[1]) for r in per_rank], "build": vs.lib.vs_build_tag().decode()},

@@ -123,6 +123,19 @@ namespace vs {
             float hfDeadZoneThreshold = 2.0f;
             int hfFreezeDuration = 10;
             float hfMotionAccumulatorDecay = 0.9f;
+
+            // ---- additions of this implementation (behind the reference's fields, with defaults: code written against the
+            // reference's struct compiles unchanged) -------------------------------------------------------------------------
+            /// stabilize() returns the frame the PREVIOUS call made due: this call's upload, the device work and the download
+            /// of that frame overlap (about twice the frame rate of the synchronous call); flush() hands out the held frame
+            /// first.  One more call of latency, the same frames.  (The environment variable VS_STAB_HOST_PIPELINE=1 does the
+            /// same for an application that cannot be rebuilt.)
+            bool hostPipeline = false;
+            /// Page-lock the host memory frames travel through: the returned frames come from a small ring of page-locked
+            /// cv::Mat buffers that are reused once the caller has let go of them (no allocation, no first-touch page faults,
+            /// DMA straight into them), and an input buffer that keeps coming back (the Mat a capture loop reads into) is
+            /// registered with the driver after its second appearance.  false: plain cv::Mat allocations, pageable transfers.
+            bool pinHostFrames = true;
         };
 
         explicit Stabilizer(const Parameters &params);
@@ -151,10 +164,19 @@ namespace vs {
         void logMessage(const std::string &msg, bool isError = false) const;
         void create();
 
+        cv::Mat outputFrame(int rows, int cols);
+        void noteInput(const cv::Mat &frame);
+        void releaseHostPins();
+
         Parameters params_;
         vs_stab *impl_ = nullptr;
         int device_ = 0;
         int frameWidth_ = 0, frameHeight_ = 0;   // geometry of the stream (set by the first frame)
+        // page-locked host memory (Parameters::pinHostFrames): ring of output frames, registered input buffers
+        struct OutSlot { cv::Mat m; bool pinned = false; };
+        struct InPin { const unsigned char *p = nullptr; size_t bytes = 0; int seen = 0; int idle = 0; bool pinned = false; };
+        OutSlot outRing_[4];
+        InPin inPins_[4];
     };
 
 }

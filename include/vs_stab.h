@@ -259,6 +259,10 @@ int vs_stab_set_host_pipeline(vs_stab* s, int enable);
  * rate). */
 int  vs_host_alloc(void** p, size_t bytes);
 void vs_host_free(void* p);
+/* The same for memory the caller already owns (a cv::Mat's buffer): page-locks it in place / lets it go again.  The memory
+ * must be unregistered before it is freed. */
+int  vs_host_register(void* p, size_t bytes);
+int  vs_host_unregister(void* p);
 /* Deferred output for vs_stab_push_dev / vs_stab_flush_dev (batch / file-to-file use): the
  * warps of up to `frames` (1..32) consecutive results are issued as ONE kernel launch, each
  * result into the d_out its push named.  Results are complete after vs_stab_sync(); with
@@ -299,6 +303,35 @@ int vs_stab_set_zero_copy(vs_stab* s, int enable);
  * With zero-copy input the stabilizer then reads decoder surfaces and writes encoder surfaces
  * in place: no repacking blit on either side.  The frame queue must be empty. */
 int vs_stab_set_nv12_layout(vs_stab* s, size_t in_uv_offset, size_t out_uv_offset);
+
+/* ---- several streams of one device scheduled together (BASELINE configs[4]: 64 streams = 8 per GPU) ----------------------
+ * The reference runs one Stabilizer per stream, each with its own cv::cuda::Stream objects (src/Stabilizer.cpp:102-104); here a
+ * GROUP runs one schedule for all its streams: every step, the frames all members have queued go through ONE launch per stage
+ * (one argument block per frame, whichever stream it belongs to), the ordered tails through one launch with a workgroup per
+ * stream, the warps through launches of 32 frames.  Results are bit-identical to n_streams independent vs_stab instances.
+ *   vs_batch_create      n_streams members with the same parameters, in batch mode with `frames_per_step` frames per stream and
+ *                        step (1..64; n_streams x frames_per_step frames are analysed together: 8 x 8 fills the device like one
+ *                        stream's batch of 64).  Adaptive smoothing, border / crop-and-zoom and the virtual canvas are per-stream
+ *                        modes of vs_stab_* and are refused here.
+ *   vs_batch_push_dev    one frame per stream (d_frames[i] == NULL: none for stream i this time); device pointers, one geometry,
+ *                        pitch and format for all; produced[i] = 1 when the push made an output of stream i due - it is complete
+ *                        after vs_batch_sync, in d_outs[i].  A step runs when a member has frames_per_step frames queued.
+ *   vs_batch_flush_dev   drains the group, then the next queued frame of every stream (Stabilizer::flush).
+ *   vs_batch_stream      the member instance i: for the per-stream getters (vs_stab_get_counters, vs_stab_get_debug, ...); its
+ *                        frames are pushed through the group only.
+ * One host thread drives a group (and all instances of a device). */
+typedef struct vs_batch vs_batch;
+int vs_batch_create(int device, int n_streams, const vs_params_c* params, int frames_per_step, vs_batch** out);
+void vs_batch_destroy(vs_batch* b);
+int vs_batch_streams(const vs_batch* b);
+vs_stab* vs_batch_stream(vs_batch* b, int i);
+int vs_batch_set_zero_copy(vs_batch* b, int enable);
+int vs_batch_set_nv12_layout(vs_batch* b, size_t in_uv_offset, size_t out_uv_offset);
+int vs_batch_push_dev(vs_batch* b, const void* const* d_frames, int w, int h, size_t stride, int fmt, void* const* d_outs,
+                      size_t out_stride, int* produced);
+int vs_batch_flush_dev(vs_batch* b, void* const* d_outs, size_t out_stride, int* produced);
+int vs_batch_sync(vs_batch* b);
+const char* vs_batch_last_error(const vs_batch* b);
 
 /* Per-stage device timing with HIP events recorded on the instance stream
  * (SURVEY.md section 5 "Tracing").  mode 0 = off, 1 = warp stage only,

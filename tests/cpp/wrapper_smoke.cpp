@@ -3,19 +3,30 @@
 // plus the reassignment idiom of examples/vs.cpp:403.  Frames are a synthetic
 // moving pattern; prints one "F <rows> <cols> <hash>" line per delivered frame (stabilize() and flush() results in
 // order), then "<inputs> <outputs> <flushed> <checksum>".  argv[2] selects the Parameters: reflect (default) | fade |
-// canvas | canvas12 (scale 1.2, fills from the temporal buffer).
+// canvas | canvas12 (scale 1.2, fills from the temporal buffer) | keep (reflect; every result is kept alive and hashed again at
+// the end: a recycled output buffer would show) | unpinned (reflect with Parameters::pinHostFrames = false) | piped (reflect with
+// Parameters::hostPipeline).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include "video/Stabilizer.h"
 
-static void report(const cv::Mat &m) {
+static unsigned long long hash_of(const cv::Mat &m) {
     unsigned long long h = 1469598103934665603ull;               // FNV-1a over every byte
     for (int y = 0; y < m.rows; y++) {
         const unsigned char *p = m.ptr(y);
         for (int x = 0; x < m.cols * 3; x++) { h ^= p[x]; h *= 1099511628211ull; }
     }
+    return h;
+}
+static std::vector<cv::Mat> g_kept;
+static std::vector<unsigned long long> g_hashes;
+static bool g_keep = false;
+static void report(const cv::Mat &m) {
+    const unsigned long long h = hash_of(m);
     std::printf("F %d %d %llu\n", m.rows, m.cols, h);
+    if (g_keep) { g_kept.push_back(m); g_hashes.push_back(h); }
 }
 
 static cv::Mat make_frame(int w, int h, int k) {
@@ -46,6 +57,12 @@ int main(int argc, char **argv) {
     } else if (!std::strcmp(mode, "canvas12")) {
         stabParams.enableVirtualCanvas = true; stabParams.adaptiveCanvasSize = false; stabParams.canvasScaleFactor = 1.2f;
         stabParams.temporalBufferSize = 5;
+    } else if (!std::strcmp(mode, "keep")) {
+        g_keep = true;
+    } else if (!std::strcmp(mode, "unpinned")) {
+        stabParams.pinHostFrames = false;
+    } else if (!std::strcmp(mode, "piped")) {
+        stabParams.hostPipeline = true;
     }
     vs::Stabilizer stab(stabParams);
     stab = vs::Stabilizer(stabParams);               // vs.cpp:403
@@ -66,6 +83,8 @@ int main(int argc, char **argv) {
         flushed++;
         report(f);
     }
+    for (size_t i = 0; i < g_kept.size(); i++)
+        if (hash_of(g_kept[i]) != g_hashes[i]) { std::printf("kept frame %zu changed after it was handed out\n", i); return 2; }
     std::printf("%d %d %d %llu\n", n, outputs, flushed, sum);
     return (outputs + flushed == n) ? 0 : 1;
 }

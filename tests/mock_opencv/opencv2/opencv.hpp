@@ -19,18 +19,47 @@
 namespace cv {
 struct Size { int width = 0, height = 0; Size() = default; Size(int w, int h) : width(w), height(h) {} };
 struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() = default; Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
+// (the data block and its reference count, with OpenCV's names: cv::Mat::u, cv::UMatData::refcount)
+struct UMatData { int refcount = 0; unsigned char *origdata = nullptr; };
 class Mat {
 public:
     int rows = 0, cols = 0;
     unsigned char *data = nullptr;
     size_t step = 0;
+    UMatData *u = nullptr;
     Mat() = default;
     Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(const Mat &m) : rows(m.rows), cols(m.cols), data(m.data), step(m.step), u(m.u), type_(m.type_) { if (u) __atomic_add_fetch(&u->refcount, 1, __ATOMIC_ACQ_REL); }
+    Mat(Mat &&m) noexcept : rows(m.rows), cols(m.cols), data(m.data), step(m.step), u(m.u), type_(m.type_) { m.u = nullptr; m.data = nullptr; m.rows = m.cols = 0; }
+    Mat &operator=(const Mat &m) {
+        if (this != &m) {
+            if (m.u) __atomic_add_fetch(&m.u->refcount, 1, __ATOMIC_ACQ_REL);
+            release();
+            rows = m.rows; cols = m.cols; data = m.data; step = m.step; u = m.u; type_ = m.type_;
+        }
+        return *this;
+    }
+    Mat &operator=(Mat &&m) noexcept {
+        if (this != &m) {
+            release();
+            rows = m.rows; cols = m.cols; data = m.data; step = m.step; u = m.u; type_ = m.type_;
+            m.u = nullptr; m.data = nullptr; m.rows = m.cols = 0;
+        }
+        return *this;
+    }
+    ~Mat() { release(); }
+    void release() {
+        if (u && __atomic_sub_fetch(&u->refcount, 1, __ATOMIC_ACQ_REL) == 0) { delete[] u->origdata; delete u; }
+        u = nullptr; data = nullptr; rows = cols = 0;
+    }
     void create(int r, int c, int type) {
+        release();
         type_ = type; rows = r; cols = c;
         step = (size_t)c * channels();
-        buf_ = std::make_shared<std::vector<unsigned char>>(step * (size_t)r);
-        data = buf_->data();
+        u = new UMatData;
+        u->refcount = 1;
+        u->origdata = new unsigned char[step * (size_t)r + 64];        // (not zeroed: like cv::Mat, the pages are untouched until written)
+        data = u->origdata;
     }
     int type() const { return type_; }
     int channels() const { return (type_ >> 3) + 1; }
@@ -53,7 +82,6 @@ public:
     const unsigned char *ptr(int y) const { return data + (size_t)y * step; }
 private:
     int type_ = CV_8UC3;
-    std::shared_ptr<std::vector<unsigned char>> buf_;
 };
 
 // ---- capture side (tests/test_host_shims.py): a synthetic cv::VideoCapture and the little of imgproc vs::CamCap calls.

@@ -65,6 +65,25 @@ def test_wrapper_modes_and_the_pipelined_host_call(gpu, mode, size):
     assert piped == frames and (n2, outs2, flushed2) == (40, 20, 20)
 
 
+@pytest.mark.gpu
+def test_wrapper_output_ring_and_the_parameters_of_this_implementation(gpu):
+    """Parameters::pinHostFrames (default on: results come from a ring of page-locked Mats that is reused once the caller has let
+    go of them) and Parameters::hostPipeline: the same frames as with plain allocations; results the caller keeps alive are never
+    written again (every one of forty is hashed a second time at the end); the pipelined call by parameter equals the one by
+    environment variable."""
+    build()
+    frames, counts = _run("reflect")
+    assert _run("unpinned") == (frames, counts)
+    assert _run("keep") == (frames, counts)
+    piped, (n, outs, flushed) = _run("piped")
+    assert piped == frames and (n, outs, flushed) == (40, 20, 20)
+
+
+def test_timing_program_of_the_class_builds(vs):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "_build", "wrapper_time"))
+
+
 ROLL_EXE = os.path.join(ROOT, "tests", "cpp", "_build", "roll_smoke")
 
 

@@ -1011,3 +1011,79 @@ def test_nv12_with_a_border_is_refused_in_both_execution_models(gpu, batch, extr
     with pytest.raises(capi.VsError, match="BGR8"):
         s.push_dev(d_in.ptr, 64, 48, 64, capi.FMT_NV12, d_out.ptr, 64 + 16)
     s.close()
+
+
+@pytest.mark.parametrize("fmt", [capi.FMT_BGR8, capi.FMT_NV12])
+@pytest.mark.parametrize("n_streams,step,extra", [(8, 8, dict()), (3, 16, dict(smoothing_method=capi.SMOOTH_KALMAN)),
+                                                   (5, 4, dict(smoothing_method=capi.SMOOTH_GAUSSIAN, drone_high_freq_mode=1)), (2, 64, dict())])
+def test_streams_of_a_vs_batch_equal_their_solo_runs(gpu, fmt, n_streams, step, extra):
+    """BASELINE configs[4], one GPU's share, through vs_batch_*: the frames of all streams in one launch per stage (one
+    workgroup per stream in the ordered tail, one warp launch per 32 due frames).  Every stream's frames, flush included, equal
+    those of a vs_stab instance run on its own - which the other tests hold against the oracle.  70 pushes per stream: steps of
+    8 x 8, 3 x 16, 5 x 4 and 2 x 64 frames, the last step partial; one stream sits out every seventh call."""
+    n = 70
+    clips = [synth.make_clip(synth.SEED_CONFIG1 + 60 + g, 320, 240, 16) for g in range(n_streams)]
+    if fmt == capi.FMT_NV12:
+        clips = [[synth.bgr_to_nv12(f) for f in c] for c in clips]
+    order = [i % 16 if (i // 16) % 2 == 0 else 15 - i % 16 for i in range(n)]
+    params = dict(smoothing_radius=7, **extra)
+    fb = clips[0][0].nbytes
+    stride = 320 * 3 if fmt == capi.FMT_BGR8 else 320
+
+    def solo(g):
+        s = gpu.stabilizer(gpu.params(**params))
+        s.set_batch(16)
+        s.set_zero_copy(True)
+        d_in, d_out = capi.DevBuf(gpu, fb * 16), capi.DevBuf(gpu, fb * (n + 2))
+        for i, f in enumerate(clips[g]):
+            d_in.upload(f, i * fb)
+        k = 0
+        for i in order:
+            k += s.push_dev(d_in.ptr + i * fb, 320, 240, stride, fmt, d_out.ptr + k * fb, stride)
+        while s.flush_dev(d_out.ptr + k * fb, stride):
+            k += 1
+        s.sync()
+        out = d_out.download((k,) + clips[g][0].shape, np.uint8)
+        s.close()
+        return out
+    alone = [solo(g) for g in range(n_streams)]
+    b = gpu.batch(gpu.params(**params), n_streams, step)
+    b.set_zero_copy(True)
+    d_in, d_out, k, pos = [], [], [0] * n_streams, [0] * n_streams
+    for g in range(n_streams):
+        buf = capi.DevBuf(gpu, fb * 16)
+        for i, f in enumerate(clips[g]):
+            buf.upload(f, i * fb)
+        d_in.append(buf)
+        d_out.append(capi.DevBuf(gpu, fb * (n + 2)))
+    call = 0
+    while min(pos) < n:
+        # stream (call mod n_streams) sits out every seventh call: the members' queues run out of step
+        skip = call % n_streams if call % 7 == 6 else -1
+        fr = [d_in[g].ptr + order[pos[g]] * fb if (g != skip and pos[g] < n) else None for g in range(n_streams)]
+        ou = [d_out[g].ptr + k[g] * fb for g in range(n_streams)]
+        prod = b.push_dev(fr, 320, 240, stride, fmt, ou, stride)
+        for g in range(n_streams):
+            if fr[g] is not None:
+                pos[g] += 1
+                k[g] += prod[g]
+        call += 1
+    while True:
+        prod = b.flush_dev([d_out[g].ptr + k[g] * fb for g in range(n_streams)], stride)
+        for g in range(n_streams):
+            k[g] += prod[g]
+        if not any(prod):
+            break
+    b.sync()
+    for g in range(n_streams):
+        got = d_out[g].download((k[g],) + clips[g][0].shape, np.uint8)
+        assert k[g] == n and np.array_equal(got, alone[g]), g
+    # the per-stream getters work on the members
+    assert b.stream(0).counters().frames_out == n and b.stream(n_streams - 1).debug().out_index == n - 1
+    b.close()
+
+
+def test_vs_batch_refuses_per_stream_modes(gpu):
+    for kw in (dict(adaptive_smoothing=1), dict(border_size=8), dict(enable_virtual_canvas=1)):
+        with pytest.raises(capi.VsError):
+            gpu.batch(gpu.params(**kw), 2, 8)

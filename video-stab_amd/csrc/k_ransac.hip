@@ -183,6 +183,7 @@ struct RansacArgs {
     TrajParams tp;
     vs_debug_frame* dbg;
     int have_prev_gray;
+    int last_of_stream;       // group launches (several streams in one table): this is its stream's last frame of the batch
 };
 
 __device__ __forceinline__ int device_count(const RansacArgs& a) {
@@ -420,7 +421,7 @@ bool score16_setting() {
 // fence per workgroup.  16 000 L2 write-backs per launch: the scoring launch went from 20 to 320 us and dragged the
 // kernels beside it along.)
 __global__ __launch_bounds__(64) void ransac_select_batch_kernel(const RansacArgs* __restrict__ table, int last_item) {
-    ransac_select<true>(table[blockIdx.x], (int)blockIdx.x == last_item);
+    ransac_select<true>(table[blockIdx.x], (int)blockIdx.x == last_item || table[blockIdx.x].last_of_stream != 0);
 }
 
 // Ordered tail of a batch, ONE launch: for every frame in push order, hypothesis selection + trajectory append,
@@ -429,8 +430,12 @@ __global__ __launch_bounds__(64) void ransac_select_batch_kernel(const RansacArg
 struct TailItem {
     int out_due, out_idx;
     double* Minv_out;
-    int ncnt, pad;               // written by the tail: transforms appended after this push (read by the release kernel)
+    int ncnt, seg;               // ncnt: written by the tail - transforms appended after this push (read by the release kernel);
+                                 // seg: group launches - index of the frame's stream segment
 };
+// A launch over the frames of several streams (vs_batch): the items of stream s are table[first .. first + n), workgroup s of the
+// tail takes them, and the stream's frame matrix goes to its own M_out.
+struct TailSeg { int first, n; float* M_out; };
 
 // RELEASE_APART: the kernel ends with the appends (phases 1 and 2a) and leaves the releases - smoothing around the frame each
 // due push lets go, its matrix and inverse map - to ransac_release_batch_kernel, one workgroup per push: on the one CU of
@@ -438,7 +443,12 @@ struct TailItem {
 // smoother, whose filter state advances from release to release.)
 template <bool RELEASE_APART>
 __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArgs* __restrict__ table,
-                                                                 TailItem* __restrict__ tail, int n, float* M_out) {
+                                                                 TailItem* __restrict__ tail, int n, float* M_out, const TailSeg* __restrict__ segs) {
+    if (segs) {                      // one workgroup per stream of a group launch
+        const TailSeg sg = segs[blockIdx.x];
+        table += sg.first; tail += sg.first; n = sg.n; M_out = sg.M_out;
+        if (n <= 0) return;
+    }
     // The ordered part below is a chain of small dependent steps executed by one lane; run from global
     // memory every step would pay an HBM round trip (and every barrier would wait for the stores of the
     // step before).  The stream's trajectory state, the parameters, the per-frame inputs and all results
@@ -577,12 +587,16 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
 // trajectory as long as it was after its push (TailItem::ncnt); the last due one leaves its record and matrix behind,
 // like the last release of the one-kernel tail.
 __global__ __launch_bounds__(64) void ransac_release_batch_kernel(const RansacArgs* __restrict__ table, const TailItem* __restrict__ tail,
-                                                                  int n, float* M_out) {
+                                                                  int n, float* M_out, const TailSeg* __restrict__ segs) {
     __shared__ vs_debug_frame l_dbg_unused;
     __shared__ float l_M[12];
-    const int f = blockIdx.x;
+    int f = blockIdx.x;
     const TailItem t = tail[f];
     if (!t.out_due) return;
+    if (segs) {                      // the frame's own stream: its items, its matrix
+        const TailSeg sg = segs[t.seg];
+        table += sg.first; tail += sg.first; f -= sg.first; n = sg.n; M_out = sg.M_out;
+    }
     int last_due = -1;
     for (int i = 0; i < n; i++) if (tail[i].out_due) last_due = i;
     const bool last = f == last_due;
@@ -652,7 +666,37 @@ size_t tail_item_bytes() { return sizeof(TailItem); }
 
 void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out) {
     TailItem& t = *static_cast<TailItem*>(host_item);
-    t.out_due = out_due; t.out_idx = out_idx; t.Minv_out = d_Minv_out; t.ncnt = 0; t.pad = 0;
+    t.out_due = out_due; t.out_idx = out_idx; t.Minv_out = d_Minv_out; t.ncnt = 0; t.seg = 0;
+}
+
+// ---- group launches (vs_batch: the frames of several streams in one table) ----
+size_t tail_seg_bytes() { return sizeof(TailSeg); }
+void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out) {
+    TailSeg& g = *static_cast<TailSeg*>(host_seg);
+    g.first = first; g.n = n; g.M_out = d_M_out;
+}
+void tail_item_set_seg(void* host_item, int seg) { static_cast<TailItem*>(host_item)->seg = seg; }
+void ransac_item_set_last(void* host_item, int last) { static_cast<RansacArgs*>(host_item)->last_of_stream = last; }
+
+// The ordered tails of `nsegs` streams in one launch (workgroup = stream), then the releases of all their pushes.
+int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void* d_segs, int nsegs, int max_n, int items, int smoothing_method,
+                             hipStream_t st) {
+    if (!d_table || !d_tail || !d_segs || nsegs < 1 || max_n < 1 || max_n > 64 || items < 1) {
+        set_last_error("ransac_tail_group: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    const int threads = 64 * (max_n > 16 ? 16 : max_n);
+    const RansacArgs* tb = static_cast<const RansacArgs*>(d_table);
+    TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
+    const TailSeg* sg = static_cast<const TailSeg*>(d_segs);
+    if (smoothing_method != VS_SMOOTH_KALMAN) {
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(nsegs), dim3(threads), 0, st, tb, tl, 0, (float*)nullptr, sg);
+        hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, 0, (float*)nullptr, sg);
+    } else {
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(nsegs), dim3(threads), 0, st, tb, tl, 0, (float*)nullptr, sg);
+    }
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
 }
 
 int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, int smoothing_method, hipStream_t st) {
@@ -664,10 +708,10 @@ int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items,
     const RansacArgs* tb = static_cast<const RansacArgs*>(d_table);
     TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
     if (apart && smoothing_method != VS_SMOOTH_KALMAN) {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out);
-        hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, items, d_M_out);
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr);
+        hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr);
     } else {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out);
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr);
     }
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;

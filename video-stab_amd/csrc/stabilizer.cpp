@@ -65,6 +65,12 @@ int launch_ransac_select_item(const void* host_item, hipStream_t st);
 size_t tail_item_bytes();
 void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out);
 int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, int smoothing_method, hipStream_t st);
+size_t tail_seg_bytes();
+void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out);
+void tail_item_set_seg(void* host_item, int seg);
+void ransac_item_set_last(void* host_item, int last);
+int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void* d_segs, int nsegs, int max_n, int items, int smoothing_method,
+                             hipStream_t st);
 size_t gftt_item_bytes();
 int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
                    double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
@@ -99,9 +105,13 @@ struct Pyramid {
 
 using namespace vsd;
 
+struct vs_batch;
+int group_drain(vs_batch* g);
+
 struct vs_stab {
     vs_params_c p;
     int device = 0;
+    vs_batch* group = nullptr;      // member of a vs_batch: its batches are run by the group (one launch per stage over all streams)
     hipStream_t st = nullptr;       // main
     hipStream_t st_pre = nullptr;
     hipStream_t st_det = nullptr;
@@ -324,6 +334,7 @@ int launch_ready(vs_stab* s);
 
 // Batch mode: everything queued so far is analysed and its warps are issued (nothing stays deferred).
 int drain_batch(vs_stab* s) {
+    if (s->group) { const int rc = group_drain(s->group); if (rc != VS_OK) s->err = get_last_error(); return rc; }
     S_TRY(s, run_batch(s));
     S_TRY(s, launch_ready(s));
     return VS_OK;
@@ -943,7 +954,7 @@ int batch_enqueue(vs_stab* s, const uint8_t* frame, int slot, int f, uint8_t* d_
         *produced = 1;
     }
     s->bq.push_back(b);
-    if ((int)s->bq.size() >= s->batch) S_TRY(s, run_batch(s));
+    if (!s->group && (int)s->bq.size() >= s->batch) S_TRY(s, run_batch(s));     // (a group runs its members' batches together)
     return VS_OK;
 }
 
@@ -1774,6 +1785,458 @@ int vs_stab_get_stage_times(vs_stab* s, double* total_ms, int64_t* launches) {
         s->ev_pool.push_back(pe.b);
     }
     s->pending.clear();
+    return VS_OK;
+}
+
+}  // extern "C"
+
+// ---- vs_batch: several streams of one device scheduled together (BASELINE configs[4]: 64 streams = 8 per GPU) ------------
+// N instances that each run their own batches take turns on the device's streams: every stage is launched once per instance,
+// and the chains of one instance queue behind the waits of another (8 instances: 101.7 k frames/s in total against 109.1 k for
+// one, round 2).  A group runs ONE schedule for its members: the frames that all of them have queued since the last step go
+// into one argument table per stage - the tables hold one block per frame anyway, and a block names its frame's buffers, so
+// a launch does not care whose frame it is -, the ordered tails run as one launch with a workgroup per stream, and all due
+// warps leave in launches of 32 frames.  The members stay ordinary vs_stab instances (queues, pyramid rings, keypoint
+// buffers, trajectory state, counters and debug records of their own); what a standalone instance keeps per batch - host and
+// device tables, the events of the batch schedule, the inverse maps and coordinate tables of the pending warps - the group
+// keeps once.  group_run is run_batch with "for each member" around its per-frame loops.
+struct vs_batch {
+    int device = 0, S = 0, B = 0, cap = 0;
+    std::vector<vs_stab*> m;
+    std::string err;
+    hipStream_t st = nullptr, st_pre = nullptr, st_det = nullptr;
+    bool allocated = false;
+    uint8_t* h_tables = nullptr;
+    size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0, ho_seg = 0;
+    uint8_t* d_all = nullptr;
+    uint8_t *d_lk[2] = {nullptr, nullptr}, *d_rs[2] = {nullptr, nullptr}, *d_tail[2] = {nullptr, nullptr}, *d_seg[2] = {nullptr, nullptr}, *d_gf = nullptr;
+    ImgPair* d_pairs = nullptr;
+    double* d_MinvB[2] = {nullptr, nullptr};
+    int32_t* d_tabs[4] = {nullptr, nullptr, nullptr, nullptr};     // [set] frame plane, [2 + set] chroma plane
+    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {}, ev_warp[2] = {};
+    bool bdet_valid[4] = {false, false, false, false}, warp_valid[2] = {false, false};
+    int last_det_batch = -1, last_warp_set = -1, batch_id = 0, pend_set = 0;
+    struct Ready {
+        bool valid = false, tabs_built = false;
+        int n = 0, set = 0;
+        size_t stride = 0;
+        std::vector<const uint8_t*> srcs;
+        std::vector<uint8_t*> dsts;
+        std::vector<int> slots;
+        std::vector<vs_stab*> owner;
+    } ready, next;          // ready: the step whose tails are queued (its warps go out with the next step); next: the step being built
+};
+
+namespace {
+
+int gfail(vs_batch* g, int code, const std::string& msg) {
+    g->err = msg;
+    set_last_error(msg);
+    return code;
+}
+#define G_HIP(g, expr)                                                                        \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return gfail((g), VS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define G_TRY(g, expr)                                  \
+    do {                                                \
+        int _r = (expr);                                \
+        if (_r != VS_OK) { (g)->err = get_last_error(); return _r; } \
+    } while (0)
+
+void group_free(vs_batch* g) {
+    if (g->h_tables) (void)hipHostFree(g->h_tables);
+    if (g->d_all) (void)hipFree(g->d_all);
+    g->h_tables = nullptr; g->d_all = nullptr;
+    g->allocated = false;
+}
+
+// Tables and workspaces for cap = S * B frames per step, once the members know their geometry.
+int group_allocate(vs_batch* g) {
+    const vs_stab* s0 = g->m[0];
+    const int cap = g->cap, ngf = g->S * (g->B / 2 + 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_gf = take(gftt_item_bytes() * ngf);
+    const size_t o_lk[2] = {take(lk_item_bytes() * cap), take(lk_item_bytes() * cap)};
+    const size_t o_rs[2] = {take(ransac_item_bytes() * cap), take(ransac_item_bytes() * cap)};
+    const size_t o_tl[2] = {take(tail_item_bytes() * cap), take(tail_item_bytes() * cap)};
+    const size_t o_sg[2] = {take(tail_seg_bytes() * g->S), take(tail_seg_bytes() * g->S)};
+    const size_t o_pairs = take(sizeof(ImgPair) * cap * (2 + 2 * MAX_PYR));
+    const size_t o_minv[2] = {take((size_t)cap * 96), take((size_t)cap * 96)};
+    const size_t tab_bytes = warp_tabs_ints(s0->w, s0->h, cap) * sizeof(int32_t);
+    size_t o_tabs[4];
+    for (auto& o : o_tabs) o = take(tab_bytes);
+    G_HIP(g, hipMalloc((void**)&g->d_all, off));
+    G_HIP(g, hipMemsetAsync(g->d_all, 0, off, g->st));
+    uint8_t* b = g->d_all;
+    g->d_gf = b + o_gf;
+    for (int i = 0; i < 2; i++) {
+        g->d_lk[i] = b + o_lk[i]; g->d_rs[i] = b + o_rs[i]; g->d_tail[i] = b + o_tl[i]; g->d_seg[i] = b + o_sg[i];
+        g->d_MinvB[i] = (double*)(b + o_minv[i]);
+    }
+    g->d_pairs = (ImgPair*)(b + o_pairs);
+    for (int i = 0; i < 4; i++) g->d_tabs[i] = (int32_t*)(b + o_tabs[i]);
+    size_t ho = 0;
+    auto htake = [&](size_t bytes) { size_t o = ho; ho += (bytes + 255) & ~(size_t)255; return o; };
+    g->ho_pairs = htake(sizeof(ImgPair) * cap * (2 + 2 * MAX_PYR));
+    g->ho_lk = htake(lk_item_bytes() * cap); g->ho_rs = htake(ransac_item_bytes() * cap);
+    g->ho_tail = htake(tail_item_bytes() * cap); g->ho_gf = htake(gftt_item_bytes() * ngf); g->ho_seg = htake(tail_seg_bytes() * g->S);
+    g->h_set_bytes = ho;
+    G_HIP(g, hipHostMalloc((void**)&g->h_tables, 4 * ho));
+    memset(g->h_tables, 0, 4 * ho);
+    G_HIP(g, hipStreamSynchronize(g->st));
+    for (vs_batch::Ready* r : {&g->ready, &g->next}) { r->srcs.assign(cap, nullptr); r->dsts.assign(cap, nullptr); r->slots.assign(cap, -1); r->owner.assign(cap, nullptr); }
+    g->allocated = true;
+    return VS_OK;
+}
+
+// The warps of the step whose tails were queued last, 32 frames per launch (or only their coordinate tables).
+int group_ready_launches(vs_batch* g, int what) {
+    vs_batch::Ready& R = g->ready;
+    const vs_stab* s0 = g->m[0];
+    int rc = VS_OK;
+    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {
+        const int m = std::min(WARP_BATCH_MAX, R.n - i0);
+        const bool tabs = m >= 4;
+        if (what == VS_WARP_TABLES_ONLY && !tabs) continue;
+        const int w = tabs ? what : VS_WARP_ALL;
+        rc = launch_warp_affine_list(R.srcs.data() + i0, R.dsts.data() + i0, m, s0->src_pitch, s0->w, s0->h, R.stride, s0->w, s0->h, s0->cn,
+                                     g->d_MinvB[R.set] + 12 * i0, 12, tabs ? g->d_tabs[R.set] + i0 * warp_tabs_ints(s0->w, s0->h, 1) : nullptr, g->st, w);
+        if (rc == VS_OK && s0->fmt == VS_FMT_NV12) {
+            const uint8_t* us[WARP_BATCH_MAX];
+            uint8_t* ud[WARP_BATCH_MAX];
+            for (int i = 0; i < m; i++) {
+                us[i] = R.srcs[i0 + i] + src_uv(s0);
+                ud[i] = R.dsts[i0 + i] + dst_uv(s0, R.dsts[i0 + i], R.stride);
+            }
+            rc = launch_warp_affine_list(us, ud, m, s0->src_pitch, s0->w / 2, s0->h / 2, R.stride, s0->w / 2, s0->h / 2, 2, g->d_MinvB[R.set] + 12 * i0 + 6, 12,
+                                         tabs ? g->d_tabs[2 + R.set] + i0 * warp_tabs_ints(s0->w / 2, s0->h / 2, 1) : nullptr, g->st, w);
+        }
+    }
+    if (rc != VS_OK) g->err = get_last_error();
+    return rc;
+}
+
+int group_launch_ready(vs_batch* g) {
+    vs_batch::Ready& R = g->ready;
+    if (!R.valid) return VS_OK;
+    hipStream_t st = g->st;
+    vs_stab* s0 = g->m[0];
+    int rc;
+    {
+        StageScope t(s0, VS_STAGE_WARP, st);       // (stage times of a group are booked on its first member)
+        rc = group_ready_launches(g, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL);
+    }
+    if (hipEventRecord(g->ev_warp[R.set], st) == hipSuccess) { g->warp_valid[R.set] = true; g->last_warp_set = R.set; }
+    if (s0->ev_dev_warp && hipEventRecord(s0->ev_dev_warp, st) == hipSuccess) s0->dev_warp_valid->store(true, std::memory_order_release);
+    for (int i = 0; i < R.n; i++) {
+        const int slot = R.slots[i];
+        vs_stab* o = R.owner[i];
+        if (slot < 0 || !o) continue;              // zero-copy: the frame is the caller's
+        if (hipEventRecord(o->ev_slot[slot], st) == hipSuccess) o->slot_valid[slot] = true;
+        o->free_slots.push_back(slot);
+    }
+    R.valid = false;
+    return rc;
+}
+
+// One step of the group: everything its members have queued (run_batch, with "for each member" around the per-frame loops).
+int group_run(vs_batch* g) {
+    std::vector<vs_stab*> act;
+    int n = 0, max_n = 0;
+    for (vs_stab* s : g->m)
+        if (!s->bq.empty()) { act.push_back(s); n += (int)s->bq.size(); max_n = std::max(max_n, (int)s->bq.size()); }
+    if (n == 0) return VS_OK;
+    G_HIP(g, hipSetDevice(g->device));
+    const vs_stab* s0 = g->m[0];
+    for (vs_stab* s : act)
+        if (!s->allocated || !s->batch_active || s->w != s0->w || s->h != s0->h || s->fmt != s0->fmt || s->src_pitch != s0->src_pitch ||
+            s->zero_copy != s0->zero_copy || s->in_uv_off != s0->in_uv_off || s->out_uv_off != s0->out_uv_off)
+            return gfail(g, VS_ERR_INVALID_ARG, "vs_batch: the streams of a group share one frame geometry, pitch and input mode");
+    if (n > g->cap || max_n > BATCH_MAX) return gfail(g, VS_ERR_CAPACITY, "vs_batch: more frames queued than a step holds");
+    if (!g->allocated) G_TRY(g, group_allocate(g));
+    const vs_params_c& p = s0->p;
+    const int k = g->batch_id++;
+    if (k >= 4) G_HIP(g, hipEventSynchronize(g->ev_blk[k % 4]));
+    uint8_t* hset = g->h_tables + (size_t)(k % 4) * g->h_set_bytes;
+    ImgPair* h_pairs = reinterpret_cast<ImgPair*>(hset + g->ho_pairs);
+    uint8_t *h_lk = hset + g->ho_lk, *h_rs = hset + g->ho_rs, *h_tail = hset + g->ho_tail, *h_gf = hset + g->ho_gf, *h_seg = hset + g->ho_seg;
+    const int dset = k & 1;
+    // ---- pre
+    if (k >= 2) {
+        G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_blk[(k - 2) % 4], 0));
+        if (g->bdet_valid[(k - 2) % 4]) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_bdet[(k - 2) % 4], 0));
+    }
+    if (s0->ev_dev_warp && s0->dev_warp_valid->load(std::memory_order_acquire)) G_HIP(g, hipStreamWaitEvent(g->st_pre, s0->ev_dev_warp, 0));
+    else if (g->last_warp_set >= 0) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_warp[g->last_warp_set], 0));
+    // ---- argument tables: tracker, scoring, tail (segment = member)
+    const int set = g->pend_set;
+    vs_batch::Ready& R = g->next;           // (g->ready still holds the warps of the step before: they go out further down)
+    int idx = 0, n_max = 0, npend = 0, nseg = 0;
+    size_t pend_stride = 0;
+    for (vs_stab* s : act) {
+        const int ns = (int)s->bq.size(), first = idx;
+        for (int i = 0; i < ns; i++, idx++) {
+            const vs_stab::BFrame& b = s->bq[i];
+            const vs_stab::ItemBufs& it = s->items[i];
+            LKLevel L[MAX_PYR];
+            for (int l = 0; l <= s->levels; l++) {
+                L[l].prev = s->pyr[b.pv].img[l]; L[l].next = s->pyr[b.c].img[l]; L[l].deriv = s->pyr[b.pv].der[l];
+                L[l].w = s->lw[l]; L[l].h = s->lh[l]; L[l].stride = s->lw[l];
+            }
+            const int cap = std::max(b.lk_cap, 0);
+            n_max = std::max(n_max, cap);
+            G_TRY(g, lk_fill_item(h_lk + lk_item_bytes() * idx, L, s->levels, s->d_pts[b.lk_buf], cap, s->d_npts[b.lk_buf], it.next, it.status, it.err,
+                                  p.lk_win_size, p.lk_max_iters, p.lk_epsilon));
+            G_TRY(g, ransac_fill_item(h_rs + ransac_item_bytes() * idx, s->d_pts[b.lk_buf], it.next, it.status, cap, s->d_npts[b.lk_buf], it.vp, it.vc,
+                                      it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab, it.counts, it.model, it.inliers, it.info, s->d_traj,
+                                      &s->tp, s->d_dbg, b.have_prev_gray));
+            ransac_item_set_last(h_rs + ransac_item_bytes() * idx, i == ns - 1 ? 1 : 0);
+            double* minv = nullptr;
+            if (b.out_due) {
+                if (npend > 0 && pend_stride != b.out_stride) return gfail(g, VS_ERR_INVALID_ARG, "vs_batch: one output pitch per step");
+                minv = g->d_MinvB[set] + 12 * npend;
+                R.srcs[npend] = b.out_frame; R.dsts[npend] = b.d_out; R.slots[npend] = b.out_slot; R.owner[npend] = s;
+                pend_stride = b.out_stride;
+                npend++;
+            }
+            tail_fill_item(h_tail + tail_item_bytes() * idx, b.out_due ? 1 : 0, b.out_idx, minv);
+            tail_item_set_seg(h_tail + tail_item_bytes() * idx, nseg);
+        }
+        tail_fill_seg(h_seg + tail_seg_bytes() * nseg, first, ns, s->d_M);
+        nseg++;
+        if (s->bq[0].prev_small) {   // Stabilizer.cpp:598-603 (once per stream: 480x270 -> analysis size)
+            G_TRY(g, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[s->bq[0].pv].img[0], s->aw, s->aw, s->ah, g->st_pre));
+            G_TRY(g, build_pyramid(s, s->bq[0].pv, g->st_pre));
+        }
+    }
+    {
+        const int L = s0->levels;
+        int aligned = 1, n_detect = 0;
+        for (vs_stab* s : act) for (const vs_stab::BFrame& b : s->bq) n_detect += b.detect ? 1 : 0;
+        int n_first = 0, n_rest = 0, i = 0;
+        for (vs_stab* s : act)
+            for (const vs_stab::BFrame& b : s->bq) {
+                const Pyramid& P = s->pyr[b.c];
+                const int slot = b.detect ? n_first++ : n_detect + n_rest++;
+                h_pairs[slot] = ImgPair{b.frame, P.img[0]};
+                if ((uintptr_t)b.frame % 8) aligned = 0;
+                for (int l = 1; l <= L; l++) h_pairs[(size_t)l * n + i] = ImgPair{P.img[l - 1], P.img[l]};
+                for (int l = 0; l <= L; l++) h_pairs[(size_t)(L + 1 + l) * n + i] = ImgPair{P.img[l], P.der[l]};
+                i++;
+            }
+        G_HIP(g, hipMemcpyAsync(g->d_pairs, h_pairs, sizeof(ImgPair) * n * (2 * L + 2), hipMemcpyHostToDevice, g->st_pre));
+        {
+            const int gfmt = s0->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s0->fmt;
+            const int n_a = (n_detect > 0 && n_detect < n) ? n_detect : n;
+            G_TRY(g, launch_resize_gray_batch(g->d_pairs, n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));
+            G_HIP(g, hipEventRecord(g->ev_bgray, g->st_pre));
+            if (n_a < n)
+                G_TRY(g, launch_resize_gray_batch(g->d_pairs + n_a, n - n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));
+        }
+        G_HIP(g, hipMemcpyAsync(g->d_lk[dset], h_lk, lk_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
+        G_HIP(g, hipMemcpyAsync(g->d_rs[dset], h_rs, ransac_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
+        G_HIP(g, hipMemcpyAsync(g->d_tail[dset], h_tail, tail_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
+        G_HIP(g, hipMemcpyAsync(g->d_seg[dset], h_seg, tail_seg_bytes() * nseg, hipMemcpyHostToDevice, g->st_pre));
+        for (int l = 0; l <= L; l++)
+            G_TRY(g, launch_pyr_level_batch(g->d_pairs + (size_t)(L + 1 + l) * n, l < L ? g->d_pairs + (size_t)(l + 1) * n : nullptr, n, s0->lw[l], s0->lw[l],
+                                            s0->lh[l], l < L ? s0->lw[l + 1] : 0, g->st_pre));
+    }
+    G_HIP(g, hipEventRecord(g->ev_bpre, g->st_pre));
+    // ---- det
+    int ndet = 0;
+    for (vs_stab* s : act) {
+        int local = 0;
+        for (const vs_stab::BFrame& b : s->bq) {
+            if (!b.detect) continue;
+            G_TRY(g, gftt_fill_item(h_gf + gftt_item_bytes() * ndet, s->pyr[b.c].img[0], s->aw, s->aw, s->ah, s->pts_cap[b.det_buf], 0.02, 15.0, 3,
+                                    s->gws[local], s->d_pts[b.det_buf], s->d_npts[b.det_buf]));
+            s->dbg_det_pts = s->d_pts[b.det_buf]; s->dbg_det_n = s->d_npts[b.det_buf];
+            s->dbg_gftt_counters = s->gws[local].counters;
+            local++; ndet++;
+        }
+        s->last_detected = s->bq.back().detect;
+    }
+    hipStream_t sd = g->st_det;
+    if (ndet > 0) {
+        G_HIP(g, hipMemcpyAsync(g->d_gf, h_gf, gftt_item_bytes() * ndet, hipMemcpyHostToDevice, sd));
+        if (k >= 2) G_HIP(g, hipStreamWaitEvent(sd, g->ev_blk[(k - 2) % 4], 0));
+        G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 1));
+        G_HIP(g, hipStreamWaitEvent(sd, g->ev_bgray, 0));
+        {
+            StageScope t(g->m[0], VS_STAGE_GFTT, sd);
+            G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 2));
+            G_HIP(g, hipEventRecord(g->ev_bnms, sd));
+            G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 3));
+        }
+        G_HIP(g, hipEventRecord(g->ev_bdet[k % 4], sd));
+        g->last_det_batch = k;
+    }
+    g->bdet_valid[k % 4] = ndet > 0;
+    // ---- main
+    hipStream_t st = g->st;
+    G_HIP(g, hipStreamWaitEvent(st, g->ev_bpre, 0));
+    for (vs_stab* s : act)
+        if (s->pts_pending[0]) { G_HIP(g, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
+    const bool wait_det = g->last_det_batch >= 0 && g->last_det_batch >= k - 1;
+    const bool early = wait_det && g->last_det_batch == k;
+    if (early) G_HIP(g, hipStreamWaitEvent(st, g->ev_bnms, 0));
+    else if (wait_det) G_HIP(g, hipStreamWaitEvent(st, g->ev_bdet[g->last_det_batch % 4], 0));
+    // `main` has waited for this step's gray / pyramid work and the wide launches of its detection: the warps of the PREVIOUS
+    // step go out here, before this step's tracking
+    G_TRY(g, group_launch_ready(g));
+    if (early) G_HIP(g, hipStreamWaitEvent(st, g->ev_bdet[g->last_det_batch % 4], 0));
+    {
+        StageScope t(g->m[0], VS_STAGE_LK, st);
+        G_TRY(g, launch_pyr_lk_batch(g->d_lk[dset], n, n_max, p.lk_win_size, st));
+    }
+    {
+        StageScope t(g->m[0], VS_STAGE_RANSAC, st);
+        G_TRY(g, launch_ransac_score_batch(g->d_rs[dset], n, p.ransac_max_iters, n_max, st));
+    }
+    if (npend > 0 && g->warp_valid[set]) {
+        G_HIP(g, hipStreamWaitEvent(st, g->ev_warp[set], 0));
+        g->warp_valid[set] = false;
+    }
+    {
+        StageScope t(g->m[0], VS_STAGE_TRAJ, st);
+        G_TRY(g, launch_ransac_tail_group(g->d_rs[dset], g->d_tail[dset], g->d_seg[dset], nseg, max_n, n, p.smoothing_method, st));
+    }
+    G_HIP(g, hipEventRecord(g->ev_blk[k % 4], st));
+    R.n = npend; R.set = set; R.stride = pend_stride; R.valid = npend > 0; R.tabs_built = false;
+    std::swap(g->ready, g->next);            // (the previous step's warps have been issued: g->ready was free)
+    if (g->ready.valid) {
+        g->pend_set = set ^ 1;
+        StageScope t(g->m[0], VS_STAGE_WARP_TABLES, st);
+        G_TRY(g, group_ready_launches(g, VS_WARP_TABLES_ONLY));
+        g->ready.tabs_built = true;
+    }
+    for (vs_stab* s : act) {
+        const vs_stab::BFrame& lb = s->bq.back();
+        const int nl = (int)s->bq.size();
+        s->dbg_prev_pts = s->d_pts[lb.lk_buf]; s->dbg_next = s->items[nl - 1].next;
+        s->dbg_status = s->items[nl - 1].status; s->dbg_inliers = s->items[nl - 1].inliers;
+        s->bq.clear();
+    }
+    return VS_OK;
+}
+
+}  // namespace
+
+// Everything the members have queued is analysed and its warps are issued.  (The warps of a step normally go out with the NEXT
+// step, between its detection and its tracking; group_run issues the pending ones itself, so the step before the drained one is
+// covered too.)
+int group_drain(vs_batch* g) {
+    G_HIP(g, hipSetDevice(g->device));
+    G_TRY(g, group_run(g));                 // (issues the warps of the step before on its way; nothing queued: nothing done)
+    return group_launch_ready(g);
+}
+
+extern "C" {
+
+int vs_batch_create(int device, int n_streams, const vs_params_c* params, int frames_per_step, vs_batch** out) {
+    if (!out) return VS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!params || n_streams < 1 || n_streams > 256 || frames_per_step < 1 || frames_per_step > BATCH_MAX) {
+        set_last_error("vs_batch_create: 1..256 streams, 1..64 frames per stream and step");
+        return VS_ERR_INVALID_ARG;
+    }
+    if (params->adaptive_smoothing || params->border_size > 0 || (params->enable_virtual_canvas && !params->crop_n_zoom)) {
+        set_last_error("vs_batch_create: adaptive smoothing, borders / crop-and-zoom and the virtual canvas are per-stream modes (use vs_stab_*)");
+        return VS_ERR_UNSUPPORTED;
+    }
+    vs_batch* g = new (std::nothrow) vs_batch();
+    if (!g) return VS_ERR_HIP;
+    g->device = device; g->S = n_streams; g->B = frames_per_step; g->cap = n_streams * frames_per_step;
+    for (int i = 0; i < n_streams; i++) {
+        vs_stab* s = nullptr;
+        int rc = vs_stab_create(params, device, &s);
+        if (rc == VS_OK) rc = vs_stab_set_batch(s, frames_per_step);
+        if (rc != VS_OK) { if (s) vs_stab_destroy(s); vs_batch_destroy(g); return rc; }
+        s->group = g;
+        g->m.push_back(s);
+    }
+    if (!g->m[0]->shared_streams) {
+        set_last_error("vs_batch_create: needs the device's shared stream set (VS_STAB_PRIVATE_STREAMS is set)");
+        vs_batch_destroy(g);
+        return VS_ERR_UNSUPPORTED;
+    }
+    g->st = g->m[0]->st; g->st_pre = g->m[0]->st_pre; g->st_det = g->m[0]->st_det;
+    auto mk = [&](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+    bool ok = mk(g->ev_bpre) && mk(g->ev_bgray) && mk(g->ev_bnms) && mk(g->ev_warp[0]) && mk(g->ev_warp[1]);
+    for (auto& e : g->ev_bdet) ok = ok && mk(e);
+    for (auto& e : g->ev_blk) ok = ok && mk(e);
+    if (!ok) { set_last_error("vs_batch_create: hipEventCreate failed"); vs_batch_destroy(g); return VS_ERR_HIP; }
+    *out = g;
+    return VS_OK;
+}
+
+void vs_batch_destroy(vs_batch* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->st_pre) (void)hipStreamSynchronize(g->st_pre);
+    if (g->st_det) (void)hipStreamSynchronize(g->st_det);
+    if (g->st) (void)hipStreamSynchronize(g->st);
+    for (vs_stab* s : g->m) { s->group = nullptr; s->bq.clear(); vs_stab_destroy(s); }
+    group_free(g);
+    auto kill = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };
+    kill(g->ev_bpre); kill(g->ev_bgray); kill(g->ev_bnms); kill(g->ev_warp[0]); kill(g->ev_warp[1]);
+    for (auto& e : g->ev_bdet) kill(e);
+    for (auto& e : g->ev_blk) kill(e);
+    delete g;
+}
+
+int vs_batch_streams(const vs_batch* g) { return g ? g->S : 0; }
+vs_stab* vs_batch_stream(vs_batch* g, int i) { return (g && i >= 0 && i < g->S) ? g->m[(size_t)i] : nullptr; }
+const char* vs_batch_last_error(const vs_batch* g) { return g ? g->err.c_str() : ""; }
+
+int vs_batch_set_zero_copy(vs_batch* g, int enable) {
+    if (!g) return VS_ERR_INVALID_ARG;
+    for (vs_stab* s : g->m) { const int rc = vs_stab_set_zero_copy(s, enable); if (rc != VS_OK) { g->err = s->err; return rc; } }
+    return VS_OK;
+}
+
+int vs_batch_set_nv12_layout(vs_batch* g, size_t in_uv_offset, size_t out_uv_offset) {
+    if (!g) return VS_ERR_INVALID_ARG;
+    for (vs_stab* s : g->m) { const int rc = vs_stab_set_nv12_layout(s, in_uv_offset, out_uv_offset); if (rc != VS_OK) { g->err = s->err; return rc; } }
+    return VS_OK;
+}
+
+int vs_batch_push_dev(vs_batch* g, const void* const* d_frames, int w, int h, size_t stride, int fmt, void* const* d_outs, size_t out_stride,
+                      int* produced) {
+    if (!g || !d_frames || !d_outs || !produced) return VS_ERR_INVALID_ARG;
+    for (int i = 0; i < g->S; i++) produced[i] = 0;
+    bool full = false;
+    for (int i = 0; i < g->S; i++) {
+        if (!d_frames[i]) continue;                       // no frame for this stream in this call
+        vs_stab* s = g->m[(size_t)i];
+        const int rc = vs_stab_push_dev(s, d_frames[i], w, h, stride, fmt, d_outs[i], out_stride, &produced[i]);
+        if (rc != VS_OK) { g->err = s->err; return rc; }
+        full |= (int)s->bq.size() >= g->B;
+    }
+    if (full) return group_run(g);
+    return VS_OK;
+}
+
+int vs_batch_flush_dev(vs_batch* g, void* const* d_outs, size_t out_stride, int* produced) {
+    if (!g || !d_outs || !produced) return VS_ERR_INVALID_ARG;
+    int rc = group_drain(g);
+    if (rc != VS_OK) return rc;
+    for (int i = 0; i < g->S; i++) {
+        produced[i] = 0;
+        rc = vs_stab_flush_dev(g->m[(size_t)i], d_outs[i], out_stride, &produced[i]);
+        if (rc != VS_OK) { g->err = g->m[(size_t)i]->err; return rc; }
+    }
+    return VS_OK;
+}
+
+int vs_batch_sync(vs_batch* g) {
+    if (!g) return VS_ERR_INVALID_ARG;
+    int rc = group_drain(g);
+    if (rc != VS_OK) return rc;
+    for (vs_stab* s : g->m) { rc = vs_stab_sync(s); if (rc != VS_OK) { g->err = s->err; return rc; } }
     return VS_OK;
 }
 

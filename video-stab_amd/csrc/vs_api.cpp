@@ -59,6 +59,19 @@ int vs_host_alloc(void** p, size_t bytes) {
     VS_HIP_TRY(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
     return VS_OK;
 }
+int vs_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return VS_ERR_INVALID_ARG;
+    VS_TRY(ensure_device());
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_last_error(std::string("vs_host_register: ") + hipGetErrorString(e)); return VS_ERR_HIP; }
+    return VS_OK;
+}
+int vs_host_unregister(void* p) {
+    if (!p) return VS_OK;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_last_error(std::string("vs_host_unregister: ") + hipGetErrorString(e)); return VS_ERR_HIP; }
+    return VS_OK;
+}
 void vs_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }

@@ -200,6 +200,22 @@ class VsLib:
         L.vs_stab_set_nv12_layout.argtypes = [vp, C.c_size_t, C.c_size_t]
         L.vs_stab_set_profiling.argtypes = [vp, C.c_int]
         L.vs_stab_get_stage_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        try:
+            L.vs_batch_create.argtypes = [C.c_int, C.c_int, C.POINTER(VsParams), C.c_int, C.POINTER(vp)]
+            L.vs_batch_destroy.argtypes = [vp]
+            L.vs_batch_destroy.restype = None
+            L.vs_batch_streams.argtypes = [vp]
+            L.vs_batch_stream.argtypes = [vp, C.c_int]
+            L.vs_batch_stream.restype = vp
+            L.vs_batch_set_zero_copy.argtypes = [vp, C.c_int]
+            L.vs_batch_set_nv12_layout.argtypes = [vp, C.c_size_t, C.c_size_t]
+            L.vs_batch_push_dev.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.c_size_t, i32p]
+            L.vs_batch_flush_dev.argtypes = [vp, C.POINTER(vp), C.c_size_t, i32p]
+            L.vs_batch_sync.argtypes = [vp]
+            L.vs_batch_last_error.argtypes = [vp]
+            L.vs_batch_last_error.restype = C.c_char_p
+        except AttributeError:      # a library of an earlier build (A/B measurements)
+            pass
         L.vs_dev_set_device.argtypes = [C.c_int]
         L.vs_dev_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
         try:
@@ -514,6 +530,9 @@ class VsLib:
 
     def roll_correction(self, params=None, device=0):
         return RollCorrection(self, params or self.roll_params(), device)
+
+    def batch(self, params, n_streams, frames_per_step, device=0):
+        return Batch(self, params, n_streams, frames_per_step, device)
 
     def stabilizer(self, params, device=0):
         return Stabilizer(self, params, device)
@@ -909,6 +928,70 @@ class Stabilizer:
         return dict(prev=prev[:d.n_prev], curr=cur[:d.n_prev], status=st[:d.n_prev], inliers=inl[:d.n_valid],
                     detected=det[:d.n_detected] if d.detected else det[:0],
                     gray=gray[:aw.value * ah.value].reshape(ah.value, aw.value))
+
+
+class Batch:
+    """vs_batch: n_streams streams of one device scheduled together (one launch per stage over the frames of all of them)."""
+
+    def __init__(self, vs, params, n_streams, frames_per_step, device=0):
+        self.vs, self.lib, self.n = vs, vs.lib, n_streams
+        h = C.c_void_p()
+        vs.check(self.lib.vs_batch_create(device, n_streams, C.byref(params), frames_per_step, C.byref(h)))
+        self.h = h
+        self._produced = (C.c_int32 * n_streams)()
+
+    def _check(self, status):
+        if status != 0:
+            msg = self.lib.vs_status_string(status).decode()
+            raise VsError("%s: %s" % (msg, (self.lib.vs_batch_last_error(self.h) or b"").decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.vs_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream(self, i):
+        """Member i as a Stabilizer view (getters only; it is not closed through the view)."""
+        s = Stabilizer.__new__(Stabilizer)
+        s.vs, s.lib = self.vs, self.lib
+        s.h = C.c_void_p(self.lib.vs_batch_stream(self.h, i))
+        s.close = lambda: None
+        return s
+
+    def set_zero_copy(self, on=True):
+        self._check(self.lib.vs_batch_set_zero_copy(self.h, int(on)))
+
+    def set_nv12_layout(self, in_uv_offset=0, out_uv_offset=0):
+        self._check(self.lib.vs_batch_set_nv12_layout(self.h, in_uv_offset, out_uv_offset))
+
+    def push_dev(self, d_frames, w, h, stride, fmt, d_outs, out_stride):
+        """d_frames / d_outs: one device pointer per stream (None: no frame for that stream).  Returns produced[]."""
+        fr = (C.c_void_p * self.n)(*[C.c_void_p(p) if p else None for p in d_frames])
+        ou = (C.c_void_p * self.n)(*[C.c_void_p(p) if p else None for p in d_outs])
+        self._check(self.lib.vs_batch_push_dev(self.h, fr, w, h, stride, fmt, ou, out_stride, self._produced))
+        return list(self._produced)
+
+    def pointer_array(self, ptrs):
+        """A reusable argument of push_dev_arrays: one device pointer per stream."""
+        return (C.c_void_p * self.n)(*[C.c_void_p(p) if p else None for p in ptrs])
+
+    def push_dev_arrays(self, fr, w, h, stride, fmt, ou, out_stride):
+        """push_dev with prepared pointer arrays (pointer_array): no per-call marshalling."""
+        self._check(self.lib.vs_batch_push_dev(self.h, fr, w, h, stride, fmt, ou, out_stride, self._produced))
+
+    def flush_dev(self, d_outs, out_stride):
+        ou = (C.c_void_p * self.n)(*[C.c_void_p(p) if p else None for p in d_outs])
+        self._check(self.lib.vs_batch_flush_dev(self.h, ou, out_stride, self._produced))
+        return list(self._produced)
+
+    def sync(self):
+        self._check(self.lib.vs_batch_sync(self.h))
 
 
 _cached = None
