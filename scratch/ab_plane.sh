@@ -1,4 +1,5 @@
 #!/bin/bash
+export VS_LAB=1    # the library reads its measurement switches only then
 # ab_plane.sh <outdir>: bench.py --workload configs2 with the first and the second plane kernel, alternating (same box)
 OUT=$1; mkdir -p $OUT
 for rep in 1 2; do for v in 1 3; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VS_LAB=1    # the library reads its measurement switches only then
 # plane_skel.sh <outdir> "<kernel> <skip>" ...: per-kernel times (rocprofv3 --stats) of the 4K NV12 stream with a plane kernel's halves switched off
 OUT=$(pwd)/$1; shift; mkdir -p $OUT; ROOT=$(pwd)
 cd /tmp; export TMPDIR=/tmp VS_BENCH_4K_WARM=10

@@ -11,7 +11,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "_build", "libvso_oracle.so")
+# VSO_ORACLE_LIB: another build of the oracle (the sanitizer build of `make asan`)
+LIB = os.environ.get("VSO_ORACLE_LIB") or os.path.join(ORACLE_DIR, "_build", "libvso_oracle.so")
 
 u8p = C.POINTER(C.c_uint8)
 f32p = C.POINTER(C.c_float)

@@ -386,6 +386,7 @@ def test_batch_mode_pyramid_levels_of_odd_sizes(gpu, monkeypatch, size, levels, 
     so the levels here have odd widths and heights (200x150 -> 100x75 -> 50x38 -> 25x19 -> ...), widths that are not
     multiples of four and tiles that hang over every border.  Same tracks, same frames as the per-frame pipeline."""
     if not fused:
+        monkeypatch.setenv("VS_LAB", "1")
         monkeypatch.setenv("VS_STAB_SPLIT_PYRAMID", "1")
     w, h = size
     clip = synth.make_clip(synth.SEED_CONFIG1 + 31, w, h, 12)
@@ -766,6 +767,7 @@ def test_keypoint_buffers_are_not_recycled_under_the_ransac_kernels(gpu, oracle,
             break
         ref.append(r)
     so.close()
+    monkeypatch.setenv("VS_LAB", "1")
     monkeypatch.setenv("VS_STAB_DEBUG_DELAY_US", "400")
     got = _unsynced_outputs(gpu, clip, order, batch, smoothing_radius=5)
     assert len(got) == len(ref) == 20

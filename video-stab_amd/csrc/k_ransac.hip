@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void ransac_score16_batch_kernel(const RansacAr
 
 // VS_RANSAC_WAVE_PER_HYPOTHESIS=1: one wave per hypothesis, the scoring before this was measured
 bool score16_setting() {
-    static const bool v = std::getenv("VS_RANSAC_WAVE_PER_HYPOTHESIS") == nullptr;
+    static const bool v = lab_env("VS_RANSAC_WAVE_PER_HYPOTHESIS") == nullptr;
     return v;
 }
 
@@ -704,7 +704,7 @@ int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items,
     const int threads = 64 * (items < 1 ? 1 : (items > 16 ? 16 : items));
     if (items > 64) { set_last_error("ransac_tail_batch: at most 64 frames"); return VS_ERR_INVALID_ARG; }
     // (VS_TAIL_ONE_KERNEL=1: releases inside the tail kernel, as measured before)
-    static const bool apart = std::getenv("VS_TAIL_ONE_KERNEL") == nullptr;
+    static const bool apart = lab_env("VS_TAIL_ONE_KERNEL") == nullptr;
     const RansacArgs* tb = static_cast<const RansacArgs*>(d_table);
     TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
     if (apart && smoothing_method != VS_SMOOTH_KALMAN) {

@@ -1532,7 +1532,7 @@ inline int tab_stride_of(int dw, int dh) { return tab_layout(dw, dh).stride; }
 
 // VS_WARP_TAB_KERNEL=0: BGR8 launches with tables take the general kernel as well (A/B measurements)
 bool tab_kernel_setting() {
-    static const bool v = [] { const char* e = std::getenv("VS_WARP_TAB_KERNEL"); return !(e && e[0] == '0'); }();
+    static const bool v = [] { const char* e = lab_env("VS_WARP_TAB_KERNEL"); return !(e && e[0] == '0'); }();
     return v;
 }
 
@@ -1542,8 +1542,8 @@ bool tab_kernel_setting() {
 // VS_WARP_XCD_ORDER=0: plain (x, y, frame) tile order in the table kernels (A/B measurements)
 uint32_t xcd_order_flag() {
     static const uint32_t v = [] {
-        const char* e = std::getenv("VS_WARP_XCD_ORDER");
-        const char* d = std::getenv("VS_WARP_LAB_SKIP");        // 1: no staging loads, 2: no blending, 3: both (plane kernel, timing only)
+        const char* e = lab_env("VS_WARP_XCD_ORDER");
+        const char* d = lab_env("VS_WARP_LAB_SKIP");        // 1: no staging loads, 2: no blending, 3: both (plane kernel, timing only)
         return ((e && e[0] == '0') ? 0u : 0x100u) | (d ? (uint32_t)(d[0] - '0') << 9 : 0u);
     }();
     return v;
@@ -1562,7 +1562,7 @@ int device_cus() {
 }
 
 int plane_kernel_setting() {
-    static const int v = [] { const char* e = std::getenv("VS_WARP_PLANE_KERNEL"); return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : 1; }();
+    static const int v = [] { const char* e = lab_env("VS_WARP_PLANE_KERNEL"); return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : 1; }();
     return v;
 }
 

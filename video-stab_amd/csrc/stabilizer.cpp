@@ -976,11 +976,11 @@ int run_batch(vs_stab* s) {
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(k - 2) % 4], 0));
         if (s->bdet_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(k - 2) % 4], 0));
     }
-    if (s->ev_dev_warp && s->dev_warp_valid->load(std::memory_order_acquire) && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr && std::getenv("VS_STAB_OWN_WARP_GUARD") == nullptr) {
+    if (s->ev_dev_warp && s->dev_warp_valid->load(std::memory_order_acquire) && lab_env("VS_STAB_NO_WARP_GUARD") == nullptr && lab_env("VS_STAB_OWN_WARP_GUARD") == nullptr) {
         // several instances share the streams: the last batched warp of ANY of them (the instances' launches interleave in
         // the shared queues, so that is the one in front of this batch's kernels)
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_dev_warp, 0));
-    } else if (s->last_warp_set >= 0 && std::getenv("VS_STAB_NO_WARP_GUARD") == nullptr) {
+    } else if (s->last_warp_set >= 0 && lab_env("VS_STAB_NO_WARP_GUARD") == nullptr) {
         // keep the HBM-bound warp alone on the GPU even when the host runs batches ahead: this batch's gray /
         // pyramid / detection kernels start after the warps issued during the previous run_batch (batch k-2's)
         S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_warp[s->last_warp_set], 0));
@@ -1066,7 +1066,7 @@ int run_batch(vs_stab* s) {
         // the schedule before): 3 launches instead of 5, level 0 of a batch 35 us instead of 37 + 61, and the detector's
         // min-eigenvalue launch no longer shares the GPU with a 60 us pyrDown.  (The first version of the kernel, with
         // byte-wide LDS reads, took 81 us for level 0 and lost: 77.6 k.)
-        if (std::getenv("VS_STAB_SPLIT_PYRAMID") != nullptr) {
+        if (lab_env("VS_STAB_SPLIT_PYRAMID") != nullptr) {
             for (int l = 1; l <= L; l++)
                 S_TRY(s, launch_pyr_down_batch(s->d_pairs + (size_t)l * n, n, s->lw[l - 1], s->lw[l - 1], s->lh[l - 1], s->lw[l], s->st_pre));
             for (int l = 0; l <= L; l++)
@@ -1100,7 +1100,7 @@ int run_batch(vs_stab* s) {
         // the previous one must have read them (the GFTT scratch is only touched on this stream)
         if (k >= 2) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 2) % 4], 0));
         S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 1));
-        S_HIP(s, hipStreamWaitEvent(s->st_det, std::getenv("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
+        S_HIP(s, hipStreamWaitEvent(s->st_det, lab_env("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
         {
             StageScope t(s, VS_STAGE_GFTT, s->st_det);
             S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 2));   // :740-744: block size 3
@@ -1118,7 +1118,7 @@ int run_batch(vs_stab* s) {
     S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
     if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
     const bool wait_det = s->last_det_batch >= 0 && s->last_det_batch >= k - 1;
-    const bool early = wait_det && s->last_det_batch == k && std::getenv("VS_STAB_WARP_AFTER_SELECT") == nullptr;
+    const bool early = wait_det && s->last_det_batch == k && lab_env("VS_STAB_WARP_AFTER_SELECT") == nullptr;
     if (early) S_HIP(s, hipStreamWaitEvent(st, s->ev_bnms, 0));
     else if (wait_det) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
     // `main` has now waited for this batch's gray / pyramid work and the wide launches of its detection: the warps of the
@@ -1158,7 +1158,7 @@ int run_batch(vs_stab* s) {
         if (R.valid) s->pend_set = set ^ 1;
         // the maps of these warps exist once the tail has run: their coordinate tables are built right behind it
         R.tabs_built = false;
-        if (R.valid && std::getenv("VS_STAB_TABLES_WITH_WARP") == nullptr) {
+        if (R.valid && lab_env("VS_STAB_TABLES_WITH_WARP") == nullptr) {
             StageScope t(s, VS_STAGE_WARP_TABLES, st);
             S_TRY(s, ready_launches(s, VS_WARP_TABLES_ONLY));
             R.tabs_built = true;
@@ -1319,7 +1319,7 @@ std::mutex g_pool_mutex;
 std::map<int, StreamPool> g_pools;
 
 hipError_t make_streams(hipStream_t* st, hipStream_t* pre, hipStream_t* det, hipStream_t* warp) {
-    if (const char* m = std::getenv("VS_STAB_STREAM_LAYOUT")) {
+    if (const char* m = lab_env("VS_STAB_STREAM_LAYOUT")) {
         // experiment switch: "1" = everything on one stream, "2" = pre+det share one stream, main has its own
         hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
         if (e != hipSuccess) return e;
@@ -1341,7 +1341,7 @@ hipError_t make_streams(hipStream_t* st, hipStream_t* pre, hipStream_t* det, hip
 }
 
 hipError_t acquire_streams(vs_stab* s) {
-    if (std::getenv("VS_STAB_PRIVATE_STREAMS")) return make_streams(&s->st, &s->st_pre, &s->st_det, &s->st_warp);
+    if (lab_env("VS_STAB_PRIVATE_STREAMS")) return make_streams(&s->st, &s->st_pre, &s->st_det, &s->st_warp);
     std::lock_guard<std::mutex> g(g_pool_mutex);
     StreamPool& p = g_pools[s->device];
     if (p.refs == 0) {
@@ -1393,7 +1393,7 @@ int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
     s->p = *params;
     s->device = device;
     s->host_radius = params->smoothing_radius;
-    if (const char* e = std::getenv("VS_STAB_DEBUG_DELAY_US")) s->dbg_delay_us = std::max(0, std::min(std::atoi(e), 20000));
+    if (const char* e = lab_env("VS_STAB_DEBUG_DELAY_US")) s->dbg_delay_us = std::max(0, std::min(std::atoi(e), 20000));
     memset(&s->counters, 0, sizeof s->counters);
     fill_traj_params(s);
     hipError_t e = acquire_streams(s);
@@ -1502,7 +1502,7 @@ static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, si
     // download is therefore issued by the instance's helper thread, beside this thread's upload (VS_STAB_HOST_HELPER=0: from
     // this thread, as before).  (Staging both directions through page-locked buffers of our own with a pool of copy threads
     // was measured first and lost to the runtime's path: scratch/README.md.)
-    static const bool use_helper = [] { const char* e = std::getenv("VS_STAB_HOST_HELPER"); return !(e && e[0] == '0'); }();
+    static const bool use_helper = [] { const char* e = lab_env("VS_STAB_HOST_HELPER"); return !(e && e[0] == '0'); }();
     struct Join {           // the helper's job refers to the caller's buffer: no way out of this call without waiting for it
         HostHelper* h = nullptr;
         ~Join() { if (h) (void)h->wait(); }

@@ -3,6 +3,7 @@
 #define VS_COMMON_H
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <cfloat>
 #include <cmath>
@@ -56,6 +57,14 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 // cv::warpAffine's inversion of the forward 2x3 matrix, in double (imgwarp.cpp).  The same
 // IEEE operation sequence on host and device (no FMA contraction in either build).
+// The measurement switches of scratch/ (kernel variants, schedule variants, timing-only skips) are read only in a process that
+// sets VS_LAB=1: a production process has exactly one configuration of this library.  (The documented runtime settings -
+// VS_STAB_DEVICE, VS_STAB_HOST_PIPELINE, VS_STAB_HELPER_SPIN_US - are ordinary environment variables.)
+inline const char* lab_env(const char* name) {
+    const char* e = std::getenv("VS_LAB");
+    return (e && e[0] == '1') ? std::getenv(name) : nullptr;
+}
+
 #ifdef __HIPCC__
 __host__ __device__
 #endif
