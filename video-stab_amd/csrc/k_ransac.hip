@@ -156,6 +156,15 @@ __device__ __forceinline__ bool is_inlier(const float F[6], float fx, float fy, 
 
 constexpr int MAX_PTS = 4096;
 
+// What the ordered tail of a batch needs of a frame, in one place: written by the frame's selection, read by the tail with ONE
+// round of loads (from the argument block it was three dependent ones - block, then the pointers in it, then what they point
+// to - and a round trip costs the one-workgroup tail 10 us and more while the detector's kernels stream beside it).
+struct TailIn {
+    double model[6];
+    int32_t info[4];
+    int32_t nprev, have_prev_gray, pad[2];
+};
+
 struct RansacArgs {
     // correspondences.  With `status` != nullptr they are the raw LK output
     // (prev/next + status) and every workgroup compacts them itself
@@ -184,6 +193,7 @@ struct RansacArgs {
     vs_debug_frame* dbg;
     int have_prev_gray;
     int last_of_stream;       // group launches (several streams in one table): this is its stream's last frame of the batch
+    TailIn* tail_in;          // batch mode: where the selection leaves its results for the tail (or nullptr)
 };
 
 __device__ __forceinline__ int device_count(const RansacArgs& a) {
@@ -306,6 +316,7 @@ __device__ __forceinline__ void ransac_select(const RansacArgs& a, const bool wr
     if (lane < 6) a.model[lane] = __longlong_as_double(0x7FF8000000000000LL);
     for (int i = lane; i < a.n; i += 64) a.inliers[i] = 0;
     if (lane < 4) a.info[lane] = lane == 1 ? -1 : 0;
+    int r_info[4] = {0, -1, 0, 0};                    // what a.info ends up holding (wave-uniform), for the tail's record
     if (a.dbg && write_dbg && lane == 0) { a.dbg->n_prev = nprev; a.dbg->n_valid = n; }
     if (MULTI) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
     else __syncthreads();
@@ -318,6 +329,7 @@ __device__ __forceinline__ void ransac_select(const RansacArgs& a, const bool wr
             if (lane < 6) a.model[lane] = best.m[lane];
             if (lane < 2) a.inliers[lane] = 1;
             if (lane == 0) { a.info[0] = 1; a.info[1] = 0; a.info[2] = 0; a.info[3] = 2; }
+            r_info[0] = 1; r_info[1] = 0; r_info[2] = 0; r_info[3] = 2;
             ok = true;
         } else {
             int best_iter = -1, niters = a.iters > 1 ? a.iters : 1, max_good = 0;
@@ -342,6 +354,7 @@ __device__ __forceinline__ void ransac_select(const RansacArgs& a, const bool wr
                 }
             }
             if (lane == 0) { a.info[1] = best_iter; a.info[2] = niters; }
+            r_info[1] = best_iter; r_info[2] = niters;
             if (max_good > 0 && best_iter >= 0) {
                 const uint32_t pr = a.pairs[(size_t)n * a.iters + best_iter];
                 const int i0 = pr & 0xFFFFu, i1 = pr >> 16;
@@ -386,9 +399,16 @@ __device__ __forceinline__ void ransac_select(const RansacArgs& a, const bool wr
                 }
                 if (lane < 6) a.model[lane] = best.m[lane];
                 if (lane == 0) { a.info[0] = 1; a.info[3] = max_good; }
+                r_info[0] = 1; r_info[3] = max_good;
                 ok = true;
             }
         }
+    }
+    if (MULTI && a.tail_in) {
+        TailIn* ti = a.tail_in;
+        if (lane < 6) ti->model[lane] = ok ? best.m[lane] : __longlong_as_double(0x7FF8000000000000LL);
+        if (lane == 6) { ti->info[0] = r_info[0]; ti->info[1] = r_info[1]; ti->info[2] = r_info[2]; ti->info[3] = r_info[3]; }
+        if (lane == 7) { ti->nprev = nprev; ti->have_prev_gray = a.have_prev_gray; }
     }
     (void)ok;
     if (!MULTI && a.traj) {
@@ -435,7 +455,7 @@ struct TailItem {
 };
 // A launch over the frames of several streams (vs_batch): the items of stream s are table[first .. first + n), workgroup s of the
 // tail takes them, and the stream's frame matrix goes to its own M_out.
-struct TailSeg { int first, n; float* M_out; };
+struct TailSeg { int first, n; float* M_out; TrajState* traj; vs_debug_frame* dbg; };
 
 // RELEASE_APART: the kernel ends with the appends (phases 1 and 2a) and leaves the releases - smoothing around the frame each
 // due push lets go, its matrix and inverse map - to ransac_release_batch_kernel, one workgroup per push: on the one CU of
@@ -443,10 +463,13 @@ struct TailSeg { int first, n; float* M_out; };
 // smoother, whose filter state advances from release to release.)
 template <bool RELEASE_APART>
 __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArgs* __restrict__ table,
-                                                                 TailItem* __restrict__ tail, int n, float* M_out, const TailSeg* __restrict__ segs) {
+                                                                 TailItem* __restrict__ tail, int n, float* M_out, const TailSeg* __restrict__ segs,
+                                                                 const TailIn* __restrict__ tin, TrajState* g_state, vs_debug_frame* g_dbg) {
+    // (Beside the detector's NMS launch of the next batch this kernel takes 85 us, alone 10 - 25; s_setprio(3) for its waves
+    // changes nothing: measured, not kept.)
     if (segs) {                      // one workgroup per stream of a group launch
         const TailSeg sg = segs[blockIdx.x];
-        table += sg.first; tail += sg.first; n = sg.n; M_out = sg.M_out;
+        table += sg.first; tail += sg.first; tin += sg.first; n = sg.n; M_out = sg.M_out; g_state = sg.traj; g_dbg = sg.dbg;
         if (n <= 0) return;
     }
     // The ordered part below is a chain of small dependent steps executed by one lane; run from global
@@ -467,8 +490,7 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     __shared__ float l_trf[TB][3];                   // measured (dx, dy, da) of frame i, decomposed by the frame's own wave
     __shared__ vs_debug_frame l_dbg_scratch[16];     // per wave: record of a release that is not the batch's last
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    TrajState* g_state = table[0].traj;
-    vs_debug_frame* g_dbg = table[0].dbg;
+    // (state, record, parameters and the frames' inputs all lie at addresses the kernel was given: one round of loads)
     for (int i = tid; i < (int)(sizeof(TrajState) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(&l_state)[i] = reinterpret_cast<const uint32_t*>(g_state)[i];
     for (int i = tid; i < (int)(sizeof(TrajParams) / 4); i += blockDim.x)
@@ -479,17 +501,17 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     const int nwaves = blockDim.x >> 6;
     // (the selections themselves ran behind the scoring launch, one workgroup per frame: ransac_select_batch_kernel)
     for (int f = tid >> 4; f < n; f += blockDim.x >> 4) {
-        const RansacArgs& a = table[f];
+        const TailIn& a = tin[f];
         const int l16 = tid & 15;
         if (l16 < 6) l_model[f][l16] = a.model[l16];
         if (l16 >= 8 && l16 < 12) l_info[f][l16 - 8] = a.info[l16 - 8];
         if (l16 == 15) {
-            l_nprev[f] = device_count(a); l_hpg[f] = a.have_prev_gray;
+            l_nprev[f] = a.nprev; l_hpg[f] = a.have_prev_gray;
             l_due[f] = tail[f].out_due; l_oidx[f] = tail[f].out_idx;
             // :644-662 for this frame (identity when the estimation failed or was skipped): the arctangent leaves the
             // ordered chain below
             float t3[3] = {0.f, 0.f, 0.f};
-            if (l_nprev[f] > 0 && a.have_prev_gray) {
+            if (a.nprev > 0 && a.have_prev_gray) {
                 float T[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
                 if (a.info[0]) for (int i = 0; i < 6; i++) T[i] = (float)a.model[i];
                 t3[0] = T[2]; t3[1] = T[5]; t3[2] = vslibm::atan2f_ref(T[3], T[0]);
@@ -497,9 +519,7 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
             l_trf[f][0] = t3[0]; l_trf[f][1] = t3[1]; l_trf[f][2] = t3[2];
         }
     }
-    __threadfence();
-    __syncthreads();
-    // (after the selections: the last one has reported n_prev / n_valid into the global record)
+    // (the selections ran in the launch before this one: the last one has reported n_prev / n_valid into the global record)
     for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)
         reinterpret_cast<uint32_t*>(&l_dbg)[i] = reinterpret_cast<const uint32_t*>(g_dbg)[i];
     __syncthreads();
@@ -671,17 +691,19 @@ void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_ou
 
 // ---- group launches (vs_batch: the frames of several streams in one table) ----
 size_t tail_seg_bytes() { return sizeof(TailSeg); }
-void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out) {
+void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out, TrajState* traj, vs_debug_frame* dbg) {
     TailSeg& g = *static_cast<TailSeg*>(host_seg);
-    g.first = first; g.n = n; g.M_out = d_M_out;
+    g.first = first; g.n = n; g.M_out = d_M_out; g.traj = traj; g.dbg = dbg;
 }
+size_t tail_in_bytes() { return sizeof(TailIn); }
+void ransac_item_set_tail_in(void* host_item, void* d_tail_in) { static_cast<RansacArgs*>(host_item)->tail_in = static_cast<TailIn*>(d_tail_in); }
 void tail_item_set_seg(void* host_item, int seg) { static_cast<TailItem*>(host_item)->seg = seg; }
 void ransac_item_set_last(void* host_item, int last) { static_cast<RansacArgs*>(host_item)->last_of_stream = last; }
 
 // The ordered tails of `nsegs` streams in one launch (workgroup = stream), then the releases of all their pushes.
-int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void* d_segs, int nsegs, int max_n, int items, int smoothing_method,
-                             hipStream_t st) {
-    if (!d_table || !d_tail || !d_segs || nsegs < 1 || max_n < 1 || max_n > 64 || items < 1) {
+int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void* d_segs, const void* d_tail_in, int nsegs, int max_n, int items,
+                             int smoothing_method, hipStream_t st) {
+    if (!d_table || !d_tail || !d_segs || !d_tail_in || nsegs < 1 || max_n < 1 || max_n > 64 || items < 1) {
         set_last_error("ransac_tail_group: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
@@ -689,18 +711,21 @@ int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void
     const RansacArgs* tb = static_cast<const RansacArgs*>(d_table);
     TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
     const TailSeg* sg = static_cast<const TailSeg*>(d_segs);
+    const TailIn* ti = static_cast<const TailIn*>(d_tail_in);
     if (smoothing_method != VS_SMOOTH_KALMAN) {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(nsegs), dim3(threads), 0, st, tb, tl, 0, (float*)nullptr, sg);
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(nsegs), dim3(threads), 0, st, tb, tl, 0, (float*)nullptr, sg, ti, (TrajState*)nullptr, (vs_debug_frame*)nullptr);
         hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, 0, (float*)nullptr, sg);
     } else {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(nsegs), dim3(threads), 0, st, tb, tl, 0, (float*)nullptr, sg);
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(nsegs), dim3(threads), 0, st, tb, tl, 0, (float*)nullptr, sg, ti, (TrajState*)nullptr, (vs_debug_frame*)nullptr);
     }
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
 
-int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, int smoothing_method, hipStream_t st) {
-    if (!d_table || !d_tail || items < 1 || !d_M_out) { set_last_error("ransac_tail_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
+int launch_ransac_tail_batch(const void* d_table, const void* d_tail, const void* d_tail_in, TrajState* traj, vs_debug_frame* dbg, int items,
+                             float* d_M_out, int smoothing_method, hipStream_t st) {
+    if (!d_table || !d_tail || !d_tail_in || !traj || !dbg || items < 1 || !d_M_out) { set_last_error("ransac_tail_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
+    const TailIn* ti = static_cast<const TailIn*>(d_tail_in);
     const int threads = 64 * (items < 1 ? 1 : (items > 16 ? 16 : items));
     if (items > 64) { set_last_error("ransac_tail_batch: at most 64 frames"); return VS_ERR_INVALID_ARG; }
     // (VS_TAIL_ONE_KERNEL=1: releases inside the tail kernel, as measured before)
@@ -708,10 +733,10 @@ int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items,
     const RansacArgs* tb = static_cast<const RansacArgs*>(d_table);
     TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
     if (apart && smoothing_method != VS_SMOOTH_KALMAN) {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr);
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr, ti, traj, dbg);
         hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr);
     } else {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr);
+        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr, ti, traj, dbg);
     }
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;

@@ -64,13 +64,16 @@ int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_m
 int launch_ransac_select_item(const void* host_item, hipStream_t st);
 size_t tail_item_bytes();
 void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out);
-int launch_ransac_tail_batch(const void* d_table, const void* d_tail, int items, float* d_M_out, int smoothing_method, hipStream_t st);
+int launch_ransac_tail_batch(const void* d_table, const void* d_tail, const void* d_tail_in, TrajState* traj, vs_debug_frame* dbg, int items,
+                             float* d_M_out, int smoothing_method, hipStream_t st);
+size_t tail_in_bytes();
+void ransac_item_set_tail_in(void* host_item, void* d_tail_in);
 size_t tail_seg_bytes();
-void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out);
+void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out, TrajState* traj, vs_debug_frame* dbg);
 void tail_item_set_seg(void* host_item, int seg);
 void ransac_item_set_last(void* host_item, int last);
-int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void* d_segs, int nsegs, int max_n, int items, int smoothing_method,
-                             hipStream_t st);
+int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void* d_segs, const void* d_tail_in, int nsegs, int max_n, int items,
+                             int smoothing_method, hipStream_t st);
 size_t gftt_item_bytes();
 int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
                    double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
@@ -243,6 +246,7 @@ struct vs_stab {
     uint8_t* h_tables = nullptr;                     // 4 x h_set_bytes
     size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0;
     uint8_t *d_lk_table[2] = {nullptr, nullptr}, *d_rs_table[2] = {nullptr, nullptr}, *d_gf_table = nullptr, *d_tail_table[2] = {nullptr, nullptr};
+    uint8_t* d_tail_in[2] = {nullptr, nullptr};     // per frame of a batch: what the selection leaves for the tail
     ImgPair* d_pairs = nullptr;
     hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
     bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
@@ -460,6 +464,7 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     const size_t o_lkt[2] = {take(lk_item_bytes() * B), take(lk_item_bytes() * B)};
     const size_t o_rst[2] = {take(ransac_item_bytes() * B), take(ransac_item_bytes() * B)};
     const size_t o_tail[2] = {take(tail_item_bytes() * B), take(tail_item_bytes() * B)};
+    const size_t o_tin[2] = {take(tail_in_bytes() * B), take(tail_in_bytes() * B)};
     const size_t o_pairs = take(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
     size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
     size_t o_MinvB[2] = {take((size_t)BATCH_MAX * 96), take((size_t)BATCH_MAX * 96)};
@@ -491,7 +496,7 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     s->d_status = s->items[0].status; s->d_inliers = s->items[0].inliers;
     s->d_m = s->items[0].m; s->d_info = s->items[0].info; s->d_counts = s->items[0].counts; s->d_model = s->items[0].model;
     s->d_gf_table = b + o_gft;
-    for (int i = 0; i < 2; i++) { s->d_lk_table[i] = b + o_lkt[i]; s->d_rs_table[i] = b + o_rst[i]; s->d_tail_table[i] = b + o_tail[i]; }
+    for (int i = 0; i < 2; i++) { s->d_lk_table[i] = b + o_lkt[i]; s->d_rs_table[i] = b + o_rst[i]; s->d_tail_table[i] = b + o_tail[i]; s->d_tail_in[i] = b + o_tin[i]; }
     s->d_pairs = (ImgPair*)(b + o_pairs);
     {
         size_t ho = 0;
@@ -1003,6 +1008,7 @@ int run_batch(vs_stab* s) {
         S_TRY(s, ransac_fill_item(h_rs + ransac_item_bytes() * i, s->d_pts[b.lk_buf], it.next, it.status, cap,
                                   s->d_npts[b.lk_buf], it.vp, it.vc, it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab,
                                   it.counts, it.model, it.inliers, it.info, s->d_traj, &s->tp, s->d_dbg, b.have_prev_gray));
+        ransac_item_set_tail_in(h_rs + ransac_item_bytes() * i, s->d_tail_in[dset] + tail_in_bytes() * i);
     }
     // the tail's table as well (which outputs become due and where their maps go is known on the host)
     S_TRY(s, flush_warps(s));                      // the list of pending warps starts empty
@@ -1145,7 +1151,7 @@ int run_batch(vs_stab* s) {
         }
         {
             StageScope t(s, VS_STAGE_TRAJ, st);
-            S_TRY(s, launch_ransac_tail_batch(s->d_rs_table[dset], s->d_tail_table[dset], n, s->d_M, p.smoothing_method, st));
+            S_TRY(s, launch_ransac_tail_batch(s->d_rs_table[dset], s->d_tail_table[dset], s->d_tail_in[dset], s->d_traj, s->d_dbg, n, s->d_M, p.smoothing_method, st));
         }
         // the keypoint and pyramid buffers of this batch may be recycled (two batches on) once the tail, which still reads
         // the points and their counts, has run
@@ -1810,6 +1816,7 @@ struct vs_batch {
     size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0, ho_seg = 0;
     uint8_t* d_all = nullptr;
     uint8_t *d_lk[2] = {nullptr, nullptr}, *d_rs[2] = {nullptr, nullptr}, *d_tail[2] = {nullptr, nullptr}, *d_seg[2] = {nullptr, nullptr}, *d_gf = nullptr;
+    uint8_t* d_tin[2] = {nullptr, nullptr};
     ImgPair* d_pairs = nullptr;
     double* d_MinvB[2] = {nullptr, nullptr};
     int32_t* d_tabs[4] = {nullptr, nullptr, nullptr, nullptr};     // [set] frame plane, [2 + set] chroma plane
@@ -1863,6 +1870,7 @@ int group_allocate(vs_batch* g) {
     const size_t o_rs[2] = {take(ransac_item_bytes() * cap), take(ransac_item_bytes() * cap)};
     const size_t o_tl[2] = {take(tail_item_bytes() * cap), take(tail_item_bytes() * cap)};
     const size_t o_sg[2] = {take(tail_seg_bytes() * g->S), take(tail_seg_bytes() * g->S)};
+    const size_t o_ti[2] = {take(tail_in_bytes() * cap), take(tail_in_bytes() * cap)};
     const size_t o_pairs = take(sizeof(ImgPair) * cap * (2 + 2 * MAX_PYR));
     const size_t o_minv[2] = {take((size_t)cap * 96), take((size_t)cap * 96)};
     const size_t tab_bytes = warp_tabs_ints(s0->w, s0->h, cap) * sizeof(int32_t);
@@ -1873,7 +1881,7 @@ int group_allocate(vs_batch* g) {
     uint8_t* b = g->d_all;
     g->d_gf = b + o_gf;
     for (int i = 0; i < 2; i++) {
-        g->d_lk[i] = b + o_lk[i]; g->d_rs[i] = b + o_rs[i]; g->d_tail[i] = b + o_tl[i]; g->d_seg[i] = b + o_sg[i];
+        g->d_lk[i] = b + o_lk[i]; g->d_rs[i] = b + o_rs[i]; g->d_tail[i] = b + o_tl[i]; g->d_seg[i] = b + o_sg[i]; g->d_tin[i] = b + o_ti[i];
         g->d_MinvB[i] = (double*)(b + o_minv[i]);
     }
     g->d_pairs = (ImgPair*)(b + o_pairs);
@@ -1994,6 +2002,7 @@ int group_run(vs_batch* g) {
                                       it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab, it.counts, it.model, it.inliers, it.info, s->d_traj,
                                       &s->tp, s->d_dbg, b.have_prev_gray));
             ransac_item_set_last(h_rs + ransac_item_bytes() * idx, i == ns - 1 ? 1 : 0);
+            ransac_item_set_tail_in(h_rs + ransac_item_bytes() * idx, g->d_tin[dset] + tail_in_bytes() * idx);
             double* minv = nullptr;
             if (b.out_due) {
                 if (npend > 0 && pend_stride != b.out_stride) return gfail(g, VS_ERR_INVALID_ARG, "vs_batch: one output pitch per step");
@@ -2005,7 +2014,7 @@ int group_run(vs_batch* g) {
             tail_fill_item(h_tail + tail_item_bytes() * idx, b.out_due ? 1 : 0, b.out_idx, minv);
             tail_item_set_seg(h_tail + tail_item_bytes() * idx, nseg);
         }
-        tail_fill_seg(h_seg + tail_seg_bytes() * nseg, first, ns, s->d_M);
+        tail_fill_seg(h_seg + tail_seg_bytes() * nseg, first, ns, s->d_M, s->d_traj, s->d_dbg);
         nseg++;
         if (s->bq[0].prev_small) {   // Stabilizer.cpp:598-603 (once per stream: 480x270 -> analysis size)
             G_TRY(g, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[s->bq[0].pv].img[0], s->aw, s->aw, s->ah, g->st_pre));
@@ -2102,7 +2111,7 @@ int group_run(vs_batch* g) {
     }
     {
         StageScope t(g->m[0], VS_STAGE_TRAJ, st);
-        G_TRY(g, launch_ransac_tail_group(g->d_rs[dset], g->d_tail[dset], g->d_seg[dset], nseg, max_n, n, p.smoothing_method, st));
+        G_TRY(g, launch_ransac_tail_group(g->d_rs[dset], g->d_tail[dset], g->d_seg[dset], g->d_tin[dset], nseg, max_n, n, p.smoothing_method, st));
     }
     G_HIP(g, hipEventRecord(g->ev_blk[k % 4], st));
     R.n = npend; R.set = set; R.stride = pend_stride; R.valid = npend > 0; R.tabs_built = false;
