@@ -1,20 +1,10 @@
 #!/bin/bash
-# same-box A/B of an environment switch: scratch/ab_env.sh VAR [rounds]   (bench lines -> gpurun_out/ab_<VAR>.txt)
-VAR=$1; N=${2:-3}
-out=gpurun_out/ab_$VAR.txt; : > $out
-for i in $(seq $N); do
-  echo "default" >> $out
-  python bench.py --no-cpu-baseline --no-extras >> $out 2>&1 || exit 1
-  echo "$VAR=1" >> $out
-  env $VAR=1 python bench.py --no-cpu-baseline --no-extras >> $out 2>&1 || exit 1
-done
-python - "$out" <<'PY'
-import json, sys
-tag = None
-for line in open(sys.argv[1]):
-    line = line.strip()
-    if line.startswith('{'):
-        d = json.loads(line)
-        print(tag, d['value'], d['roofline']['frac'])
-    elif line: tag = line
-PY
+# ab_env.sh <outdir> <VAR> : bench.py --no-extras with and without a lab switch, alternating (same box)
+export VS_LAB=1
+OUT=$1; V=$2; mkdir -p $OUT
+for rep in 1 2 3; do for on in 0 1; do
+  if [ $on = 1 ]; then export $V=1; else unset $V; fi
+  python3 bench.py --no-extras --no-cpu-baseline > $OUT/${V}_${on}_$rep.json 2>> $OUT/err.log
+  python3 -c "
+import json; d=json.load(open('$OUT/${V}_${on}_$rep.json')); print('$V=%d rep $rep: %.0f f/s  %.4f ms/step  warp %.1f us frac %.4f' % ($on, d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['frac']))"
+done; done

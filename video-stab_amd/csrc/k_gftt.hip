@@ -508,17 +508,18 @@ int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w,
 // block_size: the block size every item of the table was filled with
 // what: 0 = the whole detection; or its pieces, in this order: 1 = the reset of the counters (it does not read the images:
 // the caller may issue it before the stream waits for them); 2 = min-eigenvalue map and non-maximum suppression (the wide
-// launches); 3 = the selection (one workgroup per image: it hardly occupies the GPU)
+// launches; 4 and 5 = the two apart); 3 = the selection (one workgroup per image: it hardly occupies the GPU)
 int launch_gftt_batch(const void* d_table, int items, int w, int h, int block_size, hipStream_t st, int what) {
-    if (!d_table || items < 1 || items > 65535 || w < 3 || h < 3 || block_size < 1 || block_size > MAX_BS || what < 0 || what > 3) { set_last_error("gftt_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
+    if (!d_table || items < 1 || items > 65535 || w < 3 || h < 3 || block_size < 1 || block_size > MAX_BS || what < 0 || what > 5) { set_last_error("gftt_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
     const GfttItem* t = static_cast<const GfttItem*>(d_table);
     if (what == 0 || what == 1) hipLaunchKernelGGL(gftt_zero_batch_kernel, dim3(items), dim3(64), 0, st, t);
-    if (what == 0 || what == 2) {
+    if (what == 0 || what == 2 || what == 4) {
         const dim3 eg((w + TW - 1) / TW, (h + TH - 1) / TH, items);
         if (block_size == 3) hipLaunchKernelGGL(min_eigen_batch_kernel<3>, eg, dim3(NT), 0, st, t);
         else hipLaunchKernelGGL(min_eigen_batch_kernel<0>, eg, dim3(NT), 0, st, t);
-        hipLaunchKernelGGL(nms_batch_kernel, dim3((w + NT - 1) / NT, (h + NMS_ROWS - 1) / NMS_ROWS, items), dim3(NT), 0, st, t);
     }
+    if (what == 0 || what == 2 || what == 5)
+        hipLaunchKernelGGL(nms_batch_kernel, dim3((w + NT - 1) / NT, (h + NMS_ROWS - 1) / NMS_ROWS, items), dim3(NT), 0, st, t);
     if (what == 0 || what == 3) hipLaunchKernelGGL(select_batch_kernel, dim3(items), dim3(SEL_NT), 0, st, t);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;

@@ -1648,8 +1648,8 @@ bool bad_args(const void* d_src, const void* d_dst, const void* M, size_t sstrid
 
 // Table scratch of the standalone operator (vs_op_warp_affine): one grow-only device buffer per stream.  Launches on
 // a stream run in order, so the tables of a call are consumed before the next call on that stream rewrites them.
-// (hipMallocAsync memory is not used: on this platform a kernel read zeros from a re-issued pool block that the kernel
-// before it, on the same stream, had written - measured with a host synchronisation between the two.)
+// (hipMallocAsync memory is not used: with it, in-flight builds of round 2 read zeroed tables for the later frames of a launch
+// and faulted on the null source pointers; the cause was not established - DESIGN.md section 8 has the evidence.)
 struct OpScratch { int32_t* p = nullptr; size_t bytes = 0; };
 std::mutex g_op_mutex;
 std::map<std::pair<int, hipStream_t>, OpScratch> g_op_scratch;

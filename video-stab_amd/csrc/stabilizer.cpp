@@ -1109,7 +1109,12 @@ int run_batch(vs_stab* s) {
         S_HIP(s, hipStreamWaitEvent(s->st_det, lab_env("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
         {
             StageScope t(s, VS_STAGE_GFTT, s->st_det);
-            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 2));   // :740-744: block size 3
+            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 4));   // :740-744: block size 3
+            // (VS_STAB_NMS_AFTER_TAIL=1: the NMS launch waits for the ordered tail of the batch before this one - one workgroup
+            // whose chain takes 10 - 25 us alone and 85 us beside this launch.  Measured, three alternating pairs on one box:
+            // 99.5 k frames/s with the wait against 101.4 k without - the warps then start under the corner selection.)
+            if (k >= 1 && lab_env("VS_STAB_NMS_AFTER_TAIL") != nullptr) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 1) % 4], 0));
+            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 5));
             // the wide launches of the detection are through: the warps of the batch before may go (below); the selection -
             // one workgroup per image - runs beside them
             S_HIP(s, hipEventRecord(s->ev_bnms, s->st_det));
@@ -2076,7 +2081,8 @@ int group_run(vs_batch* g) {
         G_HIP(g, hipStreamWaitEvent(sd, g->ev_bgray, 0));
         {
             StageScope t(g->m[0], VS_STAGE_GFTT, sd);
-            G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 2));
+            G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 4));
+            G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 5));
             G_HIP(g, hipEventRecord(g->ev_bnms, sd));
             G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 3));
         }
