@@ -131,11 +131,14 @@ namespace vs {
             /// first.  One more call of latency, the same frames.  (The environment variable VS_STAB_HOST_PIPELINE=1 does the
             /// same for an application that cannot be rebuilt.)
             bool hostPipeline = false;
-            /// Page-lock the host memory frames travel through: the returned frames come from a small ring of page-locked
-            /// cv::Mat buffers that are reused once the caller has let go of them (no allocation, no first-touch page faults,
-            /// DMA straight into them), and an input buffer that keeps coming back (the Mat a capture loop reads into) is
-            /// registered with the driver after its second appearance.  false: plain cv::Mat allocations, pageable transfers.
+            /// The returned frames come from a small ring of page-locked cv::Mat buffers that are reused once the caller has let
+            /// go of them (no allocation, no first-touch page faults, DMA straight into them).  false: a new cv::Mat per call.
             bool pinHostFrames = true;
+            /// An INPUT buffer that keeps coming back (the Mat a capture loop reads into) is registered with the driver from
+            /// its second appearance on, so that its upload is a DMA transfer of its own.  Off by default because the buffer is
+            /// the application's: it must not be freed while it is registered - i.e. before clean(), the destruction of the
+            /// Stabilizer, or 64 calls that did not use it.
+            bool pinInputFrames = false;
         };
 
         explicit Stabilizer(const Parameters &params);

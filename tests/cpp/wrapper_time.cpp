@@ -1,6 +1,7 @@
 // wrapper_time [device]: frames/s of vs::Stabilizer::stabilize(cv::Mat) at 1920x1080 measured THROUGH THE C++ CLASS, the way an
 // application drives it (examples/file-capture.cpp:58-64: one capture Mat that every read fills, one stabilize() per frame):
-//   default           Parameters as constructed (synchronous call; page-locked frame ring and input registration on)
+//   default           Parameters as constructed (synchronous call; results from the page-locked frame ring)
+//   pin_input         Parameters::pinInputFrames = true as well (the capture buffers are registered)
 //   host_pipeline     Parameters::hostPipeline = true
 //   unpinned          Parameters::pinHostFrames = false (plain cv::Mat allocations: round 2's behaviour)
 //   keeps_results     default, but the application keeps every result alive for 8 frames (the ring cannot recycle)
@@ -73,8 +74,15 @@ int main(int argc, char **argv) {
     r.pinHostFrames = false;
     const double unpinned = run(r, cap, warm, timed, 0);
     const double keeps = run(p, cap, warm, timed, 8);
+    vs::Stabilizer::Parameters pi = p;
+    pi.pinInputFrames = true;
+    const double sync_pi = run(pi, cap, warm, timed, 0);
+    vs::Stabilizer::Parameters qi = q;
+    qi.pinInputFrames = true;
+    const double piped_pi = run(qi, cap, warm, timed, 0);
     std::printf("{\"what\": \"vs::Stabilizer::stabilize(cv::Mat) at %dx%d through the C++ class, %d timed calls, default Parameters\", "
                 "\"default_synchronous\": %.1f, \"host_pipeline\": %.1f, \"unpinned_synchronous\": %.1f, \"default_caller_keeps_8_results\": %.1f, "
-                "\"unit\": \"frames/s\"}\n", W, H, timed, sync, piped, unpinned, keeps);
+                "\"pin_input_synchronous\": %.1f, \"pin_input_host_pipeline\": %.1f, \"unit\": \"frames/s\"}\n", W, H, timed, sync, piped, unpinned, keeps,
+                sync_pi, piped_pi);
     return 0;
 }

@@ -110,12 +110,12 @@ cv::Mat Stabilizer::outputFrame(int rows, int cols) {
     return cv::Mat(rows, cols, CV_8UC3);
 }
 
-// The frame buffer a capture loop reads into comes back call after call: from its second appearance on it is registered
-// (page-locked in place), so its upload is a DMA transfer of its own instead of a staged copy.  At most four buffers; one that
-// has not been seen for 64 calls is let go.  (A buffer the application frees while it is registered stays valid for the
-// driver until it is unregistered here; the pages go back to the system then.)
+// Parameters::pinInputFrames: the frame buffer a capture loop reads into comes back call after call; from its second
+// appearance on it is registered (page-locked in place), so its upload is a DMA transfer of its own instead of a staged copy.
+// At most four buffers; one that has not been seen for 64 calls is let go.  The buffer is the application's - it must stay
+// allocated while it is registered -, which is why this is opt-in.
 void Stabilizer::noteInput(const cv::Mat &frame) {
-    if (!params_.pinHostFrames) return;
+    if (!params_.pinInputFrames) return;
     const size_t bytes = (size_t)frame.step * (size_t)frame.rows;
     InPin *hit = nullptr, *spare = nullptr;
     for (InPin &e : inPins_) {
