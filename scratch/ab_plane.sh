@@ -1,8 +1,8 @@
 #!/bin/bash
 export VS_LAB=1    # the library reads its measurement switches only then
-# ab_plane.sh <outdir>: bench.py --workload configs2 with the first and the second plane kernel, alternating (same box)
+# ab_plane.sh <outdir>: bench.py --workload configs2 with the plane kernel (1) and the general table kernel (0), alternating (same box)
 OUT=$1; mkdir -p $OUT
-for rep in 1 2; do for v in 1 3; do
+for rep in 1 2; do for v in 1 0; do
   VS_WARP_PLANE_KERNEL=$v python3 bench.py --workload configs2 > $OUT/c2_plane${v}_$rep.json 2>> $OUT/err.log
   python3 - <<PY
 import json

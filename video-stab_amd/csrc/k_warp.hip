@@ -776,7 +776,9 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
     pf.tv0 = 0; pf.tv1 = 0;
     load_terms(k, cur, tid, pf.tv0, pf.tv1);
     const TileBox cb = tile_box(k.c, cur);
-    if (cb.pre) {
+    if (cb.pre && (flags & 0x200u)) {            // (lab, VS_WARP_LAB_SKIP: 1 no staging loads, 2 no blending - timing only)
+        store_terms(s_tab, tid, pf.tv0, pf.tv1, cb.bx0a << 10, cb.by0 << 10);
+    } else if (cb.pre) {
         issue_tile(k, cur, cb, tid, pf);
         store_tile(k, cur, cb, tid, pf, tile, s_tab);
     } else {
@@ -798,6 +800,14 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
         store_terms(s_tab, tid, tv0, tv1, cb.fast ? cb.bx0a << 10 : 0, cb.fast ? cb.by0 << 10 : 0);
     }
     __syncthreads();
+    if (flags & 0x400u) {                        // (lab: the stores alone)
+        if (cur.x1 - cur.x0 == TW - 1 && cur.y1 - cur.y0 == TH - 1)
+            for (int r = 0; r < TH / TYN; r++) {
+                U3 v; v.a = (uint32_t)s_tab[tid & 127]; v.b = v.a; v.c = v.a;
+                store_nt3(cur.dst + (size_t)(cur.y0 + (tid >> 5) + TYN * r) * k.c.dstride + (size_t)cur.x0 * 3 + 12u * (tid & 31), v);
+            }
+        return;
+    }
     if (cb.fast) emit_fast(k.c, cur.dst, tile, obuf, lut, s_tab, s_tab + TW, s_tab + 2 * TW, s_tab + 2 * TW + TH, cur.x0, cur.y0, cur.x1, cur.y1, 0, tid);
     else if (cb.use_lds) emit_rows<3, true>(k.c, cur.src, cur.dst, tile, s_tab, s_tab + TW, s_tab + 2 * TW, s_tab + 2 * TW + TH, cur.x0, cur.y0, cur.x1,
                                             cur.y1, cb.bx0a, cb.by0, cb.bw, tid);
@@ -1028,505 +1038,6 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
     }
 }
 
-// ---- the plane kernel, second form: two staged copies of the source box ------------------------------------------------
-// Counters of the kernel above at 3840 x 2160 (profiles/r03_b_configs2_pmc.txt): 767 vector instructions per wave = 24 per Y
-// pixel, the vector unit busy for the whole run, LDS half idle, HBM side at 1.00 x the algorithmic bytes: bound by instruction
-// issue.  A third of a pixel's instructions only serve to get at its two horizontal taps, which sit at an arbitrary BYTE
-// address of the staged row (8-byte read at the aligned address below, shift amount, two v_alignbyte).  Here the box is
-// staged twice - plane E as it is, plane O shifted left by one pixel - so that the tap pair of ANY source column is an
-// aligned 2-byte (Y) or 4-byte (UV) unit of one of the two: one ds_read_u16 / ds_read_b32 per tap row whose zero-extended
-// result goes straight into v_dot4, the plane picked by one multiply-add on the column's low bit.  LDS per workgroup doubles
-// (20.2 / 21.9 KB: 7 / 6 workgroups per CU instead of 8), which a kernel bound by issue does not notice.  The interleaved UV
-// plane gives a lane two PAIRS of neighbouring pixels (2L, 2L+1, 2L+64, 2L+65) instead of four in a row, so that the 32 lanes
-// of a tap read touch 32 different banks (four in a row: every read a two-way conflict) and still store 4 bytes at a time.
-// (the compiler turns a multiply by a 0/1 value into compare + select + add: three instructions for one)
-__device__ __forceinline__ int mad_u24_asm(uint32_t a, uint32_t k, int c) {
-    int r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(k), "v"(c));
-    return r;
-}
-
-template <int CN> struct Plane2Cfg {
-    static constexpr int THP = 64 / CN;                  // rows of a tile
-    static constexpr int PBP = 144 * CN;                 // bytes of a staged row in one plane (136 pixels + slack)
-    static constexpr int CPR = PBP / 16;                 // 16-byte chunks per staged row
-    static constexpr int ROWS = CN == 1 ? 70 : 38;       // staged rows (rotations up to ~1.8 / ~2 degrees; larger ones take the direct path)
-    static constexpr int POFF = ROWS * PBP;              // where plane O starts
-};
-
-template <int CN>
-__global__ __launch_bounds__(NT, CN == 1 ? 7 : 6) void warp_plane2_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride,
-                                                                          uint32_t dstride, uint32_t swh, uint32_t dwh, uint32_t flags, uint32_t mgx,
-                                                                          uint32_t mgy) {
-    typedef Plane2Cfg<CN> P;
-    __shared__ __attribute__((aligned(16))) uint8_t tile[2 * P::POFF];
-    __shared__ __attribute__((aligned(16))) int s_tab[2 * TW + 2 * P::THP];           // ad[128] bd[128] x0[THP] y0[THP]
-    __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
-    typedef const __attribute__((address_space(4))) int32_t* cptr;
-    typedef __attribute__((address_space(1))) uint8_t* gptr;
-    const int tid = threadIdx.x;
-    WarpCore c;
-    c.sstride = sstride; c.dstride = dstride;
-    c.sw = swh & 0xFFFFu; c.sh = swh >> 16; c.dw = dwh & 0xFFFFu; c.dh = dwh >> 16;
-    c.src_aligned = flags & 1u; c.dst_aligned = (flags >> 1) & 1u; c.border = (flags >> 2) & 7u;
-    const TileId tq = tile_id(flags, (uint32_t)(c.dw + TW - 1) / TW, (uint32_t)(c.dh + P::THP - 1) / P::THP, mgx, mgy);
-    const int x0 = tq.x * TW, y0 = tq.y * P::THP;
-    const int x1 = min(x0 + TW, c.dw) - 1, y1 = min(y0 + P::THP, c.dh) - 1;
-    const uint8_t* src;
-    uint8_t* dst;
-    int ad0, ad1, bd0, bd1, Xa, Xb, Ya, Yb;
-    {
-        cptr Ts = (cptr)(const int32_t*)(tabs + (size_t)tq.z * tab_stride);
-        typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
-        typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-        const i32x8 cc = *(const __attribute__((address_space(4))) i32x8*)(Ts + TAB_COL * tq.x);
-        const i32x4 r0 = *(const __attribute__((address_space(4))) i32x4*)(Ts + tab_row + 4 * (y0 / TH));
-        const i32x4 r1 = *(const __attribute__((address_space(4))) i32x4*)(Ts + tab_row + 4 * (y1 / TH));
-        src = (const uint8_t*)(gptr)((unsigned long long)(uint32_t)cc[0] | (unsigned long long)(uint32_t)cc[1] << 32);
-        dst = (uint8_t*)(gptr)((unsigned long long)(uint32_t)cc[2] | (unsigned long long)(uint32_t)cc[3] << 32);
-        ad0 = cc[4]; ad1 = cc[5]; bd0 = cc[6]; bd1 = cc[7];
-        Xa = r0[0]; Ya = r0[2]; Xb = r1[1]; Yb = r1[3];
-    }
-    if (tid >= NT - 32) {      // vertical weights (the table of the BGR kernel: only W0 / W1 are read here)
-        const uint32_t f = tid - (NT - 32);
-        const uint32_t wlo = (32u - f) | (f << 8);
-        *reinterpret_cast<uint4*>(lut + f * LUT_STRIDE) =
-            make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
-        *reinterpret_cast<uint32_t*>(lut + f * LUT_STRIDE + 16) = (32u - f) | (f << 16);
-    }
-    int tv0 = 0, tv1 = 0;
-    {
-        gtab_t Tg = tabs + (size_t)tq.z * tab_stride + tab_ad;
-        if (tid < TW) {
-            const int cx = min(x0 + tid, x1);
-            tv0 = Tg[cx]; tv1 = Tg[c.dw + cx];
-        } else if (tid < TW + P::THP) {
-            const int r = min(y0 + (tid - TW), y1);
-            tv0 = Tg[2 * c.dw + r]; tv1 = Tg[2 * c.dw + c.dh + r];
-        }
-    }
-    int bx0a, by0, bw, bh;
-    bool fit;
-    {
-        const int sx00 = (Xa + ad0) >> 10, sx01 = (Xa + ad1) >> 10, sx10 = (Xb + ad0) >> 10, sx11 = (Xb + ad1) >> 10;
-        const int sy00 = (Ya + bd0) >> 10, sy01 = (Ya + bd1) >> 10, sy10 = (Yb + bd0) >> 10, sy11 = (Yb + bd1) >> 10;
-        const int rx0 = min(min(sx00, sx01), min(sx10, sx11)), rx1 = max(max(sx00, sx01), max(sx10, sx11));
-        const int ry0 = min(min(sy00, sy01), min(sy10, sy11)), ry1 = max(max(sy00, sy01), max(sy10, sy11));
-        const bool saturated = rx0 < -32768 || ry0 < -32768 || rx1 > 32767 || ry1 > 32767;
-        const int bx0 = max(rx0, -32768), bx1 = min(rx1, 32767) + 1;
-        by0 = max(ry0, -32768);
-        const int by1 = min(ry1, 32767) + 1;
-        bx0a = bx0 & ~3;
-        bw = bx1 - bx0a + 1;
-        bh = by1 - by0 + 1;
-        fit = !saturated && bw <= 136 && bh <= P::ROWS && c.border == VS_BORDER_BLACK;
-    }
-    if (fit && !(flags & 0x200u)) {      // (0x200 / 0x400: lab switches - no staging / no blending - that time the two halves of the kernel apart)
-        // ---- staging: chunks of 16 bytes, (row, chunk) = (i / CPR, i % CPR), and the four bytes behind each (the shifted copy
-        // needs the chunk's right neighbour); all loads of a lane first, then its stores
-        constexpr int NCH = (P::ROWS * P::CPR + NT - 1) / NT;
-        const int total = bh * P::CPR;
-        const int rowbytes = c.sw * CN;
-        uint4 d[NCH];
-        uint32_t nx[NCH];
-#pragma unroll
-        for (int k = 0; k < NCH; k++) {
-            const int i = tid + NT * k;
-            d[k] = make_uint4(0u, 0u, 0u, 0u);
-            nx[k] = 0u;
-            if (i < total) {
-                const int r = i / P::CPR, ch = i - r * P::CPR;
-                const int y = by0 + r;
-                const int xb = bx0a * CN + 16 * ch;                               // byte column of the chunk in the source row
-                if ((unsigned)y < (unsigned)c.sh) {
-                    const uint8_t* row = src + (size_t)y * c.sstride;
-                    if (xb >= 0 && xb + 20 <= rowbytes && c.src_aligned) {
-                        d[k] = *reinterpret_cast<const uint4*>(row + xb);         // 4-byte aligned: bx0a is a multiple of 4 pixels
-                        nx[k] = *reinterpret_cast<const uint32_t*>(row + xb + 16);
-                    } else if (xb + 20 > 0 && xb < rowbytes) {
-                        uint32_t w[5] = {0u, 0u, 0u, 0u, 0u};
-#pragma unroll
-                        for (int b = 0; b < 20; b++) {          // (unrolled: w[] stays in registers)
-                            const int xx = xb + b;
-                            if (xx >= 0 && xx < rowbytes) w[b >> 2] |= (uint32_t)row[xx] << (8 * (b & 3));
-                        }
-                        d[k] = make_uint4(w[0], w[1], w[2], w[3]);
-                        nx[k] = w[4];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NCH; k++) {
-            const int i = tid + NT * k;
-            if (i < total) {
-                *reinterpret_cast<uint4*>(tile + 16 * i) = d[k];                  // row * PBP + 16 * chunk = 16 * i
-                *reinterpret_cast<uint4*>(tile + P::POFF + 16 * i) =
-                    make_uint4(__builtin_amdgcn_alignbyte(d[k].y, d[k].x, CN), __builtin_amdgcn_alignbyte(d[k].z, d[k].y, CN),
-                               __builtin_amdgcn_alignbyte(d[k].w, d[k].z, CN), __builtin_amdgcn_alignbyte(nx[k], d[k].w, CN));
-            }
-        }
-    }
-    {
-        const int subx = fit ? bx0a << 10 : 0, suby = fit ? by0 << 10 : 0;
-        if (tid < TW) { s_tab[tid] = tv0; s_tab[TW + tid] = tv1; }
-        else if (tid < TW + P::THP) { s_tab[2 * TW + (tid - TW)] = tv0 - subx; s_tab[2 * TW + P::THP + (tid - TW)] = tv1 - suby; }
-    }
-    __syncthreads();
-    const int* s_ad = s_tab;
-    const int* s_bd = s_tab + TW;
-    const int* s_x0 = s_tab + 2 * TW;
-    const int* s_y0 = s_tab + 2 * TW + P::THP;
-    if (!fit) {
-        for (int j = 0; y0 + TH * j <= y1; j++)
-            emit_rows<CN, false>(c, src, dst, nullptr, s_ad, s_bd, s_x0 + TH * j, s_y0 + TH * j, x0, y0 + TH * j, x1, min(y0 + TH * j + TH - 1, y1),
-                                 bx0a, by0, bw, tid);
-        return;
-    }
-    // ---- output
-    const int L = tid & 31, ty = tid >> 5;
-    int ad[4], bd[4];
-    int xl[2];                       // the lane's first pixel of each 4-byte store, relative to the tile
-    if (CN == 1) {
-        const int4 a4 = *reinterpret_cast<const int4*>(s_ad + 4 * L), b4 = *reinterpret_cast<const int4*>(s_bd + 4 * L);
-        ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
-        bd[0] = b4.x; bd[1] = b4.y; bd[2] = b4.z; bd[3] = b4.w;
-        xl[0] = 4 * L; xl[1] = 4 * L + 2;
-    } else {
-        const int2 a0 = *reinterpret_cast<const int2*>(s_ad + 2 * L), a1 = *reinterpret_cast<const int2*>(s_ad + 2 * L + 64);
-        const int2 b0 = *reinterpret_cast<const int2*>(s_bd + 2 * L), b1 = *reinterpret_cast<const int2*>(s_bd + 2 * L + 64);
-        ad[0] = a0.x; ad[1] = a0.y; ad[2] = a1.x; ad[3] = a1.y;
-        bd[0] = b0.x; bd[1] = b0.y; bd[2] = b1.x; bd[3] = b1.y;
-        xl[0] = 2 * L; xl[1] = 2 * L + 64;
-    }
-    const bool whole = c.dst_aligned && x1 - x0 == TW - 1;          // tile-uniform: every lane's stores are whole and aligned
-    uint8_t* const dtile = dst + (size_t)y0 * c.dstride + (size_t)x0 * CN;      // wave-uniform base, 32-bit lane offsets
-    const uint32_t dstride32 = c.dstride;
-    for (int r = 0; r < P::THP / TYN; r++) {
-        const int yl = ty + TYN * r;
-        const int X0 = s_x0[yl], Y0 = s_y0[yl];
-        uint32_t res[4];
-        if (flags & 0x400u) { res[0] = res[1] = res[2] = res[3] = (uint32_t)(X0 + ad[0]); }
-        else
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int SX = X0 + ad[i], SY = Y0 + bd[i];                  // 1/1024 px, relative to the staged box
-            const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
-            // horizontal weights from the table too ((32 - f) | f << 8 at +0, (32 - f) | f << 16 at +16): one AND and an LDS read that
-            // has room, instead of a bit-field extract and a multiply-add of the 4-cycle class
-            if (CN == 1) {
-                const int sxr = SX >> 10;
-                int a = __mul24(SY >> 10, P::PBP) + sxr;                  // byte of the upper-left tap in plane E
-                a = mad_u24_asm((uint32_t)sxr & 1u, (uint32_t)(P::POFF - 1), a);      // odd column: the same pair starts an aligned unit of plane O
-                const uint32_t top = *reinterpret_cast<const uint16_t*>(tile + a), bot = *reinterpret_cast<const uint16_t*>(tile + a + P::PBP);
-                const uint32_t wx = *reinterpret_cast<const uint32_t*>(lut + (SX & 0x3E0));
-                float m = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
-                asm("" : "+v"(m));                                        // (keeps the four pixels' float operations apart: packed f32 forms are no faster here and need moves)
-                res[i] = __float_as_uint(m);
-            } else {
-                const int sx2 = (SX >> 9) & ~1;                           // two bytes per pixel
-                int a = __mul24(SY >> 10, P::PBP) + sx2;
-                a = mad_u24_asm((uint32_t)sx2 & 2u, (uint32_t)(P::POFF - 2) / 2u, a);
-                const uint32_t top = *reinterpret_cast<const uint32_t*>(tile + a), bot = *reinterpret_cast<const uint32_t*>(tile + a + P::PBP);
-                const uint32_t wu = *reinterpret_cast<const uint32_t*>(lut + 16 + (SX & 0x3E0));   // (32 - fx) | fx << 16: against bytes 0 and 2 (U0, U1)
-                const uint32_t wv = wu << 8;                              // against bytes 1 and 3 (V0, V1)
-                float mu = vlerp(__builtin_amdgcn_udot4(top, wu, 0u, false), __builtin_amdgcn_udot4(bot, wu, 0u, false), wy);
-                float mv = vlerp(__builtin_amdgcn_udot4(top, wv, 0u, false), __builtin_amdgcn_udot4(bot, wv, 0u, false), wy);
-                asm("" : "+v"(mu), "+v"(mv));
-                res[i] = __builtin_amdgcn_perm(__float_as_uint(mv), __float_as_uint(mu), 0x0C0C0400u);     // (U, V, 0, 0)
-            }
-        }
-        const int y = y0 + yl;
-        if (y > y1) continue;
-        if (CN == 1) {
-            const uint32_t lo = __builtin_amdgcn_perm(res[1], res[0], 0x0C0C0400u), hi = __builtin_amdgcn_perm(res[3], res[2], 0x0C0C0400u);   // low bytes
-            const uint32_t v = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-            if (whole) {
-                __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(dtile + (__umul24((uint32_t)yl, dstride32) + 4u * L)));
-            } else {
-                uint8_t* dp = dtile + (size_t)yl * c.dstride + 4 * L;
-                for (int i = 0; i < 4; i++)
-                    if (x0 + 4 * L + i <= x1) dp[i] = (uint8_t)(v >> (8 * i));
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t v = res[2 * h] | (res[2 * h + 1] << 16);
-                if (whole) {
-                    __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(dtile + (__umul24((uint32_t)yl, dstride32) + 2u * (uint32_t)xl[h])));
-                } else {
-                    uint8_t* dp = dtile + (size_t)yl * c.dstride + 2 * xl[h];
-                    for (int i = 0; i < 2; i++)
-                        if (x0 + xl[h] + i <= x1) { dp[2 * i] = (uint8_t)(v >> (16 * i)); dp[2 * i + 1] = (uint8_t)(v >> (16 * i + 8)); }
-                }
-            }
-        }
-    }
-}
-
-// ---- the plane kernel, third form: persistent workgroups, the next tile's source box in flight while this one is blended ----
-// What the two kernels above are bound by (scratch/plane_skel.sh, Y plane of 32 4K frames = 531 MB read + written: a plain
-// store of its 265 MB takes 46 us, a copy about 95): with the blending switched off 127 us, with the staging loads switched
-// off 119, with BOTH off - prologue, terms, barrier, stores - still 79, all of it 156; a third fewer vector instructions per
-// pixel (second form) changed nothing.  A workgroup is a chain of dependent round trips - tile record (scalar loads) ->
-// source box (vector loads) -> barrier -> blend -> store acknowledgements -, a CU holds 7 - 8 of them, and most of their
-// waves wait for memory most of the time: 20 000 cycles of life for 4 000 of work.  Here a workgroup lives for the whole
-// launch (6 per CU) and walks a sequence of tiles; while it blends tile k from one staging buffer, the box of tile k+1 is on
-// its way into the other - as LDS-DMA loads (global_load_lds_dwordx4: no registers held, nothing for the compiler to wait on;
-// issued and awaited by hand) - and the terms of tile k+1 are already computed.  One barrier per tile.  No coordinate tables:
-// a tile's terms are evaluated where they are needed, in double, from the frame's inverse map (two multiply-adds per lane;
-// the eight corner terms of the box by every lane alike) - the warp_tables_kernel launch and its 24 KB per frame disappear.
-// Tiles go to workgroups XCD-wise (tile_id's order): workgroup w (XCD w mod 8) takes every (G/8)-th tile of its XCD's
-// contiguous eighth of the launch, so the workgroups of an XCD sweep that eighth together.
-template <int CN> struct Plane3Cfg {
-    static constexpr int THP = 64 / CN;                  // rows of a tile
-    static constexpr int PB = 144 * CN;                  // staged row pitch in bytes (136 pixels + slack for the 8-byte tap read)
-    static constexpr int CPR = PB / 16;                  // 16-byte chunks per staged row
-    static constexpr int ROWS = THP + 9;                 // staged rows (rotations up to ~3.5 degrees)
-    static constexpr int TILE_B = ROWS * PB;
-    static constexpr int NCH = (ROWS * CPR + NT - 1) / NT;
-    static constexpr int TERMS = 2 * TW + 2 * THP;       // ad[128] bd[128] x0[THP] y0[THP]
-};
-
-struct PlaneJob {              // one tile (wave-uniform)
-    const uint8_t* src;
-    uint8_t* dst;
-    int x0, y0, x1, y1;
-    int bx0a, by0, bw, bh;
-    int fit;
-};
-
-// 16 bytes per lane from global memory straight into LDS at (wave-uniform) lds_dst + 16 * lane.  Not counted by the compiler:
-// s_waitcnt vmcnt(0) by hand, then a barrier, before anybody reads the bytes.
-__device__ __forceinline__ void glds16(const uint8_t* gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-// Sixteen zero bytes in global memory: the source of the LDS-DMA loads of chunks that lie outside the frame (BORDER_CONSTANT).
-__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
-
-// Tiles of the persistent kernel whose source box does not fit the staging area (large rotations, zooms, saturated
-// coordinates): one pixel at a time from global memory with cv::warpAffine's general arithmetic - short code and few
-// registers, because it shares the tile loop with the fast path; rare.
-template <int CN>
-__device__ __forceinline__ void plane3_direct_tile(const WarpCore& c, const uint8_t* src, uint8_t* dst, const int* T, int x0, int y0, int x1, int y1,
-                                                   int tid) {
-    typedef Plane3Cfg<CN> P;
-    const int L = tid & 31, ty = tid >> 5;
-#pragma unroll 1
-    for (int r = 0; r < P::THP / TYN; r++) {
-        const int yl = ty + TYN * r, y = y0 + yl;
-        if (y > y1) continue;
-        const int X0 = T[2 * TW + yl], Y0 = T[2 * TW + P::THP + yl];
-#pragma unroll 1
-        for (int i = 0; i < 4; i++) {
-            const int x = x0 + 4 * L + i;
-            if (x > x1) break;
-            const int X = (X0 + T[4 * L + i]) >> 5, Y = (Y0 + T[TW + 4 * L + i]) >> 5;
-            const int sx = sat_s16(X >> 5), sy = sat_s16(Y >> 5);
-            const uint32_t v = blend<CN>(load_px_checked<CN>(src, c.sstride, c.sw, c.sh, sx, sy, c.border), load_px_checked<CN>(src, c.sstride, c.sw, c.sh, sx + 1, sy, c.border),
-                                         load_px_checked<CN>(src, c.sstride, c.sw, c.sh, sx, sy + 1, c.border),
-                                         load_px_checked<CN>(src, c.sstride, c.sw, c.sh, sx + 1, sy + 1, c.border), X & 31, Y & 31);
-            uint8_t* d = dst + (size_t)y * c.dstride + (size_t)x * CN;
-            d[0] = (uint8_t)v;
-            if (CN == 2) d[1] = (uint8_t)(v >> 8);
-        }
-    }
-}
-
-template <int CN>
-__global__ __launch_bounds__(NT, 6) void warp_plane3_kernel(WarpArgs a, uint32_t ntiles, uint32_t gx, uint32_t gy, uint32_t mgx, uint32_t mgy, uint32_t lab) {
-    typedef Plane3Cfg<CN> P;
-    __shared__ __attribute__((aligned(16))) uint8_t tile[2][P::TILE_B];
-    __shared__ __attribute__((aligned(16))) int terms[2][P::TERMS];
-    __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
-    const int tid = threadIdx.x;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WarpCore& c = a.c;
-    // this workgroup's tiles: seq = first, first + step, ... < end
-    uint32_t first, step, end;
-    {
-        const uint32_t W = gridDim.x, w = blockIdx.x, xc = w & 7u, j = w >> 3;
-        const uint32_t q = ntiles >> 3, r = ntiles & 7u;
-        const uint32_t start = xc * q + (xc < r ? xc : r);
-        end = start + q + (xc < r ? 1u : 0u);
-        first = start + j;
-        step = (W - xc + 7u) >> 3;           // workgroups on this XCD
-    }
-    if (tid >= NT - 32) {      // weights of the vertical lerp (the table of the BGR kernel)
-        const uint32_t f = tid - (NT - 32);
-        const uint32_t wlo = (32u - f) | (f << 8);
-        *reinterpret_cast<uint4*>(lut + f * LUT_STRIDE) =
-            make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
-    }
-    const int rowbytes = c.sw * CN;
-
-    // everything a tile needs before it can be blended: its job record, its terms in terms[b], its source box on its way
-    // into tile[b] (interior boxes: LDS-DMA; boxes that leave the frame: checked loads and LDS stores, waited for here)
-    auto prepare = [&](uint32_t seq, int b, PlaneJob& jb) {
-        const uint32_t row = gx == 1 ? seq : __umulhi(seq, mgx);
-        const int tx = (int)(seq - row * gx);
-        const int tz = (int)(gy == 1 ? row : __umulhi(row, mgy));
-        const int tyy = (int)(row - (uint32_t)tz * gy);
-        jb.src = a.use_list ? a.srcs[tz] : a.src + (size_t)tz * a.sframe;
-        jb.dst = a.use_list ? a.dsts[tz] : a.dst + (size_t)tz * a.dframe;
-        double m[6];
-        load_map(a, tz, m);
-        jb.x0 = tx * TW; jb.y0 = tyy * P::THP;
-        jb.x1 = min(jb.x0 + TW, c.dw) - 1; jb.y1 = min(jb.y0 + P::THP, c.dh) - 1;
-        // corner terms and the source box (the maps are monotone in x and in y separately)
-        const int ad0 = coord_term(m[0], 0.0, (double)jb.x0), ad1 = coord_term(m[0], 0.0, (double)jb.x1);
-        const int bd0 = coord_term(m[3], 0.0, (double)jb.x0), bd1 = coord_term(m[3], 0.0, (double)jb.x1);
-        const int Xa = coord_term(m[1], m[2], (double)jb.y0) + 16, Xb = coord_term(m[1], m[2], (double)jb.y1) + 16;
-        const int Ya = coord_term(m[4], m[5], (double)jb.y0) + 16, Yb = coord_term(m[4], m[5], (double)jb.y1) + 16;
-        const int sx00 = (Xa + ad0) >> 10, sx01 = (Xa + ad1) >> 10, sx10 = (Xb + ad0) >> 10, sx11 = (Xb + ad1) >> 10;
-        const int sy00 = (Ya + bd0) >> 10, sy01 = (Ya + bd1) >> 10, sy10 = (Yb + bd0) >> 10, sy11 = (Yb + bd1) >> 10;
-        const int rx0 = min(min(sx00, sx01), min(sx10, sx11)), rx1 = max(max(sx00, sx01), max(sx10, sx11));
-        const int ry0 = min(min(sy00, sy01), min(sy10, sy11)), ry1 = max(max(sy00, sy01), max(sy10, sy11));
-        const bool saturated = rx0 < -32768 || ry0 < -32768 || rx1 > 32767 || ry1 > 32767;
-        const int bx0 = max(rx0, -32768), bx1 = min(rx1, 32767) + 1;
-        const int by1 = min(ry1, 32767) + 1;
-        jb.by0 = __builtin_amdgcn_readfirstlane(max(ry0, -32768));
-        jb.bx0a = __builtin_amdgcn_readfirstlane(bx0 & ~3);
-        jb.bw = __builtin_amdgcn_readfirstlane(bx1 - (bx0 & ~3) + 1);
-        jb.bh = __builtin_amdgcn_readfirstlane(by1 - max(ry0, -32768) + 1);
-        jb.fit = __builtin_amdgcn_readfirstlane((!saturated && jb.bw <= 136 && jb.bh <= P::ROWS && c.border == VS_BORDER_BLACK) ? 1 : 0);
-        // this lane's share of the terms, relative to the staged box for the fast path
-        {
-            const int subx = jb.fit ? jb.bx0a << 10 : 0, suby = jb.fit ? jb.by0 << 10 : 0;
-            int* T = terms[b];
-            if (tid < TW) {
-                const double dv = (double)min(jb.x0 + tid, jb.x1);
-                T[tid] = coord_term(m[0], 0.0, dv);
-                T[TW + tid] = coord_term(m[3], 0.0, dv);
-            } else if (tid < TW + P::THP) {
-                const double dv = (double)min(jb.y0 + (tid - TW), jb.y1);
-                T[2 * TW + (tid - TW)] = coord_term(m[1], m[2], dv) + 16 - subx;
-                T[2 * TW + P::THP + (tid - TW)] = coord_term(m[4], m[5], dv) + 16 - suby;
-            }
-        }
-        if (!jb.fit || (lab & 1u)) return;          // (lab: timing switches, VS_WARP_LAB_SKIP - 1 no staging, 2 no blending)
-        // the box, 16-byte chunks (row, chunk) = (i / CPR, i % CPR) at tile[b] + 16 i: chunks inside the frame and chunks outside
-        // it (from the zero block) as LDS-DMA loads; the few that straddle its left or right edge byte by byte
-        const int total = jb.bh * P::CPR;
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(&tile[b][0]) + 1024u * wave;
-#pragma unroll
-        for (int k = 0; k < P::NCH; k++) {
-            const int i = tid + NT * k;
-            if (i < total) {
-                const int r = i / P::CPR, ch = i - r * P::CPR;
-                const int y = jb.by0 + r;
-                const int xb = jb.bx0a * CN + 16 * ch;
-                const bool row_in = (unsigned)y < (unsigned)c.sh;
-                const bool inside = row_in && xb >= 0 && xb + 16 <= rowbytes;
-                const bool outside = !row_in || xb + 16 <= 0 || xb >= rowbytes;
-                if ((inside && c.src_aligned) || outside) {
-                    const uint8_t* g = inside ? jb.src + ((size_t)(uint32_t)y * c.sstride + (uint32_t)xb) : reinterpret_cast<const uint8_t*>(&g_zero16);
-                    glds16(g, lds0 + 16u * NT * k);
-                } else {
-                    const uint8_t* rowp = jb.src + (size_t)(uint32_t)y * c.sstride;
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (int bb = 0; bb < 16; bb++) {
-                        const int xx = xb + bb;
-                        if (xx >= 0 && xx < rowbytes) w[bb >> 2] |= (uint32_t)rowp[xx] << (8 * (bb & 3));
-                    }
-                    *reinterpret_cast<uint4*>(&tile[b][16 * i]) = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            }
-        }
-    };
-
-    auto blend_tile = [&](const PlaneJob& jb, int b) {
-        const int* s_ad = terms[b];
-        const int* s_bd = terms[b] + TW;
-        const int* s_x0 = terms[b] + 2 * TW;
-        const int* s_y0 = terms[b] + 2 * TW + P::THP;
-        if (!jb.fit) {
-            plane3_direct_tile<CN>(c, jb.src, jb.dst, terms[b], jb.x0, jb.y0, jb.x1, jb.y1, tid);
-            return;
-        }
-        const uint8_t* tl = tile[b];
-        const int L = tid & 31, ty = tid >> 5;
-        int ad[4], bd[4];
-        {
-            const int4 a4 = *reinterpret_cast<const int4*>(s_ad + 4 * L), b4 = *reinterpret_cast<const int4*>(s_bd + 4 * L);
-            ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
-            bd[0] = b4.x; bd[1] = b4.y; bd[2] = b4.z; bd[3] = b4.w;
-        }
-        const bool whole = c.dst_aligned && jb.x1 - jb.x0 == TW - 1;
-        uint8_t* const dtile = jb.dst + (size_t)jb.y0 * c.dstride + (size_t)jb.x0 * CN;      // wave-uniform base, 32-bit lane offsets
-        const uint32_t dstride32 = (uint32_t)c.dstride;
-        for (int r = 0; r < P::THP / TYN; r++) {
-            const int yl = ty + TYN * r;
-            const int X0 = s_x0[yl], Y0 = s_y0[yl];
-            uint32_t res[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int SX = X0 + ad[i], SY = Y0 + bd[i];                  // 1/1024 px, relative to the staged box
-                const int addr = __mul24(SY >> 10, P::PB) + (SX >> 10) * CN;  // byte of the upper-left tap
-                const uint32_t sh = (uint32_t)addr & 3u;
-                // (dword reads: the address is a multiple of 4, not of 8 - an 8-byte LDS read off its alignment is some 20 x slower)
-                const uint32_t* tq = reinterpret_cast<const uint32_t*>(tl + (addr & ~3));
-                const uint32_t top = __builtin_amdgcn_alignbyte(tq[1], tq[0], sh), bot = __builtin_amdgcn_alignbyte(tq[P::PB / 4 + 1], tq[P::PB / 4], sh);
-                const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
-                if (CN == 1) {
-                    const uint32_t wx = *reinterpret_cast<const uint32_t*>(lut + (SX & 0x3E0));           // (32 - fx) | fx << 8
-                    float m = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
-                    asm("" : "+v"(m));
-                    res[i] = __float_as_uint(m);
-                } else {
-                    const uint32_t fx = ((uint32_t)SX >> 5) & 31u;
-                    const uint32_t wu = __umul24(fx, 65535u) + 32u;           // (32 - fx) | fx << 16: against bytes 0 and 2 (U0, U1)
-                    const uint32_t wv = wu << 8;                              // against bytes 1 and 3 (V0, V1)
-                    float mu = vlerp(__builtin_amdgcn_udot4(top, wu, 0u, false), __builtin_amdgcn_udot4(bot, wu, 0u, false), wy);
-                    float mv = vlerp(__builtin_amdgcn_udot4(top, wv, 0u, false), __builtin_amdgcn_udot4(bot, wv, 0u, false), wy);
-                    asm("" : "+v"(mu), "+v"(mv));
-                    res[i] = __builtin_amdgcn_perm(__float_as_uint(mv), __float_as_uint(mu), 0x0C0C0400u);     // (U, V, 0, 0)
-                }
-            }
-            const int y = jb.y0 + yl;
-            if (y > jb.y1) continue;
-            if (CN == 1) {
-                const uint32_t lo = __builtin_amdgcn_perm(res[1], res[0], 0x0C0C0400u), hi = __builtin_amdgcn_perm(res[3], res[2], 0x0C0C0400u);   // low bytes
-                const uint32_t v = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-                if (whole) {
-                    __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(dtile + (__umul24((uint32_t)yl, dstride32) + 4u * L)));
-                } else {
-                    uint8_t* dp = dtile + (size_t)yl * c.dstride + 4 * L;
-                    for (int i = 0; i < 4; i++)
-                        if (jb.x0 + 4 * L + i <= jb.x1) dp[i] = (uint8_t)(v >> (8 * i));
-                }
-            } else {
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 v = {res[0] | (res[1] << 16), res[2] | (res[3] << 16)};
-                if (whole) {
-                    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(dtile + (__umul24((uint32_t)yl, dstride32) + 8u * L)));
-                } else {
-                    uint8_t* dp = dtile + (size_t)yl * c.dstride + 8 * L;
-                    for (int i = 0; i < 4; i++)
-                        if (jb.x0 + 4 * L + i <= jb.x1) { dp[2 * i] = (uint8_t)(res[i]); dp[2 * i + 1] = (uint8_t)(res[i] >> 8); }
-                }
-            }
-        }
-    };
-
-    PlaneJob cur, nxt;
-    if (first < end) prepare(first, 0, nxt);
-    int b = 0;
-    for (uint32_t seq = first; seq < end; seq += step, b ^= 1) {
-        cur = nxt;
-        // this wave's LDS-DMA loads of tile `seq` have landed (and its stores of the tile before are through) ...
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and everybody's: the box and the terms of this tile are complete, nobody reads the other buffer any more
-        __syncthreads();
-        if (seq + step < end) prepare(seq + step, b ^ 1, nxt);
-        if (!(lab & 2u)) blend_tile(cur, b);
-    }
-}
-
 // Ints of table workspace per frame of dw x dh (see warp_tables_kernel).
 inline int tab_stride_of(int dw, int dh) { return tab_layout(dw, dh).stride; }
 
@@ -1536,9 +1047,9 @@ bool tab_kernel_setting() {
     return v;
 }
 
-// VS_WARP_PLANE_KERNEL=0: one- and two-channel launches with tables take the general kernel, 1: the first plane kernel (one staged
-// copy, 8-byte tap reads; the default), 2: warp_plane2_kernel (two staged copies), 3: warp_plane3_kernel (persistent) - the two
-// round-3 experiments, bit-identical and not faster
+// VS_WARP_PLANE_KERNEL=0 (lab): one- and two-channel launches with tables take the general kernel.  (Round 3 measured three more
+// forms of the plane kernel - 256 x 32 tiles, two staged copies, persistent with LDS-DMA staging: bit-identical, none faster;
+// scratch/k_warp_r3_plane_experiments.hip.txt)
 // VS_WARP_XCD_ORDER=0: plain (x, y, frame) tile order in the table kernels (A/B measurements)
 uint32_t xcd_order_flag() {
     static const uint32_t v = [] {
@@ -1549,20 +1060,8 @@ uint32_t xcd_order_flag() {
     return v;
 }
 
-// compute units of the current device (the persistent kernel's grid)
-int device_cus() {
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        int n = 0;
-        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return cus[dev];
-}
-
 int plane_kernel_setting() {
-    static const int v = [] { const char* e = lab_env("VS_WARP_PLANE_KERNEL"); return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : 1; }();
+    static const int v = [] { const char* e = lab_env("VS_WARP_PLANE_KERNEL"); return e && e[0] == '0' ? 0 : 1; }();
     return v;
 }
 
@@ -1573,18 +1072,6 @@ void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, int what, hipStream_t s
     a.tabs = d_tabs;
     const TabLayout tl = tab_layout(a.c.dw, a.c.dh);
     a.tab_stride = tl.stride; a.tab_row = tl.row; a.tab_ad = tl.ad;
-    if (d_tabs && CN != 3 && plane_kernel_setting() == 3 && a.c.border == VS_BORDER_BLACK && a.c.dw < 65536 && a.c.dh < 65536 &&
-        (unsigned long long)grid.x * ((a.c.dh + Plane3Cfg<CN == 3 ? 1 : CN>::THP - 1) / Plane3Cfg<CN == 3 ? 1 : CN>::THP) * grid.z < (1ull << 24)) {
-        // persistent plane kernel: no tables (a launch of the tables alone has nothing to do)
-        if (what == VS_WARP_TABLES_ONLY) return;
-        typedef Plane3Cfg<CN == 3 ? 1 : CN> P;
-        const uint32_t gx = grid.x, gy = (a.c.dh + P::THP - 1) / P::THP;
-        const uint32_t ntiles = gx * gy * grid.z;
-        const uint32_t mgx = (uint32_t)((0x100000000ull + gx - 1) / gx), mgy = (uint32_t)((0x100000000ull + gy - 1) / gy);
-        const uint32_t wgs = std::min<uint32_t>((ntiles + 7u) & ~7u, 6u * (uint32_t)device_cus());
-        hipLaunchKernelGGL((warp_plane3_kernel<(CN == 3 ? 1 : CN)>), dim3(wgs), dim3(NT), 0, st, a, ntiles, gx, gy, mgx, mgy, (xcd_order_flag() >> 9) & 3u);
-        return;
-    }
     if (d_tabs) {
         if (what != VS_WARP_ONLY)
             hipLaunchKernelGGL(warp_tables_kernel, dim3((a.c.dw + a.c.dh + grid.x + grid.y + NT - 1) / NT, grid.z), dim3(NT), 0, st, a);
@@ -1606,8 +1093,7 @@ void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, int what, hipStream_t s
         } else if (CN != 3 && packs && a.c.border == VS_BORDER_BLACK && plane_kernel_setting()) {
             const dim3 pg(grid.x, (a.c.dh + PlaneCfg<CN>::THP - 1) / PlaneCfg<CN>::THP, grid.z);
             const uint32_t of = order(pg, &mgx, &mgy);
-            auto kern = plane_kernel_setting() == 2 ? warp_plane2_kernel<(CN == 3 ? 1 : CN)> : warp_plane_kernel<(CN == 3 ? 1 : CN)>;
-            hipLaunchKernelGGL(kern, pg, dim3(NT), 0, st, (gtab_t)a.tabs, a.tab_stride, a.tab_row, a.tab_ad, (uint32_t)a.c.sstride,
+            hipLaunchKernelGGL((warp_plane_kernel<(CN == 3 ? 1 : CN)>), pg, dim3(NT), 0, st, (gtab_t)a.tabs, a.tab_stride, a.tab_row, a.tab_ad, (uint32_t)a.c.sstride,
                                (uint32_t)a.c.dstride, (uint32_t)a.c.sw | (uint32_t)a.c.sh << 16, (uint32_t)a.c.dw | (uint32_t)a.c.dh << 16,
                                (uint32_t)(a.c.src_aligned ? 1 : 0) | (uint32_t)(a.c.dst_aligned ? 2 : 0) | (uint32_t)a.c.border << 2 | of, mgx, mgy);
         } else {
