@@ -36,6 +36,9 @@ namespace vsd {
 
 namespace {
 
+#ifndef VS_WARP_BLEND_LAB
+#define VS_WARP_BLEND_LAB 0      // (scratch/blend_lab.sh builds timing variants of the plane kernels' blend with 1 | 2)
+#endif
 constexpr int TW = 128;      // output tile width  (pixels)
 constexpr int TH = 16;       // output tile height (rows)
 constexpr int PX = 4;        // consecutive output pixels per lane
@@ -833,12 +836,143 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
 // It shares the per-frame coordinate tables with the other kernels (the tables know tiles of 16 rows: the corner terms of
 // a taller tile come from the records of its first and last 16 rows).  A box that does not fit the staging area (large
 // rotations or zooms) takes emit_rows' direct path, 16 rows at a time.
+// A 16-byte chunk of a source row that straddles the row's left or right end (byte column xb .. xb + 15, row of `rowbytes`
+// bytes at rowp): zeros outside.  All loads unconditional, from clamped addresses, so that they travel together (under
+// conditions the compiler waits for each of sixteen byte loads in turn: 16 round trips for a tile at the frame's edge).
+__device__ __forceinline__ uint4 load_chunk_straddling(const uint8_t* rowp, int xb, int rowbytes, bool dwords) {
+    uint32_t w[4];
+    if (dwords) {            // row start and row length multiples of 4: a dword is inside or outside as a whole
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int xq = xb + 4 * q;
+            const bool in = xq >= 0 && xq + 4 <= rowbytes;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + (in ? xq : 0));
+            w[q] = in ? v : 0u;
+        }
+    } else {                 // four bytes at a time (a rolled loop: sixteen loads in flight would cost the callers their registers)
+        uint32_t wq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int xx = xb + 4 * q + k;
+                const uint32_t v = rowp[min(max(xx, 0), rowbytes - 1)];
+                wq[q] |= (xx >= 0 && xx < rowbytes ? v : 0u) << (8 * k);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = wq[q];
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 template <int CN> struct PlaneCfg {
     static constexpr int THP = 64 / CN;                  // rows of a tile
-    static constexpr int PB = 136 * CN + 8 * CN;         // staged row pitch in bytes (136 pixels + slack for the 8-byte tap read)
+    static constexpr int DB = 136 * CN + 8 * CN;         // staged bytes of a row (136 pixels + slack for the 8-byte tap read)
+    // Row pitch of the staged box: a multiple of 128 bytes = of the 32 LDS banks.  The lanes of a tap read sit on consecutive dwords
+    // of a row until the map's rotation moves them a source row down (or up), once per tile row for anything but a pure
+    // translation; with a pitch of 144 bytes those lanes land 4 banks to the side, on banks their neighbours use, and every tap
+    // read pays a second pass.  With this pitch a lane's bank does not depend on its row.  (scratch/blend_lab.sh: the tap reads
+    // were 66 of the kernel's 209 us per 32 4K frames.)
+    static constexpr int PB = (DB + 127) / 128 * 128;    // 256 / 384
     static constexpr int ROWS = THP + 9;                 // staged rows (rotations up to ~3.5 degrees)
-    static constexpr int CPR = PB / 16;                  // 16-byte chunks per staged row
+    static constexpr int CPR = DB / 16;                  // 16-byte chunks per staged row
 };
+
+// Output of a staged plane tile: lane L of a 32-lane row takes the four CONSECUTIVE pixels 4L .. 4L+3 of rows ty, ty + 8, ...: with
+// the box staged as bytes that puts neighbouring lanes on neighbouring LDS dwords, and the lane's four results are its 4 / 8
+// output bytes.  tl: the staged box (row pitch PB), the terms relative to it: ad / bd of the lane's columns, s_x0 / s_y0 of the
+// tile's rows.  The plane kernels are bound by the NUMBER of vector instructions they issue (727 per wave and luma tile at
+// 3.9 cycles each = the kernel's time, profiles/r03_d), three quarters of them here, so this is written for few instructions:
+// the taps are dword reads (the address is a multiple of 4, not of 8, and an 8-byte LDS read off its alignment is some 20 x
+// slower) shifted into place by v_alignbyte, which takes its byte count from the low two bits of the tap address as it is; the
+// weights of both lerps come from the table; and for the common tile - whole, aligned - the rows are unrolled with their terms
+// fetched beforehand and the store address split into a lane offset computed once and a scalar base that moves from row to row.
+template <int CN>
+__device__ __forceinline__ uint32_t plane_blend_px(const uint8_t* tl, const uint8_t* lut, int SX, int SY) {
+    typedef PlaneCfg<CN> P;
+    const int addr = __mul24(SY >> 10, P::PB) + (SX >> 10) * CN;  // byte of the upper-left tap
+#if VS_WARP_BLEND_LAB & 2          // (timing experiment: no tap reads, the same arithmetic)
+    const uint32_t ta = (uint32_t)(addr & ~3);
+    const uint32_t top = __builtin_amdgcn_alignbyte(ta, (uint32_t)SX, (uint32_t)addr), bot = __builtin_amdgcn_alignbyte((uint32_t)SY, ta, (uint32_t)addr);
+#else
+    const uint32_t* tp = reinterpret_cast<const uint32_t*>(tl + (addr & ~3));
+    const uint32_t top = __builtin_amdgcn_alignbyte(tp[1], tp[0], (uint32_t)addr), bot = __builtin_amdgcn_alignbyte(tp[P::PB / 4 + 1], tp[P::PB / 4], (uint32_t)addr);
+#endif
+#if VS_WARP_BLEND_LAB & 1          // (timing experiment: no weight reads)
+    LutY wy; wy.w0 = __uint_as_float((uint32_t)(SY & 0x3E0)); wy.w1 = wy.w0;
+    if (CN == 1) {
+        const uint32_t wx = (uint32_t)(SX & 0x3E0);
+        float m = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
+        asm("" : "+v"(m));
+        return __float_as_uint(m);
+    }
+#else
+    const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
+#endif
+    if (CN == 1) {
+        const uint32_t wx = *reinterpret_cast<const uint32_t*>(lut + (SX & 0x3E0));          // (32 - fx) | fx << 8
+        float m = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
+        asm("" : "+v"(m));            // (keeps the pixels' float operations apart: the packed f32 forms need moves and are no faster)
+        return __float_as_uint(m);
+    }
+    const uint32_t wu = *reinterpret_cast<const uint32_t*>(lut + 16 + (SX & 0x3E0));         // (32 - fx) | fx << 16: against bytes 0 and 2 (U0, U1)
+    const uint32_t wv = wu << 8;                                  // against bytes 1 and 3 (V0, V1)
+    float mu = vlerp(__builtin_amdgcn_udot4(top, wu, 0u, false), __builtin_amdgcn_udot4(bot, wu, 0u, false), wy);
+    float mv = vlerp(__builtin_amdgcn_udot4(top, wv, 0u, false), __builtin_amdgcn_udot4(bot, wv, 0u, false), wy);
+    asm("" : "+v"(mu), "+v"(mv));
+    return __builtin_amdgcn_perm(__float_as_uint(mv), __float_as_uint(mu), 0x0C0C0400u);     // (U, V, 0, 0)
+}
+
+template <int CN>
+__device__ __forceinline__ void plane_store4(uint8_t* dq, const uint32_t (&res)[4]) {       // four pixels = 4 / 8 aligned bytes
+    if (CN == 1) {
+        const uint32_t lo = __builtin_amdgcn_perm(res[1], res[0], 0x0C0C0400u), hi = __builtin_amdgcn_perm(res[3], res[2], 0x0C0C0400u);   // low bytes
+        __builtin_nontemporal_store(__builtin_amdgcn_perm(hi, lo, 0x05040100u), reinterpret_cast<uint32_t*>(dq));
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(u32x2{res[0] | (res[1] << 16), res[2] | (res[3] << 16)}, reinterpret_cast<u32x2*>(dq));
+    }
+}
+
+template <int CN>
+__device__ __forceinline__ void plane_blend_rows(const WarpCore& c, const uint8_t* tl, const uint8_t* lut, const int* s_x0, const int* s_y0,
+                                                 const int (&ad)[4], const int (&bd)[4], int L, int ty, uint8_t* dst, uint32_t dstride,
+                                                 int x0, int y0, int x1, int y1) {
+    typedef PlaneCfg<CN> P;
+    constexpr int NR = P::THP / TYN;
+    uint8_t* const dtile = dst + (size_t)y0 * dstride + (size_t)x0 * CN;      // wave-uniform base, 32-bit lane offsets
+    if (c.dst_aligned && x1 - x0 == TW - 1 && y1 - y0 == P::THP - 1) {         // (tile-uniform)
+        int X0[NR], Y0[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) { X0[r] = s_x0[ty + TYN * r]; Y0[r] = s_y0[ty + TYN * r]; }
+        const uint32_t voff = __umul24((uint32_t)ty, dstride) + (uint32_t)(4 * CN) * L;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            uint32_t res[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) res[i] = plane_blend_px<CN>(tl, lut, X0[r] + ad[i], Y0[r] + bd[i]);
+            plane_store4<CN>(dtile + (size_t)(TYN * r) * dstride + voff, res);
+        }
+        return;
+    }
+    const int x = x0 + 4 * L;
+    for (int r = 0; r < NR; r++) {
+        const int yl = ty + TYN * r;
+        const int X0 = s_x0[yl], Y0 = s_y0[yl];
+        uint32_t res[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) res[i] = plane_blend_px<CN>(tl, lut, X0 + ad[i], Y0 + bd[i]);
+        const int y = y0 + yl;
+        if (y > y1 || x > x1) continue;
+        uint8_t* dp = dst + (size_t)y * c.dstride + (size_t)x * CN;
+        if (c.dst_aligned && x + 3 <= x1) { plane_store4<CN>(dp, res); continue; }
+        for (int i = 0; i < 4; i++) {
+            if (x + i > x1) break;
+            for (int k = 0; k < CN; k++) dp[i * CN + k] = (uint8_t)(res[i] >> (8 * k));     // (one channel: the low byte of the float's bits)
+        }
+    }
+}
 
 template <int CN>
 __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
@@ -927,13 +1061,7 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
                     if (xb >= 0 && xb + 16 <= rowbytes && c.src_aligned) {
                         d[k] = *reinterpret_cast<const uint4*>(row + xb);       // 4-byte aligned: bx0a is a multiple of 4 pixels
                     } else if (xb + 16 > 0 && xb < rowbytes) {
-                        uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                        for (int b = 0; b < 16; b++) {          // (unrolled: w[] stays in registers)
-                            const long long xx = xb + b;
-                            if (xx >= 0 && xx < rowbytes) w[b >> 2] |= (uint32_t)row[xx] << (8 * (b & 3));
-                        }
-                        d[k] = make_uint4(w[0], w[1], w[2], w[3]);
+                        d[k] = load_chunk_straddling(row, (int)xb, (int)rowbytes, c.src_aligned && (rowbytes & 3) == 0);
                     }
                 }
             }
@@ -941,7 +1069,10 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
 #pragma unroll
         for (int k = 0; k < NCH; k++) {
             const int i = tid + NT * k;
-            if (i < total) *reinterpret_cast<uint4*>(tile + 16 * i) = d[k];       // row * PB + 16 * chunk = 16 * i
+            if (i < total) {
+                const int r = i / P::CPR;
+                *reinterpret_cast<uint4*>(tile + r * P::PB + 16 * (i - r * P::CPR)) = d[k];
+            }
         }
     }
     // the terms, relative to the staged box for the fast path
@@ -962,11 +1093,7 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
                                  bx0a, by0, bw, tid);
         return;
     }
-    // ---- output.  Lane L of a 32-lane row takes the four CONSECUTIVE pixels 4L .. 4L+3: with the box staged as bytes that puts
-    // neighbouring lanes on neighbouring LDS dwords (the BGR kernel, one dword per staged pixel, needs the stride-32 mapping and
-    // a transposition for that), and the lane's four results are its 4 / 8 output bytes.  The kernel is bound by LDS
-    // bandwidth (per pixel: two 8-byte tap reads and the 8 bytes of vertical weights), so nothing else goes through LDS: the
-    // horizontal weights are one multiply-add of the fraction.
+    // ---- output
     const int L = tid & 31, ty = tid >> 5;
     int ad[4], bd[4];
     {
@@ -974,68 +1101,7 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
         ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
         bd[0] = b4.x; bd[1] = b4.y; bd[2] = b4.z; bd[3] = b4.w;
     }
-    const int x = x0 + 4 * L;
-    const bool vec = c.dst_aligned && x + 3 <= x1;
-    const bool whole = c.dst_aligned && x1 - x0 == TW - 1;
-    uint8_t* const dtile = dst + (size_t)y0 * c.dstride + (size_t)x0 * CN;
-    for (int r = 0; r < P::THP / TYN; r++) {
-        const int yl = ty + TYN * r;
-        const int X0 = s_x0[yl], Y0 = s_y0[yl];
-        uint32_t res[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int SX = X0 + ad[i], SY = Y0 + bd[i];                  // 1/1024 px, relative to the staged box
-            const int addr = __mul24(SY >> 10, P::PB) + (SX >> 10) * CN;  // byte of the upper-left tap
-            const uint32_t sh = (uint32_t)addr & 3u;
-            const uint2 t = *reinterpret_cast<const uint2*>(tile + (addr & ~3));
-            const uint2 b = *reinterpret_cast<const uint2*>(tile + (addr & ~3) + P::PB);
-            const uint32_t top = __builtin_amdgcn_alignbyte(t.y, t.x, sh), bot = __builtin_amdgcn_alignbyte(b.y, b.x, sh);
-            // the weights of both lerps from the table (the horizontal ones were a bit-field extract and a multiply-add: the kernel is
-            // bound by the NUMBER of vector instructions - about four cycles each whatever their class, profiles/r03 - and LDS has room)
-            const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
-            if (CN == 1) {
-                const uint32_t wx = *reinterpret_cast<const uint32_t*>(lut + (SX & 0x3E0));          // (32 - fx) | fx << 8
-                float m = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
-                asm("" : "+v"(m));            // (keeps the four pixels' float operations apart: the packed f32 forms need moves and are no faster)
-                res[i] = __float_as_uint(m);
-            } else {
-                const uint32_t wu = *reinterpret_cast<const uint32_t*>(lut + 16 + (SX & 0x3E0));     // (32 - fx) | fx << 16: against bytes 0 and 2 (U0, U1)
-                const uint32_t wv = wu << 8;                              // against bytes 1 and 3 (V0, V1)
-                float mu = vlerp(__builtin_amdgcn_udot4(top, wu, 0u, false), __builtin_amdgcn_udot4(bot, wu, 0u, false), wy);
-                float mv = vlerp(__builtin_amdgcn_udot4(top, wv, 0u, false), __builtin_amdgcn_udot4(bot, wv, 0u, false), wy);
-                asm("" : "+v"(mu), "+v"(mv));
-                res[i] = __builtin_amdgcn_perm(__float_as_uint(mv), __float_as_uint(mu), 0x0C0C0400u);     // (U, V, 0, 0)
-            }
-        }
-        const int y = y0 + yl;
-        if (y > y1 || x > x1) continue;
-        if (whole) {            // tile-uniform: wave-uniform base + 32-bit lane offset
-            uint8_t* dq = dtile + (__umul24((uint32_t)yl, dstride) + (uint32_t)(4 * CN) * L);
-            if (CN == 1) {
-                const uint32_t lo = __builtin_amdgcn_perm(res[1], res[0], 0x0C0C0400u), hi = __builtin_amdgcn_perm(res[3], res[2], 0x0C0C0400u);   // low bytes
-                __builtin_nontemporal_store(__builtin_amdgcn_perm(hi, lo, 0x05040100u), reinterpret_cast<uint32_t*>(dq));
-            } else {
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                __builtin_nontemporal_store(u32x2{res[0] | (res[1] << 16), res[2] | (res[3] << 16)}, reinterpret_cast<u32x2*>(dq));
-            }
-            continue;
-        }
-        uint8_t* dp = dst + (size_t)y * c.dstride + (size_t)x * CN;
-        if (vec) {
-            if (CN == 1) {
-                const uint32_t lo = __builtin_amdgcn_perm(res[1], res[0], 0x0C0C0400u), hi = __builtin_amdgcn_perm(res[3], res[2], 0x0C0C0400u);   // low bytes
-                __builtin_nontemporal_store(__builtin_amdgcn_perm(hi, lo, 0x05040100u), reinterpret_cast<uint32_t*>(dp));
-            } else {
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                __builtin_nontemporal_store(u32x2{res[0] | (res[1] << 16), res[2] | (res[3] << 16)}, reinterpret_cast<u32x2*>(dp));
-            }
-        } else {
-            for (int i = 0; i < 4; i++) {
-                if (x + i > x1) break;
-                for (int k = 0; k < CN; k++) dp[i * CN + k] = (uint8_t)(res[i] >> (8 * k));     // (one channel: the low byte of the float's bits)
-            }
-        }
-    }
+    plane_blend_rows<CN>(c, tile, lut, s_x0, s_y0, ad, bd, L, ty, dst, dstride, x0, y0, x1, y1);
 }
 
 // Ints of table workspace per frame of dw x dh (see warp_tables_kernel).

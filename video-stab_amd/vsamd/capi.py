@@ -1001,7 +1001,8 @@ def load(path=None):
     """Load libvideo-stab.so; raises if it has not been built (no fallback)."""
     global _cached
     if _cached is None:
-        path = path or LIB_PATH
+        # (VS_LAB=1 VS_LIB_PATH=...: a measurement build of the library, scratch/blend_lab.sh)
+        path = path or (os.environ.get("VS_LIB_PATH") if os.environ.get("VS_LAB") == "1" else None) or LIB_PATH
         if not os.path.exists(path):
             raise VsError("libvideo-stab.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _cached = VsLib(C.CDLL(path))
