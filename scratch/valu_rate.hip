@@ -49,6 +49,14 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned long long* clk,
         if (OP == 33) asm volatile(".rept 32\nv_add3_u32 %0, %0, %4, %5\nv_add3_u32 %1, %1, %4, %5\nv_add3_u32 %2, %2, %4, %5\nv_add3_u32 %3, %3, %4, %5\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
         if (OP == 34) asm volatile(".rept 32\nv_xad_u32 %0, %0, %4, %5\nv_xad_u32 %1, %1, %4, %5\nv_xad_u32 %2, %2, %4, %5\nv_xad_u32 %3, %3, %4, %5\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
         if (OP == 35) asm volatile(".rept 32\nv_mul_hi_u32 %0, %0, %4\nv_mul_hi_u32 %1, %1, %4\nv_mul_hi_u32 %2, %2, %4\nv_mul_hi_u32 %3, %3, %4\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+        if (OP == 36) asm volatile(".rept 32\nv_lshl_or_b32 %0, %0, 16, %5\nv_lshl_or_b32 %1, %1, 16, %5\nv_lshl_or_b32 %2, %2, 16, %5\nv_lshl_or_b32 %3, %3, 16, %5\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+        if (OP == 37) asm volatile(".rept 32\nv_alignbyte_b32 %0, %0, %5, %4\nv_alignbyte_b32 %1, %1, %5, %4\nv_alignbyte_b32 %2, %2, %5, %4\nv_alignbyte_b32 %3, %3, %5, %4\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+        if (OP == 38) asm volatile(".rept 32\nv_ashrrev_i32 %0, 10, %0\nv_ashrrev_i32 %1, 10, %1\nv_ashrrev_i32 %2, 10, %2\nv_ashrrev_i32 %3, 10, %3\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+        if (OP == 39) asm volatile(".rept 32\nv_fmac_f32 %0, %4, %5\nv_fmac_f32 %1, %4, %5\nv_fmac_f32 %2, %4, %5\nv_fmac_f32 %3, %4, %5\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+        if (OP == 40) asm volatile(".rept 32\nv_lshlrev_b32 %0, 8, %0\nv_lshlrev_b32 %1, 8, %1\nv_lshlrev_b32 %2, 8, %2\nv_lshlrev_b32 %3, 8, %3\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+        if (OP == 41) asm volatile(".rept 32\nv_or_b32 %0, %0, %4\nv_or_b32 %1, %1, %4\nv_or_b32 %2, %2, %4\nv_or_b32 %3, %3, %4\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+        if (OP == 42) asm volatile(".rept 32\nv_sub_u32 %0, %0, %4\nv_sub_u32 %1, %1, %4\nv_sub_u32 %2, %2, %4\nv_sub_u32 %3, %3, %4\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+        if (OP == 43) asm volatile(".rept 32\nv_cndmask_b32 %0, %0, %4, vcc\nv_cndmask_b32 %1, %1, %4, vcc\nv_cndmask_b32 %2, %2, %4, vcc\nv_cndmask_b32 %3, %3, %4, vcc\n.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
     }
     const unsigned long long t1 = clock64(), w1 = wall_clock64();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (unsigned)(q0 + q1 + q2 + q3);
@@ -81,7 +89,7 @@ void run(const char* name, int wg_per_cu, unsigned* o, unsigned long long* c) {
 int main() {
     unsigned* o; unsigned long long* c;
     hipMalloc(&o, 256 * 8 * 256 * 4); hipMalloc(&c, 256 * 8 * 16);
-    for (int w : {8, 4, 1}) {
+    for (int w : {8, 2}) {
         run<0>("v_mad_u32_u24", w, o, c);
         run<1>("v_perm_b32", w, o, c);
         run<2>("v_dot4_u32_u8", w, o, c);
@@ -118,6 +126,14 @@ int main() {
         run<33>("v_med3_u32? v_add3_u32", w, o, c);
         run<34>("v_xad_u32", w, o, c);
         run<35>("v_mul_hi_u32", w, o, c);
+        run<36>("v_lshl_or_b32", w, o, c);
+        run<37>("v_alignbyte_b32", w, o, c);
+        run<38>("v_ashrrev_i32", w, o, c);
+        run<39>("v_fmac_f32", w, o, c);
+        run<40>("v_lshlrev_b32", w, o, c);
+        run<41>("v_or_b32", w, o, c);
+        run<42>("v_sub_u32", w, o, c);
+        run<43>("v_cndmask_b32", w, o, c);
     }
     return 0;
 }

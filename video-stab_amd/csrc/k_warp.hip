@@ -48,10 +48,13 @@ constexpr int TYN = NT / TXN;// 8 lane-rows
 constexpr int MAXB = 32;     // frames per launch (frame pointers and, for host matrices, the maps travel as kernel arguments)
 // fast path (near-identity maps): the source box of a tile is staged with a FIXED row pitch, so
 // the lower taps sit at an immediate offset and the tap address is one multiply-add
-constexpr int FPITCH = 136;  // staged row pitch in pixels (128 + tap + shear + 12-byte alignment slack)
+constexpr int FDATA = 136;   // staged pixels of a row (128 + tap + shear + 12-byte alignment slack)
+constexpr int FPITCH = 136;  // staged row pitch in pixels (= dwords).  (A pitch of 160 - a multiple of the 32 LDS banks, so that the lanes the
+                             // map's rotation moves to the next source row keep their banks: what the plane kernels do - costs the
+                             // BGR kernel its eighth workgroup per CU: 90.8 instead of 85 us per 32 frames, not kept.)
 constexpr int FROWS = 25;    // staged rows (rotations up to ~3.5 degrees at scale ~1)
-constexpr int LDS_PX = FPITCH * FROWS;   // 13.8 KiB of staged pixels per workgroup
-constexpr int SG = FPITCH / 4;           // 34 four-pixel groups per staged row
+constexpr int LDS_PX = FPITCH * FROWS;   // 13.3 KiB of staged pixels per workgroup
+constexpr int SG = FDATA / 4;            // 34 four-pixel groups per staged row
 constexpr int SR = 7;                    // rows per staging pass (34 x 7 = 238 lanes)
 constexpr int SPASS = (FROWS + SR - 1) / SR;   // 4 staging passes held in registers (the last one is partial)
 constexpr int LUT_STRIDE = 32;           // bytes between the entries of the weight table (index = coordinate & 0x3E0)
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
     const int bx0a = bx0 & ~3;                       // 4-pixel (12-byte) aligned start
     const int bw = (bx1 - bx0a + 1 + 3) & ~3;        // staged width, multiple of 4
     const int bh = by1 - by0 + 1;
-    const bool fast = CN == 3 && !saturated && bw <= FPITCH && bh <= FROWS;
+    const bool fast = CN == 3 && !saturated && bw <= FDATA && bh <= FROWS;
     const bool use_lds = fast || (!saturated && (long long)bw * bh <= LDS_PX);
     // (the last group of a row loads 4 bytes past the box: inside the frame unless the box ends with the frame)
     const bool interior = fast && a.c.src_aligned && bx0a >= 0 && bx0a + bw <= a.c.sw && by0 >= 0 && by0 + bh <= a.c.sh &&
@@ -592,7 +595,7 @@ __device__ __forceinline__ TileBox tile_box(const WarpCore& c, const TileIn& t) 
     b.bx0a = bx0 & ~3;
     b.bw = (bx1 - b.bx0a + 1 + 3) & ~3;
     b.bh = by1 - b.by0 + 1;
-    b.fast = !saturated && b.bw <= FPITCH && b.bh <= FROWS;
+    b.fast = !saturated && b.bw <= FDATA && b.bh <= FROWS;
     b.use_lds = b.fast || (!saturated && (long long)b.bw * b.bh <= LDS_PX);
     b.interior = b.fast && c.src_aligned && b.bx0a >= 0 && b.bx0a + b.bw <= c.sw && b.by0 >= 0 && b.by0 + b.bh <= c.sh &&
                  (b.bx0a + b.bw + 2 <= c.sw || b.by0 + b.bh < c.sh);
@@ -888,37 +891,53 @@ template <int CN> struct PlaneCfg {
 // slower) shifted into place by v_alignbyte, which takes its byte count from the low two bits of the tap address as it is; the
 // weights of both lerps come from the table; and for the common tile - whole, aligned - the rows are unrolled with their terms
 // fetched beforehand and the store address split into a lane offset computed once and a scalar base that moves from row to row.
+// (After the instructions, the LDS reads: scratch/blend_lab.sh - without the tap reads the kernel takes 143 instead of 209 us.)
+// One output pixel of a staged plane tile -> its value(s) in bytes 0 (Y) / 0, 1 (U, V) of the result.  Vertical lerp as in the BGR
+// kernel (vlerp: three float operations of the 2-cycle class on the integer sums read as denormals).  (Measured against it on one
+// box, scratch/ab_lib.sh: the integer form - t | b << 16 against (64 (32 - f), 64 f) in one v_dot2_u32_u16 preset to 2^15, result
+// in byte 2: one instruction and 4 bytes of LDS weights less per pixel, bit-identical - 204 us against 198: its two
+// instructions are of the 4-cycle class, scratch/valu_rate.hip.)
 template <int CN>
 __device__ __forceinline__ uint32_t plane_blend_px(const uint8_t* tl, const uint8_t* lut, int SX, int SY) {
     typedef PlaneCfg<CN> P;
-    const int addr = __mul24(SY >> 10, P::PB) + (SX >> 10) * CN;  // byte of the upper-left tap
+    int addr;                                                     // byte of the upper-left tap: row * PB + column * CN
+    if (P::PB == 256 && CN == 1) {          // (one shift-add; left to itself the compiler makes shift, mask, add of it)
+        const int sy = SY >> 10, sx = SX >> 10;
+        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(addr) : "v"(sy), "v"(sx));
+    } else {
+        addr = __mul24(SY >> 10, P::PB) + (SX >> 10) * CN;
+    }
 #if VS_WARP_BLEND_LAB & 2          // (timing experiment: no tap reads, the same arithmetic)
     const uint32_t ta = (uint32_t)(addr & ~3);
     const uint32_t top = __builtin_amdgcn_alignbyte(ta, (uint32_t)SX, (uint32_t)addr), bot = __builtin_amdgcn_alignbyte((uint32_t)SY, ta, (uint32_t)addr);
 #else
     const uint32_t* tp = reinterpret_cast<const uint32_t*>(tl + (addr & ~3));
+#if VS_WARP_BLEND_LAB & 4          // (timing experiment: the reads as they are, no v_alignbyte)
+    const uint32_t top = tp[0] ^ tp[1], bot = tp[P::PB / 4] ^ tp[P::PB / 4 + 1];
+#else
     const uint32_t top = __builtin_amdgcn_alignbyte(tp[1], tp[0], (uint32_t)addr), bot = __builtin_amdgcn_alignbyte(tp[P::PB / 4 + 1], tp[P::PB / 4], (uint32_t)addr);
+#endif
 #endif
 #if VS_WARP_BLEND_LAB & 1          // (timing experiment: no weight reads)
     LutY wy; wy.w0 = __uint_as_float((uint32_t)(SY & 0x3E0)); wy.w1 = wy.w0;
-    if (CN == 1) {
-        const uint32_t wx = (uint32_t)(SX & 0x3E0);
-        float m = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
-        asm("" : "+v"(m));
-        return __float_as_uint(m);
-    }
+    const uint32_t wx = (uint32_t)(SX & 0x3E0);
+#else
+#if VS_WARP_WY32
+    LutY wy;                       // (variant: W1 from the table, W0 = 32 * 2^121 - W1: 4 bytes of LDS less, one 2-cycle instruction more)
+    wy.w1 = *reinterpret_cast<const float*>(lut + 12 + (SY & 0x3E0));
+    wy.w0 = 0x1p126f - wy.w1;
 #else
     const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
 #endif
+    const uint32_t wx = *reinterpret_cast<const uint32_t*>(lut + (CN == 1 ? 0 : 16) + (SX & 0x3E0));   // (32 - fx) | fx << 8  /  (32 - fx) | fx << 16
+#endif
     if (CN == 1) {
-        const uint32_t wx = *reinterpret_cast<const uint32_t*>(lut + (SX & 0x3E0));          // (32 - fx) | fx << 8
         float m = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
         asm("" : "+v"(m));            // (keeps the pixels' float operations apart: the packed f32 forms need moves and are no faster)
         return __float_as_uint(m);
     }
-    const uint32_t wu = *reinterpret_cast<const uint32_t*>(lut + 16 + (SX & 0x3E0));         // (32 - fx) | fx << 16: against bytes 0 and 2 (U0, U1)
-    const uint32_t wv = wu << 8;                                  // against bytes 1 and 3 (V0, V1)
-    float mu = vlerp(__builtin_amdgcn_udot4(top, wu, 0u, false), __builtin_amdgcn_udot4(bot, wu, 0u, false), wy);
+    const uint32_t wv = wx << 8;                                  // wx against bytes 0 and 2 (U0, U1), wv against bytes 1 and 3 (V0, V1)
+    float mu = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
     float mv = vlerp(__builtin_amdgcn_udot4(top, wv, 0u, false), __builtin_amdgcn_udot4(bot, wv, 0u, false), wy);
     asm("" : "+v"(mu), "+v"(mv));
     return __builtin_amdgcn_perm(__float_as_uint(mv), __float_as_uint(mu), 0x0C0C0400u);     // (U, V, 0, 0)
@@ -936,22 +955,20 @@ __device__ __forceinline__ void plane_store4(uint8_t* dq, const uint32_t (&res)[
 }
 
 template <int CN>
-__device__ __forceinline__ void plane_blend_rows(const WarpCore& c, const uint8_t* tl, const uint8_t* lut, const int* s_x0, const int* s_y0,
+__device__ __forceinline__ void plane_blend_rows(const WarpCore& c, const uint8_t* tl, const uint8_t* lut, const int2* s_row,
                                                  const int (&ad)[4], const int (&bd)[4], int L, int ty, uint8_t* dst, uint32_t dstride,
                                                  int x0, int y0, int x1, int y1) {
     typedef PlaneCfg<CN> P;
     constexpr int NR = P::THP / TYN;
     uint8_t* const dtile = dst + (size_t)y0 * dstride + (size_t)x0 * CN;      // wave-uniform base, 32-bit lane offsets
     if (c.dst_aligned && x1 - x0 == TW - 1 && y1 - y0 == P::THP - 1) {         // (tile-uniform)
-        int X0[NR], Y0[NR];
-#pragma unroll
-        for (int r = 0; r < NR; r++) { X0[r] = s_x0[ty + TYN * r]; Y0[r] = s_y0[ty + TYN * r]; }
         const uint32_t voff = __umul24((uint32_t)ty, dstride) + (uint32_t)(4 * CN) * L;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
+            const int2 XY = s_row[ty + TYN * r];
             uint32_t res[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) res[i] = plane_blend_px<CN>(tl, lut, X0[r] + ad[i], Y0[r] + bd[i]);
+            for (int i = 0; i < 4; i++) res[i] = plane_blend_px<CN>(tl, lut, XY.x + ad[i], XY.y + bd[i]);
             plane_store4<CN>(dtile + (size_t)(TYN * r) * dstride + voff, res);
         }
         return;
@@ -959,7 +976,8 @@ __device__ __forceinline__ void plane_blend_rows(const WarpCore& c, const uint8_
     const int x = x0 + 4 * L;
     for (int r = 0; r < NR; r++) {
         const int yl = ty + TYN * r;
-        const int X0 = s_x0[yl], Y0 = s_y0[yl];
+        const int2 XY = s_row[ty + TYN * r];
+        const int X0 = XY.x, Y0 = XY.y;
         uint32_t res[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) res[i] = plane_blend_px<CN>(tl, lut, X0 + ad[i], Y0 + bd[i]);
@@ -974,16 +992,44 @@ __device__ __forceinline__ void plane_blend_rows(const WarpCore& c, const uint8_
     }
 }
 
+// A plane tile whose source box does not fit the staging area (large rotations, zooms, saturated coordinates, BORDER_REPLICATE): the
+// general path without staging (emit_rows works on 16 rows, terms as arrays: they go where the box would be).  Not inlined: as
+// part of the kernel body it costs the common path its eighth wave per SIMD or register spills.
 template <int CN>
-__global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
+__device__ __attribute__((noinline)) void plane_direct_tile(WarpCore c, const uint8_t* src, uint8_t* dst, gtab_t Tg, int* s_tab, int x0, int y0, int x1, int y1,
+                                                            int bx0a, int by0, int bw, int tid) {
+    typedef PlaneCfg<CN> P;
+    if (tid < TW) {           // ad[128] bd[128] x0[THP] y0[THP]
+        const int cx = min(x0 + tid, x1);
+        s_tab[tid] = Tg[cx]; s_tab[TW + tid] = Tg[c.dw + cx];
+    } else if (tid < TW + P::THP) {
+        const int r = min(y0 + (tid - TW), y1);
+        s_tab[2 * TW + (tid - TW)] = Tg[2 * c.dw + r]; s_tab[2 * TW + P::THP + (tid - TW)] = Tg[2 * c.dw + c.dh + r];
+    }
+    __syncthreads();
+    for (int j = 0; y0 + TH * j <= y1; j++)
+        emit_rows<CN, false>(c, src, dst, nullptr, s_tab, s_tab + TW, s_tab + 2 * TW + TH * j, s_tab + 2 * TW + P::THP + TH * j, x0, y0 + TH * j, x1,
+                             min(y0 + TH * j + TH - 1, y1), bx0a, by0, bw, tid);
+}
+
+#ifndef VS_PLANE_WAVES
+#define VS_PLANE_WAVES 8
+#endif
+#ifndef VS_WARP_WY32
+#define VS_WARP_WY32 0
+#endif
+template <int CN>
+__global__ __launch_bounds__(NT, VS_PLANE_WAVES) void warp_plane_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
                                                         uint32_t swh, uint32_t dwh, uint32_t flags, uint32_t mgx, uint32_t mgy) {
     typedef PlaneCfg<CN> P;
     __shared__ __attribute__((aligned(16))) uint8_t tile[P::ROWS * P::PB];
-    __shared__ __attribute__((aligned(16))) int s_tab[2 * TW + 2 * P::THP];           // ad[128] bd[128] x0[THP] y0[THP]
     __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
+    __shared__ __attribute__((aligned(16))) int2 s_row[P::THP];                 // (X0, Y0) of the tile's rows
     typedef const __attribute__((address_space(4))) int32_t* cptr;
     typedef __attribute__((address_space(1))) uint8_t* gptr;
     const int tid = threadIdx.x;
+    const int L = tid & 31, ty = tid >> 5;
+    int ad[4], bd[4];
     WarpCore c;
     c.sstride = sstride; c.dstride = dstride;
     c.sw = swh & 0xFFFFu; c.sh = swh >> 16; c.dw = dwh & 0xFFFFu; c.dh = dwh >> 16;
@@ -1013,18 +1059,7 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
             make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
         *reinterpret_cast<uint32_t*>(lut + f * LUT_STRIDE + 16) = (32u - f) | (f << 16);
     }
-    // this lane's share of the coordinate terms: (ad, bd) of a column for the first 128 lanes, (X0, Y0) of a row for the next THP
-    int tv0 = 0, tv1 = 0;
-    {
-        gtab_t Tg = tabs + (size_t)tq.z * tab_stride + tab_ad;
-        if (tid < TW) {
-            const int cx = min(x0 + tid, x1);
-            tv0 = Tg[cx]; tv1 = Tg[c.dw + cx];
-        } else if (tid < TW + P::THP) {
-            const int r = min(y0 + (tid - TW), y1);
-            tv0 = Tg[2 * c.dw + r]; tv1 = Tg[2 * c.dw + c.dh + r];
-        }
-    }
+    gtab_t Tg = tabs + (size_t)tq.z * tab_stride + tab_ad;
     // source box of the tile (the maps are monotone in x and in y separately)
     int bx0a, by0, bw, bh;
     bool fit;
@@ -1058,13 +1093,35 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
                 const long long xb = (long long)bx0a * CN + 16 * ch;          // byte column of the chunk in the source row
                 if ((unsigned)y < (unsigned)c.sh) {
                     const uint8_t* row = src + (size_t)y * c.sstride;
-                    if (xb >= 0 && xb + 16 <= rowbytes && c.src_aligned) {
+                    if (flags & 0x200u) {                                       // (lab, VS_WARP_LAB_SKIP 1: no staging loads - timing only)
+                    } else if (xb >= 0 && xb + 16 <= rowbytes && c.src_aligned) {
                         d[k] = *reinterpret_cast<const uint4*>(row + xb);       // 4-byte aligned: bx0a is a multiple of 4 pixels
                     } else if (xb + 16 > 0 && xb < rowbytes) {
                         d[k] = load_chunk_straddling(row, (int)xb, (int)rowbytes, c.src_aligned && (rowbytes & 3) == 0);
                     }
                 }
             }
+        }
+        // the terms (behind the box's loads): (ad, bd) of the lane's four columns straight into its registers, (X0, Y0) of the tile's
+        // rows, relative to the box, into a small array (broadcast reads).  (Kept in the free bytes of the staged rows instead - one
+        // LDS array less - the lanes of a read sit 256 bytes apart on ONE bank: 217 us instead of 192.)
+        const int x = x0 + 4 * L;
+        if (x1 - x0 == TW - 1 && (c.dw & 3) == 0) {
+            typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(1))) i32x4* g4;
+            const i32x4 a4 = *(g4)(Tg + x), b4 = *(g4)(Tg + c.dw + x);
+            ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
+            bd[0] = b4.x; bd[1] = b4.y; bd[2] = b4.z; bd[3] = b4.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int cx = min(x + i, x1);
+                ad[i] = Tg[cx]; bd[i] = Tg[c.dw + cx];
+            }
+        }
+        if (tid >= TW && tid < TW + P::THP) {
+            const int r = min(y0 + (tid - TW), y1);
+            s_row[tid - TW] = make_int2(Tg[2 * c.dw + r] - (bx0a << 10), Tg[2 * c.dw + c.dh + r] - (by0 << 10));
         }
 #pragma unroll
         for (int k = 0; k < NCH; k++) {
@@ -1075,33 +1132,21 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
             }
         }
     }
-    // the terms, relative to the staged box for the fast path
-    {
-        const int subx = fit ? bx0a << 10 : 0, suby = fit ? by0 << 10 : 0;
-        if (tid < TW) { s_tab[tid] = tv0; s_tab[TW + tid] = tv1; }
-        else if (tid < TW + P::THP) { s_tab[2 * TW + (tid - TW)] = tv0 - subx; s_tab[2 * TW + P::THP + (tid - TW)] = tv1 - suby; }
-    }
-    __syncthreads();
-    const int* s_ad = s_tab;
-    const int* s_bd = s_tab + TW;
-    const int* s_x0 = s_tab + 2 * TW;
-    const int* s_y0 = s_tab + 2 * TW + P::THP;
     if (!fit) {
-        // direct path (emit_rows works on 16 rows): no staging
-        for (int j = 0; y0 + TH * j <= y1; j++)
-            emit_rows<CN, false>(c, src, dst, nullptr, s_ad, s_bd, s_x0 + TH * j, s_y0 + TH * j, x0, y0 + TH * j, x1, min(y0 + TH * j + TH - 1, y1),
-                                 bx0a, by0, bw, tid);
+        plane_direct_tile<CN>(c, src, dst, Tg, reinterpret_cast<int*>(tile), x0, y0, x1, y1, bx0a, by0, bw, tid);
         return;
     }
+    __syncthreads();
     // ---- output
-    const int L = tid & 31, ty = tid >> 5;
-    int ad[4], bd[4];
-    {
-        const int4 a4 = *reinterpret_cast<const int4*>(s_ad + 4 * L), b4 = *reinterpret_cast<const int4*>(s_bd + 4 * L);
-        ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
-        bd[0] = b4.x; bd[1] = b4.y; bd[2] = b4.z; bd[3] = b4.w;
+    if (flags & 0x400u) {            // (lab, VS_WARP_LAB_SKIP 2: the stores of a whole tile alone - timing only)
+        if (c.dst_aligned && x1 - x0 == TW - 1 && y1 - y0 == P::THP - 1) {
+            const uint32_t res[4] = {(uint32_t)ad[0], (uint32_t)bd[0], (uint32_t)ad[1], (uint32_t)bd[1]};
+            for (int r = 0; r < P::THP / TYN; r++)
+                plane_store4<CN>(dst + (size_t)(y0 + ty + TYN * r) * dstride + (size_t)x0 * CN + (uint32_t)(4 * CN) * L, res);
+        }
+        return;
     }
-    plane_blend_rows<CN>(c, tile, lut, s_x0, s_y0, ad, bd, L, ty, dst, dstride, x0, y0, x1, y1);
+    plane_blend_rows<CN>(c, tile, lut, s_row, ad, bd, L, ty, dst, dstride, x0, y0, x1, y1);
 }
 
 // Ints of table workspace per frame of dw x dh (see warp_tables_kernel).
