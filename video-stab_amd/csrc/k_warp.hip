@@ -870,7 +870,10 @@ __device__ __forceinline__ uint4 load_chunk_straddling(const uint8_t* rowp, int 
 }
 
 template <int CN> struct PlaneCfg {
-    static constexpr int THP = 64 / CN;                  // rows of a tile
+#ifndef VS_PLANE_THP
+#define VS_PLANE_THP 64
+#endif
+    static constexpr int THP = VS_PLANE_THP / CN;        // rows of a tile
     static constexpr int DB = 136 * CN + 8 * CN;         // staged bytes of a row (136 pixels + slack for the 8-byte tap read)
     // Row pitch of the staged box: a multiple of 128 bytes = of the 32 LDS banks.  The lanes of a tap read sit on consecutive dwords
     // of a row until the map's rotation moves them a source row down (or up), once per tile row for anything but a pure
@@ -885,13 +888,14 @@ template <int CN> struct PlaneCfg {
 // Output of a staged plane tile: lane L of a 32-lane row takes the four CONSECUTIVE pixels 4L .. 4L+3 of rows ty, ty + 8, ...: with
 // the box staged as bytes that puts neighbouring lanes on neighbouring LDS dwords, and the lane's four results are its 4 / 8
 // output bytes.  tl: the staged box (row pitch PB), the terms relative to it: ad / bd of the lane's columns, s_x0 / s_y0 of the
-// tile's rows.  The plane kernels are bound by the NUMBER of vector instructions they issue (727 per wave and luma tile at
-// 3.9 cycles each = the kernel's time, profiles/r03_d), three quarters of them here, so this is written for few instructions:
-// the taps are dword reads (the address is a multiple of 4, not of 8, and an 8-byte LDS read off its alignment is some 20 x
-// slower) shifted into place by v_alignbyte, which takes its byte count from the low two bits of the tap address as it is; the
-// weights of both lerps come from the table; and for the common tile - whole, aligned - the rows are unrolled with their terms
-// fetched beforehand and the store address split into a lane offset computed once and a scalar base that moves from row to row.
-// (After the instructions, the LDS reads: scratch/blend_lab.sh - without the tap reads the kernel takes 143 instead of 209 us.)
+// tile's rows.  Written for few instructions: the taps are dword reads (the address is a multiple of 4, not of 8, and an 8-byte LDS
+// read off its alignment is some 20 x slower) shifted into place by v_alignbyte, which takes its byte count from the low two
+// bits of the tap address as it is; the weights of both lerps come from the table; and for the common tile - whole, aligned -
+// the rows are unrolled and the store address is a lane offset computed once plus a base that moves from row to row.
+// What the measurements of round 3 say about it (same-box pairs, scratch/ab_lib.sh): with the row pitch
+// of PlaneCfg the LDS reads no longer show (a build without them is no faster), the kernel's time does not move between 4
+// and 8 waves per SIMD, and the staging loads plus the stores alone take 105 of the luma kernel's 133 us - a copy of the
+// same bytes takes 95.
 // One output pixel of a staged plane tile -> its value(s) in bytes 0 (Y) / 0, 1 (U, V) of the result.  Vertical lerp as in the BGR
 // kernel (vlerp: three float operations of the 2-cycle class on the integer sums read as denormals).  (Measured against it on one
 // box, scratch/ab_lib.sh: the integer form - t | b << 16 against (64 (32 - f), 64 f) in one v_dot2_u32_u16 preset to 2^15, result
