@@ -49,7 +49,10 @@ constexpr int MAXB = 32;     // frames per launch (frame pointers and, for host 
 // fast path (near-identity maps): the source box of a tile is staged with a FIXED row pitch, so
 // the lower taps sit at an immediate offset and the tap address is one multiply-add
 constexpr int FDATA = 136;   // staged pixels of a row (128 + tap + shear + 12-byte alignment slack)
-constexpr int FPITCH = 136;  // staged row pitch in pixels (= dwords).  (A pitch of 160 - a multiple of the 32 LDS banks, so that the lanes the
+#ifndef VS_WARP_FPITCH
+#define VS_WARP_FPITCH 136
+#endif
+constexpr int FPITCH = VS_WARP_FPITCH;  // staged row pitch in pixels (= dwords).  (A pitch of 160 - a multiple of the 32 LDS banks, so that the lanes the
                              // map's rotation moves to the next source row keep their banks: what the plane kernels do - costs the
                              // BGR kernel its eighth workgroup per CU: 90.8 instead of 85 us per 32 frames, not kept.)
 constexpr int FROWS = 25;    // staged rows (rotations up to ~3.5 degrees at scale ~1)
