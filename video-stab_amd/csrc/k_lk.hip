@@ -94,6 +94,15 @@ __device__ __forceinline__ short2 load_deriv(const int16_t* __restrict__ d, int 
     return *reinterpret_cast<const short2*>(d + ((size_t)y * w + x) * 2);
 }
 
+// A pointer every lane of the wave holds the same value of, as a global-memory pointer in scalar registers.
+typedef const __attribute__((address_space(1))) uint8_t* gmem_u8;
+typedef const __attribute__((address_space(1))) int16_t* gmem_i16;
+__device__ __forceinline__ gmem_u8 uniform_global(const uint8_t* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (gmem_u8)(((unsigned long long)hi << 32) | lo);
+}
+
 constexpr int LK_MARGIN = 6;                       // search region = window + 1 + 2*margin
 constexpr int LK_WIN_MAX = 31;
 
@@ -116,9 +125,12 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
     // 32-frame batch took two rounds on 5632 slots; 3.6 KB leaves the wave limit (32 per CU) as the only one
     constexpr int WM = NPX <= 4 ? 16 : (NPX <= 7 ? 21 : LK_WIN_MAX);
     constexpr int PWM = WM + 1, RWM = WM + 1 + 2 * LK_MARGIN;
-    __shared__ uint8_t pI[PWM * PWM];
-    __shared__ short2 pD[PWM * PWM];
-    __shared__ uint8_t region[RWM * RWM];
+    // elements per lane of the lane-strided staging walks; the arrays are padded to whole rounds of 64 so that the stores of a
+    // round need no bounds check (the padding is never read)
+    constexpr int PN = (PWM * PWM + 63) / 64, RN = (RWM * RWM + 63) / 64;
+    __shared__ uint8_t pI[PN * 64];
+    __shared__ short2 pD[PN * 64];
+    __shared__ uint8_t region[RN * 64];
     const int lane = threadIdx.x;
     int n = a.n;
     if (a.d_n) { int dn = *a.d_n; n = dn < n ? dn : n; }
@@ -172,18 +184,43 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
         // walk with incremental (row, col); patches that lie inside the image (the common
         // case) skip the border arithmetic.
         __syncthreads();
-        {
-            const bool inside = ipx >= 0 && ipy >= 0 && ipx + PW <= L.w && ipy + PW <= L.h;
+        // Patches and regions that lie inside the image (the common case) are staged by straight-line code: every load of the
+        // level goes out before the first LDS store waits for one (elements past the end of a walk repeat element 0 and land in
+        // the arrays' padding).  Written as loops over a run-time count the compiler had turned each walk into load - wait -
+        // store per element: 26 dependent round trips per level and point, two thirds of the tracker's time
+        // (SQ_WAIT_ANY 68 % of its wave cycles, profiles/r03_c_configs1_pmc.txt).
+        // (Batches of at most ten loads: the values and offsets of a batch are all that is live, 128 registers - four waves per
+        // SIMD - hold without spills; three to four round trips per level instead of 26.)
+        const bool p_inside = ipx >= 0 && ipy >= 0 && ipx + PW <= L.w && ipy + PW <= L.h;
+        if (p_inside) {
+            // (the wave tracks ONE point: bases in scalar registers, global - not flat - loads with a 32-bit lane offset)
+            const gmem_u8 pbase = uniform_global(L.prev + ((size_t)ipy * L.stride + ipx));
+            const gmem_i16 dbase = (gmem_i16)uniform_global(reinterpret_cast<const uint8_t*>(L.deriv + ((size_t)ipy * L.w + ipx) * 2));
+            constexpr int PB_ = 5;             // elements per batch (two loads each)
+            int y = p_y0, x = p_x0;
+#pragma unroll
+            for (int k0 = 0; k0 < PN; k0 += PB_) {
+                uint8_t vI[PB_];
+                uint32_t vD[PB_];
+#pragma unroll
+                for (int k = k0; k < k0 + PB_ && k < PN; k++) {
+                    const bool ok = lane + 64 * k < PW * PW;
+                    const uint32_t eo = ok ? (uint32_t)(y * (int)L.stride + x) : 0u, dof = ok ? (uint32_t)((y * L.w + x) * 2) : 0u;
+                    vI[k - k0] = pbase[eo];
+                    vD[k - k0] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(dbase + dof);
+                    x += p_sx; y += p_sy;
+                    if (x >= PW) { x -= PW; y++; }
+                }
+#pragma unroll
+                for (int k = k0; k < k0 + PB_ && k < PN; k++) { pI[lane + 64 * k] = vI[k - k0]; *reinterpret_cast<uint32_t*>(&pD[lane + 64 * k]) = vD[k - k0]; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
             int y = p_y0, x = p_x0;
             for (int i = lane; i < PW * PW; i += 64) {
                 const int X = ipx + x, Y = ipy + y;
-                if (inside) {
-                    pI[i] = L.prev[(size_t)Y * L.stride + X];
-                    pD[i] = *reinterpret_cast<const short2*>(L.deriv + ((size_t)Y * L.w + X) * 2);
-                } else {
-                    pI[i] = L.prev[(size_t)reflect101(Y, L.h) * L.stride + reflect101(X, L.w)];
-                    pD[i] = load_deriv(L.deriv, L.w, L.h, X, Y);
-                }
+                pI[i] = L.prev[(size_t)reflect101(Y, L.h) * L.stride + reflect101(X, L.w)];
+                pD[i] = load_deriv(L.deriv, L.w, L.h, X, Y);
                 x += p_sx; y += p_sy;
                 if (x >= PW) { x -= PW; y++; }
             }
@@ -193,12 +230,31 @@ __device__ __forceinline__ void lk_track(const LKArgs& a, const int pt) {
         auto stage_region = [&]() {
             const bool inside = rx0 >= 0 && ry0 >= 0 && rx0 + RW <= L.w && ry0 + RW <= L.h;
             int y = r_y0, x = r_x0;
-            for (int i = lane; i < RW * RW; i += 64) {
-                const int X = rx0 + x, Y = ry0 + y;
-                region[i] = inside ? L.next[(size_t)Y * L.stride + X]
-                                   : L.next[(size_t)reflect101(Y, L.h) * L.stride + reflect101(X, L.w)];
-                x += r_sx; y += r_sy;
-                if (x >= RW) { x -= RW; y++; }
+            asm volatile("" : "+v"(x), "+v"(y));       // (the offsets of the walk are recomputed at every call: hoisted out of the iteration loop they cost 40 registers)
+            if (inside) {
+                const gmem_u8 rbase = uniform_global(L.next + ((size_t)ry0 * L.stride + rx0));
+                constexpr int RB_ = 10;
+#pragma unroll
+                for (int k0 = 0; k0 < RN; k0 += RB_) {
+                    uint8_t vR[RB_];
+#pragma unroll
+                    for (int k = k0; k < k0 + RB_ && k < RN; k++) {
+                        const bool ok = lane + 64 * k < RW * RW;
+                        vR[k - k0] = rbase[ok ? (uint32_t)(y * (int)L.stride + x) : 0u];
+                        x += r_sx; y += r_sy;
+                        if (x >= RW) { x -= RW; y++; }
+                    }
+#pragma unroll
+                    for (int k = k0; k < k0 + RB_ && k < RN; k++) region[lane + 64 * k] = vR[k - k0];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {                           // a region that leaves the image: element by element, reflected
+                for (int i = lane; i < RW * RW; i += 64) {
+                    const int X = rx0 + x, Y = ry0 + y;
+                    region[i] = L.next[(size_t)reflect101(Y, L.h) * L.stride + reflect101(X, L.w)];
+                    x += r_sx; y += r_sy;
+                    if (x >= RW) { x -= RW; y++; }
+                }
             }
         };
         stage_region();
