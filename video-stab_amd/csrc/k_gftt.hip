@@ -66,9 +66,29 @@ __device__ __forceinline__ void min_eigen_tile(const uint8_t* __restrict__ gray,
     const int GW = TW + bs - 1 + 2, GH = TH + bs - 1 + 2;
     const int CW = TW + bs - 1, CH = TH + bs - 1;
     const float f0 = 2.f * f1;
-    for (int i = tid; i < GW * GH; i += NT) {
-        const int ly = i / GW, lx = i - ly * GW;
-        g[ly][lx] = gray[(size_t)reflect101(gy0 + ly, h) * stride + reflect101(gx0 + lx, w)];
+    // A tile whose staged rim lies inside the image (all but the image's border tiles) is staged by straight-line code: the
+    // (up to) NG byte loads of a lane go out together.  As a loop over a run-time count with REFLECT_101 per element the
+    // compiler made load - wait - store of every element: six dependent round trips per tile.
+    const bool interior = gx0 >= 0 && gy0 >= 0 && gx0 + GW <= w && gy0 + GH <= h;       // (workgroup-uniform)
+    if (interior) {
+        constexpr int NG = ((TW + BSM - 1 + 2) * (TH + BSM - 1 + 2) + NT - 1) / NT;
+        const uint8_t* gb = gray + ((size_t)gy0 * stride + gx0);
+        uint8_t v[NG];
+        int ly[NG], lx[NG];
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            const int i = tid + NT * k;
+            ly[k] = i / GW; lx[k] = i - ly[k] * GW;
+            v[k] = i < GW * GH ? gb[(size_t)ly[k] * stride + lx[k]] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < NG; k++)
+            if (tid + NT * k < GW * GH) g[ly[k]][lx[k]] = v[k];
+    } else {
+        for (int i = tid; i < GW * GH; i += NT) {
+            const int ly = i / GW, lx = i - ly * GW;
+            g[ly][lx] = gray[(size_t)reflect101(gy0 + ly, h) * stride + reflect101(gx0 + lx, w)];
+        }
     }
     __syncthreads();
     // covariance at every position the tile's box windows touch; positions
@@ -77,8 +97,9 @@ __device__ __forceinline__ void min_eigen_tile(const uint8_t* __restrict__ gray,
         const int cy = i / CW, cx = i - cy * CW;
         const int px = x0 - anchor + cx, py = y0 - anchor + cy;
         float vxx = 0.f, vxy = 0.f, vyy = 0.f;
-        if (px >= -anchor && px <= w - 1 + hi && py >= -anchor && py <= h - 1 + hi) {
-            const int qx = reflect101(px, w) - gx0, qy = reflect101(py, h) - gy0;   // LDS coords
+        if (interior || (px >= -anchor && px <= w - 1 + hi && py >= -anchor && py <= h - 1 + hi)) {
+            // (interior tiles: every position is its own reflection)
+            const int qx = (interior ? px : reflect101(px, w)) - gx0, qy = (interior ? py : reflect101(py, h)) - gy0;   // LDS coords
             const int a00 = g[qy - 1][qx - 1], a01 = g[qy - 1][qx], a02 = g[qy - 1][qx + 1];
             const int a10 = g[qy][qx - 1], a11 = g[qy][qx], a12 = g[qy][qx + 1];
             const int a20 = g[qy + 1][qx - 1], a21 = g[qy + 1][qx], a22 = g[qy + 1][qx + 1];

@@ -84,21 +84,35 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const ImgPair* __restrict
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
     // ---- stage rows y0-2 .. y0+17, columns x0-4 .. x0+67 (the dword grid of the image; tile column c = x - (x0 - 4))
     const bool inside = x0 >= 4 && y0 >= 2 && x0 + FT_W + 4 <= w && y0 + FT_H + 2 <= h && (sstride & 3) == 0 && ((uintptr_t)src & 3) == 0;
+    // (Both forms: every load of a lane goes out before its first LDS store - addresses first, then the loads without
+    // conditions, then the stores.  With a condition or a reflection loop between two loads the compiler waits for each in
+    // turn: two round trips per interior tile, seven per border tile, and 18 % of a 960 x 540 image's tiles are border tiles.)
     if (inside) {
-        for (int i = tid; i < FT_ROWS * (FT_PITCH / 4); i += NT) {
+        constexpr int ND = (FT_ROWS * (FT_PITCH / 4) + NT - 1) / NT;
+        uint32_t v[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            const int i = min(tid + NT * k, FT_ROWS * (FT_PITCH / 4) - 1);
             const int r = i / (FT_PITCH / 4), c4 = i - r * (FT_PITCH / 4);
-            reinterpret_cast<uint32_t*>(tile)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(y0 - 2 + r) * sstride + (x0 - 4) + 4 * c4);
+            v[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(y0 - 2 + r) * sstride + (x0 - 4) + 4 * c4);
         }
+#pragma unroll
+        for (int k = 0; k < ND; k++)
+            if (tid + NT * k < FT_ROWS * (FT_PITCH / 4)) reinterpret_cast<uint32_t*>(tile)[tid + NT * k] = v[k];
     } else if (tid < 3 * FT_PITCH) {
-        // a tile on the image's border: a lane keeps one column (its reflection is computed once) and takes every third row;
-        // its (up to 7) byte loads do not depend on each other
+        // a tile on the image's border: a lane keeps one column (its reflection is computed once) and takes every third row
+        constexpr int NB = (FT_ROWS + 2) / 3;
         const int c = tid % FT_PITCH, r0 = tid / FT_PITCH;
         const uint8_t* col = src + reflect101(x0 - 4 + c, w);
+        size_t off[NB];
 #pragma unroll
-        for (int k = 0; k < (FT_ROWS + 2) / 3; k++) {
-            const int r = r0 + 3 * k;
-            if (r < FT_ROWS) tile[r * FT_PITCH + c] = col[(size_t)reflect101(y0 - 2 + r, h) * sstride];
-        }
+        for (int k = 0; k < NB; k++) off[k] = (size_t)reflect101(y0 - 2 + min(r0 + 3 * k, FT_ROWS - 1), h) * sstride;
+        uint8_t v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) v[k] = col[off[k]];
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            if (r0 + 3 * k < FT_ROWS) tile[(r0 + 3 * k) * FT_PITCH + c] = v[k];
     }
     __syncthreads();
     const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
