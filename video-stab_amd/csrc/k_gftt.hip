@@ -168,12 +168,23 @@ __device__ __forceinline__ void nms_row(const float* __restrict__ eig, int w, in
     const float maxv = key_to_float(*max_key);
     const float thr = (float)((double)maxv * quality);
     const int lane = threadIdx.x & 63;
-    for (int y = blockIdx.y * NMS_ROWS; y < min((int)(blockIdx.y + 1) * NMS_ROWS, h); y++) {
+    // the lane's values of all rows of the strip first (loads without conditions, from clamped positions): one round trip in front
+    // of the loop instead of one per row - most positions lie under the threshold and need nothing else
+    float centre[NMS_ROWS];
+    {
+        const int xc = min(max(x, 0), w - 1);
+#pragma unroll
+        for (int k = 0; k < NMS_ROWS; k++) centre[k] = eig[(size_t)min((int)blockIdx.y * NMS_ROWS + k, h - 1) * w + xc];
+    }
+#pragma unroll
+    for (int k = 0; k < NMS_ROWS; k++) {
+    const int y = blockIdx.y * NMS_ROWS + k;
+    if (y >= h) break;
     bool is_cand = false;
     float v = 0.f;
     if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
         const float* r = eig + (size_t)y * w + x;
-        v = r[0] > thr ? r[0] : 0.f;   // THRESH_TOZERO
+        v = centre[k] > thr ? centre[k] : 0.f;   // THRESH_TOZERO
         if (v != 0.f) {
             float m = v;
 #pragma unroll
