@@ -204,17 +204,28 @@ __device__ __forceinline__ int device_count(const RansacArgs& a) {
 
 // Order-preserving compaction of the tracked pairs into LDS; returns M.
 __device__ __forceinline__ int compact_to_lds(const RansacArgs& a, int n, float2* sf, float2* st, int lane) {
+    // Four rounds of 64 pairs at a time: their status bytes and coordinates are loaded without conditions (from clamped
+    // positions) before the first ballot - one round trip per 256 pairs where status load -> ballot -> coordinate loads per
+    // round made two dependent ones per 64.
     int m = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const bool keep = i < n && (a.status == nullptr || a.status[i] != 0);
-        const unsigned long long mask = __ballot(keep);
-        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-        if (keep) {
-            sf[pos] = make_float2(a.from[2 * i], a.from[2 * i + 1]);
-            st[pos] = make_float2(a.to[2 * i], a.to[2 * i + 1]);
+    for (int base = 0; base < n; base += 256) {
+        uint8_t sv[4];
+        float2 fv[4], tv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = min(base + 64 * r + lane, n - 1);
+            sv[r] = a.status ? a.status[i] : (uint8_t)1;
+            fv[r] = *reinterpret_cast<const float2*>(a.from + 2 * i);
+            tv[r] = *reinterpret_cast<const float2*>(a.to + 2 * i);
         }
-        m += __popcll(mask);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool keep = base + 64 * r + lane < n && sv[r] != 0;
+            const unsigned long long mask = __ballot(keep);
+            const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+            if (keep) { sf[pos] = fv[r]; st[pos] = tv[r]; }
+            m += __popcll(mask);
+        }
     }
     return m;
 }
