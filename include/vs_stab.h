@@ -27,8 +27,10 @@
 extern "C" {
 #endif
 
-/* 2: VS_STAGE_COUNT grew to 9 (VS_STAGE_WARP_TABLES: the arrays of vs_stab_get_stage_times), vs_params_c.host_pipeline took the
- *    last reserved slot, vs_stab_enable_graph is gone (round 2), vs_batch_* and vs_dev_copy_rate / vs_dev_memcpy_d2d added. */
+/* 2: VS_STAGE_COUNT grew to 9 (VS_STAGE_WARP_TABLES: the arrays of vs_stab_get_stage_times), vs_stab_enable_graph is gone
+ *    (round 2), vs_batch_* and vs_dev_copy_rate / vs_dev_memcpy_d2d added.  (The pipelined host call is chosen with
+ *    vs_stab_set_host_pipeline - Parameters::hostPipeline of the C++ class - not through vs_params_c, whose layout is unchanged.)
+ *    Added since without a layout change: vs_batch_create_params (round 4). */
 #define VS_STAB_ABI_VERSION 2
 
 typedef enum vs_status {
@@ -311,17 +313,25 @@ int vs_stab_set_nv12_layout(vs_stab* s, size_t in_uv_offset, size_t out_uv_offse
  * stream, the warps through launches of 32 frames.  Results are bit-identical to n_streams independent vs_stab instances.
  *   vs_batch_create      n_streams members with the same parameters, in batch mode with `frames_per_step` frames per stream and
  *                        step (1..64; n_streams x frames_per_step frames are analysed together: 8 x 8 fills the device like one
- *                        stream's batch of 64).  Adaptive smoothing, border / crop-and-zoom and the virtual canvas are per-stream
- *                        modes of vs_stab_* and are refused here.
+ *                        stream's batch of 64).  Adaptive smoothing, the fade border and the virtual canvas are per-stream
+ *                        modes of vs_stab_* (their outputs depend on each other or on a host decision) and are refused here.
+ *   vs_batch_create_params  the same with one parameter block per stream (params_per_stream[n_streams]).  The blocks may differ
+ *                        in whatever does not shape a launch: smoothing radius and method, horizon lock, the drone filters'
+ *                        settings, corner count and quality.  Frame geometry, analysis size (drone mode on or off for all),
+ *                        pyramid depth, tracking window, RANSAC iteration count and the border / crop-and-zoom mode are common;
+ *                        a step refuses members that disagree on them (VS_ERR_INVALID_ARG).
+ * A standalone vs_stab instance in batch mode (vs_stab_set_batch) runs the same schedule as a group of one.
  *   vs_batch_push_dev    one frame per stream (d_frames[i] == NULL: none for stream i this time); device pointers, one geometry,
  *                        pitch and format for all; produced[i] = 1 when the push made an output of stream i due - it is complete
  *                        after vs_batch_sync, in d_outs[i].  A step runs when a member has frames_per_step frames queued.
  *   vs_batch_flush_dev   drains the group, then the next queued frame of every stream (Stabilizer::flush).
- *   vs_batch_stream      the member instance i: for the per-stream getters (vs_stab_get_counters, vs_stab_get_debug, ...); its
- *                        frames are pushed through the group only.
+ *   vs_batch_stream      the member instance i: for the per-stream getters (vs_stab_get_counters, vs_stab_get_debug, vs_stab_sync,
+ *                        ...).  Its frames are pushed through the group only: vs_stab_push* / flush* / clean / set_* on a member
+ *                        return VS_ERR_INVALID_ARG, vs_stab_destroy ignores it (the group owns its members).
  * One host thread drives a group (and all instances of a device). */
 typedef struct vs_batch vs_batch;
 int vs_batch_create(int device, int n_streams, const vs_params_c* params, int frames_per_step, vs_batch** out);
+int vs_batch_create_params(int device, int n_streams, const vs_params_c* params_per_stream, int frames_per_step, vs_batch** out);
 void vs_batch_destroy(vs_batch* b);
 int vs_batch_streams(const vs_batch* b);
 vs_stab* vs_batch_stream(vs_batch* b, int i);

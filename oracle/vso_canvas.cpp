@@ -110,7 +110,7 @@ static bool region_available(const Rect& region, const float rel[3], const Image
 // :2316-2347 with applyMotionCompensation :2429-2443
 static Image extract_temporal_region(const Image& frame, const Rect& region, const float rel[3]) {
     const float dx = -rel[0], dy = -rel[1], da = -rel[2];
-    const float M[6] = {std::cos(da), -std::sin(da), dx, std::sin(da), std::cos(da), dy};
+    const float M[6] = {libm_cosf(da), -libm_sinf(da), dx, libm_sinf(da), libm_cosf(da), dy};
     double Md[6];
     for (int i = 0; i < 6; i++) Md[i] = (double)M[i];
     Image comp;

@@ -10,8 +10,22 @@
 #include <vector>
 
 #include "vso.h"
+// glibc's cosf / sinf / atan2f as a frozen restatement (the header the product evaluates on the device as well): see libm_*
+// below.  It is a statement of a third party's published algorithm, checked against the host's own libm on every float by
+// tests/test_libm.py; nothing else of the product is visible to the oracle.
+#include "../video-stab_amd/csrc/vs_libm.h"
 
 namespace vso {
+
+// std::cos(float) / std::sin(float) / std::atan2(float, float) of the reference (/root/reference/src/Stabilizer.cpp:662,
+// 902-908, 1689) are the HOST libm's cosf / sinf / atan2f.  Their last place depends on the libm build (glibc >= 2.41 ships
+// correctly rounded atan2f; x86 hosts without FMA take another sincosf variant), and one ulp in a matrix entry moves a pixel
+// column.  The oracle's pipeline therefore evaluates the one definition the tests verified against a real glibc (2.35, x86-64
+// with FMA: 0 mismatches over every float) wherever the suite runs; tests/test_libm.py remains the check against the host's
+// own libm and says so when the host is outside the verified set.
+static inline float libm_cosf(float x) { return vslibm::cosf_ref(x); }
+static inline float libm_sinf(float x) { return vslibm::sinf_ref(x); }
+static inline float libm_atan2f(float y, float x) { return vslibm::atan2f_ref(y, x); }
 
 // cvRound: round-half-to-even (SSE cvtsd2si / lrint in the default FP mode)
 static inline int cv_round(double v) { return (int)lrint(v); }

@@ -192,7 +192,7 @@ static void generate_transform(vso_stab* s, const uint8_t* data, int w, int h, s
             }
             d.ransac_best_iter = info[1]; d.ransac_iters_run = info[2]; d.n_inliers = info[3];
         }
-        tr[0] = T[2]; tr[1] = T[5]; tr[2] = std::atan2(T[3], T[0]);  // :660-662
+        tr[0] = T[2]; tr[1] = T[5]; tr[2] = libm_atan2f(T[3], T[0]);  // :660-662
         if (p.drone_high_freq_mode) {  // :666-671
             dead_zone_freeze(s, tr);
             micro_shake(s, tr);
@@ -285,7 +285,7 @@ static int apply_next(vso_stab* s, uint8_t* out, size_t out_stride) {
     }
     float dx = raw[0] + diff[0], dy = raw[1] + diff[1], da = raw[2] + diff[2];  // :890-894
     if (p.horizon_lock) da = 0.0f;  // :897-899
-    float T[6] = {std::cos(da), -std::sin(da), dx, std::sin(da), std::cos(da), dy};  // :902-908
+    float T[6] = {libm_cosf(da), -libm_sinf(da), dx, libm_sinf(da), libm_cosf(da), dy};  // :902-908
     memcpy(d.warp_matrix, T, sizeof T);
 
     if (s->fmt == VS_FMT_NV12) {

@@ -142,7 +142,7 @@ int motion_intent(const std::vector<float>& tr, const float motion[3], int frame
             if (i < n) {
                 float t0 = tr[3 * i], t1 = tr[3 * i + 1];
                 mags.push_back(std::sqrt(t0 * t0 + t1 * t1));
-                dirs.push_back(std::atan2(t1, t0));
+                dirs.push_back(libm_atan2f(t1, t0));
             }
         }
         if (!mags.empty()) {

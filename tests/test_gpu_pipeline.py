@@ -378,16 +378,12 @@ def test_batch_mode_matches_per_frame_pipeline(gpu, batch, radius, n):
 
 
 @pytest.mark.parametrize("size,levels,win", [((200, 150), 4, 9), ((322, 242), 3, 15), ((134, 98), 5, 5)])
-@pytest.mark.parametrize("fused", [0, 1])
-def test_batch_mode_pyramid_levels_of_odd_sizes(gpu, monkeypatch, size, levels, win, fused):
+def test_batch_mode_pyramid_levels_of_odd_sizes(gpu, size, levels, win):
     """Batch mode builds the pyramid levels of all frames of a batch per launch: one launch per level that produces the
-    derivatives of level l and the image of level l+1 from one staged tile (k_pyr.hip pyr_level_kernel), or
-    (VS_STAB_SPLIT_PYRAMID=1) the two stencils of the per-frame pipeline over a table of images.  Drone mode analyses at the frame's own size,
+    derivatives of level l and the image of level l+1 from one staged tile (k_pyr.hip pyr_level_kernel; the per-frame pipeline
+    runs the two stencils apart).  Drone mode analyses at the frame's own size,
     so the levels here have odd widths and heights (200x150 -> 100x75 -> 50x38 -> 25x19 -> ...), widths that are not
     multiples of four and tiles that hang over every border.  Same tracks, same frames as the per-frame pipeline."""
-    if not fused:
-        monkeypatch.setenv("VS_LAB", "1")
-        monkeypatch.setenv("VS_STAB_SPLIT_PYRAMID", "1")
     w, h = size
     clip = synth.make_clip(synth.SEED_CONFIG1 + 31, w, h, 12)
     p = gpu.params(smoothing_radius=5, drone_high_freq_mode=1, hf_analysis_max_width=1024, lk_max_level=levels, lk_win_size=win, max_corners=120)
@@ -1086,6 +1082,104 @@ def test_streams_of_a_vs_batch_equal_their_solo_runs(gpu, fmt, n_streams, step, 
 
 
 def test_vs_batch_refuses_per_stream_modes(gpu):
-    for kw in (dict(adaptive_smoothing=1), dict(border_size=8), dict(enable_virtual_canvas=1)):
+    """Modes whose outputs depend on each other or on a host decision per output stay with vs_stab_* (per-frame pipeline)."""
+    for kw in (dict(adaptive_smoothing=1), dict(border_size=8, border_type=capi.BORDER_FADE), dict(enable_virtual_canvas=1)):
         with pytest.raises(capi.VsError):
             gpu.batch(gpu.params(**kw), 2, 8)
+
+
+def _group_vs_solo(gpu, per_stream_params, step, n=50, size=(320, 240), solo_batch=16):
+    """Every stream of a vs_batch (one parameter block per stream) against a standalone instance with the same block."""
+    w, h = size
+    S = len(per_stream_params)
+    clips = [synth.make_clip(synth.SEED_CONFIG1 + 80 + g, w, h, 16) for g in range(S)]
+    order = [i % 16 if (i // 16) % 2 == 0 else 15 - i % 16 for i in range(n)]
+    fb = clips[0][0].nbytes
+    probe = gpu.stabilizer(per_stream_params[0])
+    oh, ow, _ = probe.out_shape(w, h, capi.FMT_BGR8)
+    probe.close()
+    ob = ow * oh * 3
+
+    def load(g):
+        buf = capi.DevBuf(gpu, fb * 16)
+        for i, f in enumerate(clips[g]):
+            buf.upload(f, i * fb)
+        return buf
+    alone = []
+    for g in range(S):
+        s = gpu.stabilizer(per_stream_params[g])
+        s.set_batch(solo_batch)
+        s.set_zero_copy(True)
+        d_in, d_out = load(g), capi.DevBuf(gpu, ob * (n + 2))
+        k = 0
+        for i in order:
+            k += s.push_dev(d_in.ptr + i * fb, w, h, w * 3, capi.FMT_BGR8, d_out.ptr + k * ob, ow * 3)
+        # (the last queued frame has no transform and comes back at its own size: not part of this comparison)
+        s.sync()
+        alone.append(d_out.download((k, oh, ow, 3), np.uint8))
+        s.close()
+    b = gpu.batch(list(per_stream_params), S, step)
+    b.set_zero_copy(True)
+    d_in = [load(g) for g in range(S)]
+    d_out = [capi.DevBuf(gpu, ob * (n + 2)) for _ in range(S)]
+    k = [0] * S
+    for i in order:
+        prod = b.push_dev([d_in[g].ptr + i * fb for g in range(S)], w, h, w * 3, capi.FMT_BGR8, [d_out[g].ptr + k[g] * ob for g in range(S)], ow * 3)
+        for g in range(S):
+            k[g] += prod[g]
+    b.sync()
+    for g in range(S):
+        got = d_out[g].download((k[g], oh, ow, 3), np.uint8)
+        assert k[g] == len(alone[g]) > 0 and np.array_equal(got, alone[g]), g
+    b.close()
+
+
+@pytest.mark.parametrize("extra", [dict(border_size=16, border_type=capi.BORDER_REFLECT), dict(border_size=9, border_type=capi.BORDER_REPLICATE),
+                                   dict(border_size=12, crop_n_zoom=1)])
+def test_vs_batch_with_border_pad_and_crop_n_zoom_members(gpu, extra):
+    """Border pad and crop-and-zoom are launch shapes, not per-output decisions: a group batches them like a standalone
+    instance does (it IS the same schedule: an instance is a group of one)."""
+    p = gpu.params(smoothing_radius=7, **extra)
+    _group_vs_solo(gpu, [p, p, p], 8, n=44)
+
+
+def test_vs_batch_members_with_their_own_parameters(gpu):
+    """vs_batch_create_params: the streams of a group may differ in what does not shape a launch - smoothing radius and
+    method (the Kalman stream's releases stay inside its tail workgroup, the others' run apart), horizon lock, corner count."""
+    ps = [gpu.params(smoothing_radius=7), gpu.params(smoothing_radius=12, smoothing_method=capi.SMOOTH_KALMAN),
+          gpu.params(smoothing_radius=5, smoothing_method=capi.SMOOTH_GAUSSIAN, gaussian_sigma=2.5, horizon_lock=1),
+          gpu.params(smoothing_radius=9, max_corners=90)]
+    _group_vs_solo(gpu, ps, 8, n=60)
+    # ... but not in what does: another tracking window is refused when the step runs
+    b = gpu.batch([gpu.params(smoothing_radius=7), gpu.params(smoothing_radius=7, lk_win_size=15)], 2, 4)
+    clip = synth.make_clip(synth.SEED_CONFIG1, 320, 240, 6)
+    fb = clip[0].nbytes
+    d_in, d_out = capi.DevBuf(gpu, fb * 6), capi.DevBuf(gpu, fb * 12)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    with pytest.raises(capi.VsError):
+        for i in range(6):
+            b.push_dev([d_in.ptr + i * fb] * 2, 320, 240, 960, capi.FMT_BGR8, [d_out.ptr + i * fb, d_out.ptr + (6 + i) * fb], 960)
+    b.close()
+
+
+def test_members_of_a_vs_batch_are_driven_through_the_group_only(gpu):
+    """vs_batch_stream hands out the members for their getters; pushing, flushing, cleaning or re-configuring one behind the
+    group's back would leave the group with dangling entries, so those calls are refused (and destroy is ignored)."""
+    import ctypes as C
+    b = gpu.batch(gpu.params(smoothing_radius=5), 2, 4)
+    m = b.stream(0)
+    clip = synth.make_clip(synth.SEED_CONFIG1, 320, 240, 2)
+    d = capi.DevBuf(gpu, clip[0].nbytes * 2)
+    prod = C.c_int(0)
+    L = gpu.lib
+    assert L.vs_stab_push_dev(m.h, C.c_void_p(d.ptr), 320, 240, 960, capi.FMT_BGR8, C.c_void_p(d.ptr + clip[0].nbytes), 960, C.byref(prod)) == 1   # VS_ERR_INVALID_ARG
+    assert L.vs_stab_clean(m.h) == 1 and L.vs_stab_set_batch(m.h, 8) == 1 and L.vs_stab_set_zero_copy(m.h, 1) == 1
+    assert L.vs_stab_set_warp_batch(m.h, 4) == 1 and L.vs_stab_set_nv12_layout(m.h, 0, 0) == 1
+    L.vs_stab_destroy(m.h)                     # ignored: the group owns the member
+    assert m.counters().frames_in == 0         # ... which is still alive
+    b.set_zero_copy(True)
+    b.push_dev([d.ptr, d.ptr], 320, 240, 960, capi.FMT_BGR8, [d.ptr + clip[0].nbytes] * 2, 960)
+    b.sync()
+    assert m.counters().frames_in == 1
+    b.close()

@@ -192,8 +192,7 @@ int launch_resize_gray_batch(const ImgPair* d_pairs, int items, size_t sstride, 
     uint8_t* nd = nullptr;
     if (fmt == VS_FMT_BGR8 && area2) {
         const int vec_ok = aligned && (sstride % 8 == 0) && (dstride % 4 == 0);
-        static const bool old_kernel = lab_env("VS_GRAY_OLD_KERNEL") != nullptr;       // A/B switch
-        if (aligned && sstride % 4 == 0 && dstride % 2 == 0 && !old_kernel) {
+        if (aligned && sstride % 4 == 0 && dstride % 2 == 0) {
             // (aligned: every frame of the table starts on an 8-byte boundary; the analysis images come from the library's own
             // allocation, 256-byte aligned)
             dim3 grid(((dw + 1) / 2 + NT - 1) / NT, (dh + HG_ROWS - 1) / HG_ROWS, items);

@@ -15,10 +15,9 @@ constexpr int RPB = 4;      // image rows per workgroup: one row each made the l
 
 __global__ __launch_bounds__(NT) void pyr_down_kernel(const uint8_t* __restrict__ src_, size_t sstride,
                                                       int sw, int sh, uint8_t* __restrict__ dst_,
-                                                      size_t dstride, int dw, int dh, const ImgPair* __restrict__ table) {
-    // batched launch: blockIdx.z selects the frame's (source, destination) pair
-    const uint8_t* __restrict__ src = table ? static_cast<const uint8_t*>(table[blockIdx.z].src) : src_;
-    uint8_t* __restrict__ dst = table ? static_cast<uint8_t*>(table[blockIdx.z].dst) : dst_;
+                                                      size_t dstride, int dw, int dh) {
+    const uint8_t* __restrict__ src = src_;
+    uint8_t* __restrict__ dst = dst_;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= dw) return;
     int xi[5];
@@ -36,9 +35,9 @@ __global__ __launch_bounds__(NT) void pyr_down_kernel(const uint8_t* __restrict_
 }
 
 __global__ __launch_bounds__(NT) void scharr_kernel(const uint8_t* __restrict__ src_, size_t sstride, int w,
-                                                    int h, int16_t* __restrict__ dst_, const ImgPair* __restrict__ table) {
-    const uint8_t* __restrict__ src = table ? static_cast<const uint8_t*>(table[blockIdx.z].src) : src_;
-    int16_t* __restrict__ dst = table ? static_cast<int16_t*>(table[blockIdx.z].dst) : dst_;
+                                                    int h, int16_t* __restrict__ dst_) {
+    const uint8_t* __restrict__ src = src_;
+    int16_t* __restrict__ dst = dst_;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= w) return;
     for (int y = blockIdx.y * RPB; y < min((int)(blockIdx.y + 1) * RPB, h); y++) {
@@ -199,7 +198,7 @@ int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_
     }
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     dim3 grid((dw + NT - 1) / NT, (dh + RPB - 1) / RPB);
-    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst, dstride, dw, dh, (const ImgPair*)nullptr);
+    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(NT), 0, st, d_src, sstride, sw, sh, d_dst, dstride, dw, dh);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -210,31 +209,7 @@ int launch_scharr(const uint8_t* d_src, size_t sstride, int w, int h, int16_t* d
         return VS_ERR_INVALID_ARG;
     }
     dim3 grid((w + NT - 1) / NT, (h + RPB - 1) / RPB);
-    hipLaunchKernelGGL(scharr_kernel, grid, dim3(NT), 0, st, d_src, sstride, w, h, d_dst, (const ImgPair*)nullptr);
-    VS_HIP_TRY(hipGetLastError());
-    return VS_OK;
-}
-
-int launch_pyr_down_batch(const ImgPair* d_pairs, int items, size_t sstride, int sw, int sh, size_t dstride, hipStream_t st) {
-    if (!d_pairs || items < 1 || items > 65535 || sw <= 0 || sh <= 0 || sh > 131070) {
-        set_last_error("pyr_down_batch: invalid argument");
-        return VS_ERR_INVALID_ARG;
-    }
-    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    dim3 grid((dw + NT - 1) / NT, (dh + RPB - 1) / RPB, items);
-    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(NT), 0, st, (const uint8_t*)nullptr, sstride, sw, sh, (uint8_t*)nullptr, dstride,
-                       dw, dh, d_pairs);
-    VS_HIP_TRY(hipGetLastError());
-    return VS_OK;
-}
-
-int launch_scharr_batch(const ImgPair* d_pairs, int items, size_t sstride, int w, int h, hipStream_t st) {
-    if (!d_pairs || items < 1 || items > 65535 || w <= 0 || h <= 0 || h > 65535) {
-        set_last_error("scharr_batch: invalid argument");
-        return VS_ERR_INVALID_ARG;
-    }
-    dim3 grid((w + NT - 1) / NT, (h + RPB - 1) / RPB, items);
-    hipLaunchKernelGGL(scharr_kernel, grid, dim3(NT), 0, st, (const uint8_t*)nullptr, sstride, w, h, (int16_t*)nullptr, d_pairs);
+    hipLaunchKernelGGL(scharr_kernel, grid, dim3(NT), 0, st, d_src, sstride, w, h, d_dst);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

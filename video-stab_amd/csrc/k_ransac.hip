@@ -230,45 +230,11 @@ __device__ __forceinline__ int compact_to_lds(const RansacArgs& a, int n, float2
     return m;
 }
 
-__device__ __forceinline__ void ransac_score(const RansacArgs& a, const int k) {
-    extern __shared__ float2 s_pts[];          // [2][a.n]: compacted from / to
-    float2* sf = s_pts;
-    float2* st = s_pts + a.n;
-    const int lane = threadIdx.x;
-    const int n = device_count(a);
-    const int m = compact_to_lds(a, n, sf, st, lane);
-    __syncthreads();
-    if (k == 0 && a.status) {
-        for (int i = lane; i < m; i += 64) {
-            a.vp[2 * i] = sf[i].x; a.vp[2 * i + 1] = sf[i].y;
-            a.vc[2 * i] = st[i].x; a.vc[2 * i + 1] = st[i].y;
-        }
-        if (lane == 0) *a.d_m = m;
-    }
-    if (m < a.min_points || m <= 2 || m > a.table_max_m) return;
-    const uint32_t pr = a.pairs[(size_t)m * a.iters + k];
-    const int i0 = pr & 0xFFFFu, i1 = pr >> 16;
-    const Model M = kernel2(sf[i0].x, sf[i0].y, sf[i1].x, sf[i1].y, st[i0].x, st[i0].y, st[i1].x, st[i1].y);
-    float F[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) F[i] = (float)M.m[i];
-    int good = 0;
-    for (int base = 0; base < m; base += 64) {
-        const int i = base + lane;
-        bool in = false;
-        if (i < m) in = is_inlier(F, sf[i].x, sf[i].y, st[i].x, st[i].y, a.t);
-        good += __popcll(__ballot(in));
-    }
-    if (lane == 0) a.counts[k] = good;
-}
-
-__global__ __launch_bounds__(64) void ransac_score_kernel(RansacArgs a) { ransac_score(a, blockIdx.x); }
-
-// The same votes, SC_HYP hypotheses per wave: four lanes share a hypothesis and take every fourth point each, their counts
-// meet in two DPP adds.  A wave compacts the correspondences once for 16 hypotheses instead of once per hypothesis, and a
-// batch of 32 frames x 500 hypotheses is 1024 waves - one per SIMD - instead of 16 000: the launch is as long as one wave's
-// chain (compaction, the closed-form model, m / 4 inlier tests).  (The votes are integers: who counts them does not change
-// them.)
+// Hypothesis scoring, SC_HYP hypotheses per wave: four lanes share a hypothesis and take every fourth point each, their counts
+// meet in two DPP adds.  A wave compacts the correspondences once for 16 hypotheses, and a batch of 32 frames x 500 hypotheses
+// is 1024 waves - one per SIMD: the launch is as long as one wave's chain (compaction, the closed-form model, m / 4 inlier
+// tests).  (The votes are integers: who counts them does not change them.  Round 2 measured one wave per hypothesis, 16 000
+// waves per batch, against it: 22 -> 13.7 us per batch; scratch/README.md.)
 constexpr int SC_HYP = 16;
 
 __device__ __forceinline__ void ransac_score16(const RansacArgs& a, const int kgroup) {
@@ -433,17 +399,8 @@ __device__ __forceinline__ void ransac_select(const RansacArgs& a, const bool wr
 __global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) { ransac_select<false>(a); }
 
 // Several frames per launch: blockIdx.y selects the frame's argument block in a device table, blockIdx.x the hypothesis.
-__global__ __launch_bounds__(64) void ransac_score_batch_kernel(const RansacArgs* __restrict__ table) {
-    ransac_score(table[blockIdx.y], blockIdx.x);
-}
 __global__ __launch_bounds__(64) void ransac_score16_batch_kernel(const RansacArgs* __restrict__ table) {
     ransac_score16(table[blockIdx.y], blockIdx.x);
-}
-
-// VS_RANSAC_WAVE_PER_HYPOTHESIS=1: one wave per hypothesis, the scoring before this was measured
-bool score16_setting() {
-    static const bool v = lab_env("VS_RANSAC_WAVE_PER_HYPOTHESIS") == nullptr;
-    return v;
 }
 
 // The selections of a batch, one wave (workgroup) per frame, launched right behind the scoring: they do not depend on
@@ -464,25 +421,25 @@ struct TailItem {
     int ncnt, seg;               // ncnt: written by the tail - transforms appended after this push (read by the release kernel);
                                  // seg: group launches - index of the frame's stream segment
 };
-// A launch over the frames of several streams (vs_batch): the items of stream s are table[first .. first + n), workgroup s of the
-// tail takes them, and the stream's frame matrix goes to its own M_out.
-struct TailSeg { int first, n; float* M_out; TrajState* traj; vs_debug_frame* dbg; };
-
-// RELEASE_APART: the kernel ends with the appends (phases 1 and 2a) and leaves the releases - smoothing around the frame each
+// A step's frames belong to one or more streams (a standalone instance is a group of one): the items of stream s are
+// table[first .. first + n), workgroup s of the tail takes them, and the stream's frame matrix goes to its own M_out.
+// apart: the tail workgroup ends with the appends (phases 1 and 2a) and leaves the releases - smoothing around the frame each
 // due push lets go, its matrix and inverse map - to ransac_release_batch_kernel, one workgroup per push: on the one CU of
-// this kernel sixteen waves share four SIMDs and a batch of 64 releases took 60 of the tail's 130 us.  (Not for the Kalman
-// smoother, whose filter state advances from release to release.)
-template <bool RELEASE_APART>
-__global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArgs* __restrict__ table,
-                                                                 TailItem* __restrict__ tail, int n, float* M_out, const TailSeg* __restrict__ segs,
-                                                                 const TailIn* __restrict__ tin, TrajState* g_state, vs_debug_frame* g_dbg) {
+// a tail workgroup sixteen waves share four SIMDs and a batch of 64 releases took 60 of the tail's 130 us.  (Not for the Kalman
+// smoother, whose filter state advances from release to release: apart = 0, the releases stay inside the tail.)
+struct TailSeg { int first, n; float* M_out; TrajState* traj; vs_debug_frame* dbg; int apart, pad; };
+
+__global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArgs* __restrict__ table, TailItem* __restrict__ tail,
+                                                                 const TailSeg* __restrict__ segs, const TailIn* __restrict__ tin) {
     // (Beside the detector's NMS launch of the next batch this kernel takes 85 us, alone 10 - 25; s_setprio(3) for its waves
     // changes nothing: measured, not kept.)
-    if (segs) {                      // one workgroup per stream of a group launch
-        const TailSeg sg = segs[blockIdx.x];
-        table += sg.first; tail += sg.first; tin += sg.first; n = sg.n; M_out = sg.M_out; g_state = sg.traj; g_dbg = sg.dbg;
-        if (n <= 0) return;
-    }
+    const TailSeg sg = segs[blockIdx.x];
+    table += sg.first; tail += sg.first; tin += sg.first;
+    const int n = sg.n;
+    float* const M_out = sg.M_out;
+    TrajState* const g_state = sg.traj;
+    vs_debug_frame* const g_dbg = sg.dbg;
+    if (n <= 0) return;
     // The ordered part below is a chain of small dependent steps executed by one lane; run from global
     // memory every step would pay an HBM round trip (and every barrier would wait for the stores of the
     // step before).  The stream's trajectory state, the parameters, the per-frame inputs and all results
@@ -566,7 +523,7 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
     int last_due = -1;
     for (int i = 0; i < n; i++) if (l_due[i]) last_due = i;
     __syncthreads();
-    if (RELEASE_APART) {
+    if (sg.apart) {
         for (int i = tid; i < (int)(sizeof(TrajState) / 4); i += blockDim.x)
             reinterpret_cast<uint32_t*>(g_state)[i] = reinterpret_cast<const uint32_t*>(&l_state)[i];
         for (int i = tid; i < (int)(sizeof(vs_debug_frame) / 4); i += blockDim.x)
@@ -614,24 +571,23 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
         if (lane < 12 && l_due[f]) tail[f].Minv_out[lane] = l_minv[f][lane];
 }
 
-// The releases of a batch whose appends ransac_tail_batch_kernel<true> has made: workgroup f = push f.  Each sees the
-// trajectory as long as it was after its push (TailItem::ncnt); the last due one leaves its record and matrix behind,
-// like the last release of the one-kernel tail.
+// The releases of a step whose appends ransac_tail_batch_kernel has made (segments with `apart`): workgroup f = push f.  Each sees
+// the trajectory as long as it was after its push (TailItem::ncnt); the last due one of a stream leaves its record and matrix
+// behind, like the last release of the one-kernel tail.
 __global__ __launch_bounds__(64) void ransac_release_batch_kernel(const RansacArgs* __restrict__ table, const TailItem* __restrict__ tail,
-                                                                  int n, float* M_out, const TailSeg* __restrict__ segs) {
+                                                                  const TailSeg* __restrict__ segs) {
     __shared__ vs_debug_frame l_dbg_unused;
     __shared__ float l_M[12];
     int f = blockIdx.x;
     const TailItem t = tail[f];
     if (!t.out_due) return;
-    if (segs) {                      // the frame's own stream: its items, its matrix
-        const TailSeg sg = segs[t.seg];
-        table += sg.first; tail += sg.first; f -= sg.first; n = sg.n; M_out = sg.M_out;
-    }
+    const TailSeg sg = segs[t.seg];          // the frame's own stream: its items, its matrix
+    if (!sg.apart) return;
+    table += sg.first; tail += sg.first; f -= sg.first;
     int last_due = -1;
-    for (int i = 0; i < n; i++) if (tail[i].out_due) last_due = i;
+    for (int i = 0; i < sg.n; i++) if (tail[i].out_due) last_due = i;
     const bool last = f == last_due;
-    traj_emit_device(table[0].traj, table[0].tp, t.out_idx, last ? M_out : l_M, t.Minv_out, last ? table[0].dbg : &l_dbg_unused, nullptr, t.ncnt);
+    traj_emit_device(table[0].traj, table[0].tp, t.out_idx, last ? sg.M_out : l_M, t.Minv_out, last ? table[0].dbg : &l_dbg_unused, nullptr, t.ncnt);
 }
 
 }  // namespace
@@ -682,12 +638,8 @@ int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_m
         set_last_error("ransac_score_batch: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
-    if (score16_setting())
-        hipLaunchKernelGGL(ransac_score16_batch_kernel, dim3((iters + SC_HYP - 1) / SC_HYP, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
-                           static_cast<const RansacArgs*>(d_table));
-    else
-        hipLaunchKernelGGL(ransac_score_batch_kernel, dim3(iters, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
-                           static_cast<const RansacArgs*>(d_table));
+    hipLaunchKernelGGL(ransac_score16_batch_kernel, dim3((iters + SC_HYP - 1) / SC_HYP, items), dim3(64), (size_t)(n_max > 0 ? n_max : 1) * 16, st,
+                       static_cast<const RansacArgs*>(d_table));
     hipLaunchKernelGGL(ransac_select_batch_kernel, dim3(items), dim3(64), 0, st, static_cast<const RansacArgs*>(d_table), items - 1);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
@@ -702,18 +654,20 @@ void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_ou
 
 // ---- group launches (vs_batch: the frames of several streams in one table) ----
 size_t tail_seg_bytes() { return sizeof(TailSeg); }
-void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out, TrajState* traj, vs_debug_frame* dbg) {
+void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out, TrajState* traj, vs_debug_frame* dbg, int smoothing_method) {
     TailSeg& g = *static_cast<TailSeg*>(host_seg);
     g.first = first; g.n = n; g.M_out = d_M_out; g.traj = traj; g.dbg = dbg;
+    g.apart = smoothing_method != VS_SMOOTH_KALMAN ? 1 : 0; g.pad = 0;
 }
 size_t tail_in_bytes() { return sizeof(TailIn); }
 void ransac_item_set_tail_in(void* host_item, void* d_tail_in) { static_cast<RansacArgs*>(host_item)->tail_in = static_cast<TailIn*>(d_tail_in); }
 void tail_item_set_seg(void* host_item, int seg) { static_cast<TailItem*>(host_item)->seg = seg; }
 void ransac_item_set_last(void* host_item, int last) { static_cast<RansacArgs*>(host_item)->last_of_stream = last; }
 
-// The ordered tails of `nsegs` streams in one launch (workgroup = stream), then the releases of all their pushes.
+// The ordered tails of `nsegs` streams in one launch (workgroup = stream), then the releases of all their pushes
+// (any_apart: some segment leaves its releases to the second launch).
 int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void* d_segs, const void* d_tail_in, int nsegs, int max_n, int items,
-                             int smoothing_method, hipStream_t st) {
+                             int any_apart, hipStream_t st) {
     if (!d_table || !d_tail || !d_segs || !d_tail_in || nsegs < 1 || max_n < 1 || max_n > 64 || items < 1) {
         set_last_error("ransac_tail_group: invalid argument");
         return VS_ERR_INVALID_ARG;
@@ -723,39 +677,8 @@ int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void
     TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
     const TailSeg* sg = static_cast<const TailSeg*>(d_segs);
     const TailIn* ti = static_cast<const TailIn*>(d_tail_in);
-    if (smoothing_method != VS_SMOOTH_KALMAN) {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(nsegs), dim3(threads), 0, st, tb, tl, 0, (float*)nullptr, sg, ti, (TrajState*)nullptr, (vs_debug_frame*)nullptr);
-        hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, 0, (float*)nullptr, sg);
-    } else {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(nsegs), dim3(threads), 0, st, tb, tl, 0, (float*)nullptr, sg, ti, (TrajState*)nullptr, (vs_debug_frame*)nullptr);
-    }
-    VS_HIP_TRY(hipGetLastError());
-    return VS_OK;
-}
-
-int launch_ransac_tail_batch(const void* d_table, const void* d_tail, const void* d_tail_in, TrajState* traj, vs_debug_frame* dbg, int items,
-                             float* d_M_out, int smoothing_method, hipStream_t st) {
-    if (!d_table || !d_tail || !d_tail_in || !traj || !dbg || items < 1 || !d_M_out) { set_last_error("ransac_tail_batch: invalid argument"); return VS_ERR_INVALID_ARG; }
-    const TailIn* ti = static_cast<const TailIn*>(d_tail_in);
-    const int threads = 64 * (items < 1 ? 1 : (items > 16 ? 16 : items));
-    if (items > 64) { set_last_error("ransac_tail_batch: at most 64 frames"); return VS_ERR_INVALID_ARG; }
-    // (VS_TAIL_ONE_KERNEL=1: releases inside the tail kernel, as measured before)
-    static const bool apart = lab_env("VS_TAIL_ONE_KERNEL") == nullptr;
-    const RansacArgs* tb = static_cast<const RansacArgs*>(d_table);
-    TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
-    if (apart && smoothing_method != VS_SMOOTH_KALMAN) {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<true>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr, ti, traj, dbg);
-        hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr);
-    } else {
-        hipLaunchKernelGGL(ransac_tail_batch_kernel<false>, dim3(1), dim3(threads), 0, st, tb, tl, items, d_M_out, (const TailSeg*)nullptr, ti, traj, dbg);
-    }
-    VS_HIP_TRY(hipGetLastError());
-    return VS_OK;
-}
-
-int launch_ransac_select_item(const void* host_item, hipStream_t st) {
-    if (!host_item) return VS_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, st, *static_cast<const RansacArgs*>(host_item));
+    hipLaunchKernelGGL(ransac_tail_batch_kernel, dim3(nsegs), dim3(threads), 0, st, tb, tl, sg, ti);
+    if (any_apart) hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, sg);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -776,10 +699,8 @@ int launch_ransac(const float* d_from, const float* d_to, const uint8_t* d_statu
     RansacArgs a;
     fill_ransac_args(a, d_from, d_to, d_status, n, d_n, d_vp, d_vc, d_m, min_points, thr, iters, tab, d_counts, d_model,
                      d_inliers, d_info, traj, tp, dbg, have_prev_gray);
-    if ((n > 2 || d_status) && score16_setting())
+    if (n > 2 || d_status)
         hipLaunchKernelGGL(ransac_score16_kernel, dim3((iters + SC_HYP - 1) / SC_HYP), dim3(64), (size_t)(n > 0 ? n : 1) * 16, st, a);
-    else if (n > 2 || d_status)
-        hipLaunchKernelGGL(ransac_score_kernel, dim3(iters), dim3(64), (size_t)(n > 0 ? n : 1) * 16, st, a);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(64), 0, st, a);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;

@@ -36,9 +36,6 @@ namespace vsd {
 
 namespace {
 
-#ifndef VS_WARP_BLEND_LAB
-#define VS_WARP_BLEND_LAB 0      // (scratch/blend_lab.sh builds timing variants of the plane kernels' blend with 1 | 2)
-#endif
 constexpr int TW = 128;      // output tile width  (pixels)
 constexpr int TH = 16;       // output tile height (rows)
 constexpr int PX = 4;        // consecutive output pixels per lane
@@ -49,10 +46,7 @@ constexpr int MAXB = 32;     // frames per launch (frame pointers and, for host 
 // fast path (near-identity maps): the source box of a tile is staged with a FIXED row pitch, so
 // the lower taps sit at an immediate offset and the tap address is one multiply-add
 constexpr int FDATA = 136;   // staged pixels of a row (128 + tap + shear + 12-byte alignment slack)
-#ifndef VS_WARP_FPITCH
-#define VS_WARP_FPITCH 136
-#endif
-constexpr int FPITCH = VS_WARP_FPITCH;  // staged row pitch in pixels (= dwords).  (A pitch of 160 - a multiple of the 32 LDS banks, so that the lanes the
+constexpr int FPITCH = 136;  // staged row pitch in pixels (= dwords).  (A pitch of 160 - a multiple of the 32 LDS banks, so that the lanes the
                              // map's rotation moves to the next source row keep their banks: what the plane kernels do - costs the
                              // BGR kernel its eighth workgroup per CU: 90.8 instead of 85 us per 32 frames, not kept.)
 constexpr int FROWS = 25;    // staged rows (rotations up to ~3.5 degrees at scale ~1)
@@ -785,9 +779,7 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
     pf.tv0 = 0; pf.tv1 = 0;
     load_terms(k, cur, tid, pf.tv0, pf.tv1);
     const TileBox cb = tile_box(k.c, cur);
-    if (cb.pre && (flags & 0x200u)) {            // (lab, VS_WARP_LAB_SKIP: 1 no staging loads, 2 no blending - timing only)
-        store_terms(s_tab, tid, pf.tv0, pf.tv1, cb.bx0a << 10, cb.by0 << 10);
-    } else if (cb.pre) {
+    if (cb.pre) {
         issue_tile(k, cur, cb, tid, pf);
         store_tile(k, cur, cb, tid, pf, tile, s_tab);
     } else {
@@ -809,14 +801,6 @@ __global__ __launch_bounds__(NT, 8) void warp_tab_kernel(gtab_t tabs, int tab_st
         store_terms(s_tab, tid, tv0, tv1, cb.fast ? cb.bx0a << 10 : 0, cb.fast ? cb.by0 << 10 : 0);
     }
     __syncthreads();
-    if (flags & 0x400u) {                        // (lab: the stores alone)
-        if (cur.x1 - cur.x0 == TW - 1 && cur.y1 - cur.y0 == TH - 1)
-            for (int r = 0; r < TH / TYN; r++) {
-                U3 v; v.a = (uint32_t)s_tab[tid & 127]; v.b = v.a; v.c = v.a;
-                store_nt3(cur.dst + (size_t)(cur.y0 + (tid >> 5) + TYN * r) * k.c.dstride + (size_t)cur.x0 * 3 + 12u * (tid & 31), v);
-            }
-        return;
-    }
     if (cb.fast) emit_fast(k.c, cur.dst, tile, obuf, lut, s_tab, s_tab + TW, s_tab + 2 * TW, s_tab + 2 * TW + TH, cur.x0, cur.y0, cur.x1, cur.y1, 0, tid);
     else if (cb.use_lds) emit_rows<3, true>(k.c, cur.src, cur.dst, tile, s_tab, s_tab + TW, s_tab + 2 * TW, s_tab + 2 * TW + TH, cur.x0, cur.y0, cur.x1,
                                             cur.y1, cb.bx0a, cb.by0, cb.bw, tid);
@@ -873,10 +857,7 @@ __device__ __forceinline__ uint4 load_chunk_straddling(const uint8_t* rowp, int 
 }
 
 template <int CN> struct PlaneCfg {
-#ifndef VS_PLANE_THP
-#define VS_PLANE_THP 64
-#endif
-    static constexpr int THP = VS_PLANE_THP / CN;        // rows of a tile
+    static constexpr int THP = 64 / CN;                  // rows of a tile
     static constexpr int DB = 136 * CN + 8 * CN;         // staged bytes of a row (136 pixels + slack for the 8-byte tap read)
     // Row pitch of the staged box: a multiple of 128 bytes = of the 32 LDS banks.  The lanes of a tap read sit on consecutive dwords
     // of a row until the map's rotation moves them a source row down (or up), once per tile row for anything but a pure
@@ -914,30 +895,10 @@ __device__ __forceinline__ uint32_t plane_blend_px(const uint8_t* tl, const uint
     } else {
         addr = __mul24(SY >> 10, P::PB) + (SX >> 10) * CN;
     }
-#if VS_WARP_BLEND_LAB & 2          // (timing experiment: no tap reads, the same arithmetic)
-    const uint32_t ta = (uint32_t)(addr & ~3);
-    const uint32_t top = __builtin_amdgcn_alignbyte(ta, (uint32_t)SX, (uint32_t)addr), bot = __builtin_amdgcn_alignbyte((uint32_t)SY, ta, (uint32_t)addr);
-#else
     const uint32_t* tp = reinterpret_cast<const uint32_t*>(tl + (addr & ~3));
-#if VS_WARP_BLEND_LAB & 4          // (timing experiment: the reads as they are, no v_alignbyte)
-    const uint32_t top = tp[0] ^ tp[1], bot = tp[P::PB / 4] ^ tp[P::PB / 4 + 1];
-#else
     const uint32_t top = __builtin_amdgcn_alignbyte(tp[1], tp[0], (uint32_t)addr), bot = __builtin_amdgcn_alignbyte(tp[P::PB / 4 + 1], tp[P::PB / 4], (uint32_t)addr);
-#endif
-#endif
-#if VS_WARP_BLEND_LAB & 1          // (timing experiment: no weight reads)
-    LutY wy; wy.w0 = __uint_as_float((uint32_t)(SY & 0x3E0)); wy.w1 = wy.w0;
-    const uint32_t wx = (uint32_t)(SX & 0x3E0);
-#else
-#if VS_WARP_WY32
-    LutY wy;                       // (variant: W1 from the table, W0 = 32 * 2^121 - W1: 4 bytes of LDS less, one 2-cycle instruction more)
-    wy.w1 = *reinterpret_cast<const float*>(lut + 12 + (SY & 0x3E0));
-    wy.w0 = 0x1p126f - wy.w1;
-#else
     const LutY wy = *reinterpret_cast<const LutY*>(lut + 8 + (SY & 0x3E0));
-#endif
     const uint32_t wx = *reinterpret_cast<const uint32_t*>(lut + (CN == 1 ? 0 : 16) + (SX & 0x3E0));   // (32 - fx) | fx << 8  /  (32 - fx) | fx << 16
-#endif
     if (CN == 1) {
         float m = vlerp(__builtin_amdgcn_udot4(top, wx, 0u, false), __builtin_amdgcn_udot4(bot, wx, 0u, false), wy);
         asm("" : "+v"(m));            // (keeps the pixels' float operations apart: the packed f32 forms need moves and are no faster)
@@ -1019,14 +980,8 @@ __device__ __attribute__((noinline)) void plane_direct_tile(WarpCore c, const ui
                              min(y0 + TH * j + TH - 1, y1), bx0a, by0, bw, tid);
 }
 
-#ifndef VS_PLANE_WAVES
-#define VS_PLANE_WAVES 8
-#endif
-#ifndef VS_WARP_WY32
-#define VS_WARP_WY32 0
-#endif
 template <int CN>
-__global__ __launch_bounds__(NT, VS_PLANE_WAVES) void warp_plane_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
+__global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
                                                         uint32_t swh, uint32_t dwh, uint32_t flags, uint32_t mgx, uint32_t mgy) {
     typedef PlaneCfg<CN> P;
     __shared__ __attribute__((aligned(16))) uint8_t tile[P::ROWS * P::PB];
@@ -1100,8 +1055,7 @@ __global__ __launch_bounds__(NT, VS_PLANE_WAVES) void warp_plane_kernel(gtab_t t
                 const long long xb = (long long)bx0a * CN + 16 * ch;          // byte column of the chunk in the source row
                 if ((unsigned)y < (unsigned)c.sh) {
                     const uint8_t* row = src + (size_t)y * c.sstride;
-                    if (flags & 0x200u) {                                       // (lab, VS_WARP_LAB_SKIP 1: no staging loads - timing only)
-                    } else if (xb >= 0 && xb + 16 <= rowbytes && c.src_aligned) {
+                    if (xb >= 0 && xb + 16 <= rowbytes && c.src_aligned) {
                         d[k] = *reinterpret_cast<const uint4*>(row + xb);       // 4-byte aligned: bx0a is a multiple of 4 pixels
                     } else if (xb + 16 > 0 && xb < rowbytes) {
                         d[k] = load_chunk_straddling(row, (int)xb, (int)rowbytes, c.src_aligned && (rowbytes & 3) == 0);
@@ -1145,43 +1099,11 @@ __global__ __launch_bounds__(NT, VS_PLANE_WAVES) void warp_plane_kernel(gtab_t t
     }
     __syncthreads();
     // ---- output
-    if (flags & 0x400u) {            // (lab, VS_WARP_LAB_SKIP 2: the stores of a whole tile alone - timing only)
-        if (c.dst_aligned && x1 - x0 == TW - 1 && y1 - y0 == P::THP - 1) {
-            const uint32_t res[4] = {(uint32_t)ad[0], (uint32_t)bd[0], (uint32_t)ad[1], (uint32_t)bd[1]};
-            for (int r = 0; r < P::THP / TYN; r++)
-                plane_store4<CN>(dst + (size_t)(y0 + ty + TYN * r) * dstride + (size_t)x0 * CN + (uint32_t)(4 * CN) * L, res);
-        }
-        return;
-    }
     plane_blend_rows<CN>(c, tile, lut, s_row, ad, bd, L, ty, dst, dstride, x0, y0, x1, y1);
 }
 
 // Ints of table workspace per frame of dw x dh (see warp_tables_kernel).
 inline int tab_stride_of(int dw, int dh) { return tab_layout(dw, dh).stride; }
-
-// VS_WARP_TAB_KERNEL=0: BGR8 launches with tables take the general kernel as well (A/B measurements)
-bool tab_kernel_setting() {
-    static const bool v = [] { const char* e = lab_env("VS_WARP_TAB_KERNEL"); return !(e && e[0] == '0'); }();
-    return v;
-}
-
-// VS_WARP_PLANE_KERNEL=0 (lab): one- and two-channel launches with tables take the general kernel.  (Round 3 measured three more
-// forms of the plane kernel - 256 x 32 tiles, two staged copies, persistent with LDS-DMA staging: bit-identical, none faster;
-// scratch/k_warp_r3_plane_experiments.hip.txt)
-// VS_WARP_XCD_ORDER=0: plain (x, y, frame) tile order in the table kernels (A/B measurements)
-uint32_t xcd_order_flag() {
-    static const uint32_t v = [] {
-        const char* e = lab_env("VS_WARP_XCD_ORDER");
-        const char* d = lab_env("VS_WARP_LAB_SKIP");        // 1: no staging loads, 2: no blending, 3: both (plane kernel, timing only)
-        return ((e && e[0] == '0') ? 0u : 0x100u) | (d ? (uint32_t)(d[0] - '0') << 9 : 0u);
-    }();
-    return v;
-}
-
-int plane_kernel_setting() {
-    static const int v = [] { const char* e = lab_env("VS_WARP_PLANE_KERNEL"); return e && e[0] == '0' ? 0 : 1; }();
-    return v;
-}
 
 // what: VS_WARP_ALL = tables (when d_tabs is given) and warp; VS_WARP_TABLES_ONLY / VS_WARP_ONLY = the two halves apart, so
 // that a caller whose maps are ready long before it warps (the batch tail of the stabilizer) builds the tables then.
@@ -1194,21 +1116,23 @@ void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, int what, hipStream_t s
         if (what != VS_WARP_ONLY)
             hipLaunchKernelGGL(warp_tables_kernel, dim3((a.c.dw + a.c.dh + grid.x + grid.y + NT - 1) / NT, grid.z), dim3(NT), 0, st, a);
         if (what == VS_WARP_TABLES_ONLY) return;
-        const bool packs = a.c.sw < 65536 && a.c.sh < 65536 && a.c.dw < 65536 && a.c.dh < 65536 && a.c.sstride < (1ull << 32) && a.c.dstride < (1ull << 32);
+        // (the table kernels pack sizes into 16 bits and form row offsets with 24-bit multiplies: larger frames or pitches of
+        // 16 MiB and more take the general kernel)
+        const bool packs = a.c.sw < 65536 && a.c.sh < 65536 && a.c.dw < 65536 && a.c.dh < 65536 && a.c.sstride < (1ull << 24) && a.c.dstride < (1ull << 24);
         // XCD-aware tile order (tile_id): the reciprocals of the grid's x and y extents, and the flag only where they are exact
         auto order = [](const dim3& g, uint32_t* mgx, uint32_t* mgy) -> uint32_t {
             *mgx = (uint32_t)((0x100000000ull + g.x - 1) / g.x); *mgy = (uint32_t)((0x100000000ull + g.y - 1) / g.y);
             const unsigned long long n = (unsigned long long)g.x * g.y * g.z;
-            return (g.x > 1 || g.y > 1) && n * std::max(g.x, g.y) < (1ull << 31) && g.z < 65536 ? (xcd_order_flag() | (uint32_t)g.z << 16) : 0u;
+            return (g.x > 1 || g.y > 1) && n * std::max(g.x, g.y) < (1ull << 31) && g.z < 65536 ? (0x100u | (uint32_t)g.z << 16) : 0u;
         };
         uint32_t mgx = 0, mgy = 0;
-        if (CN == 3 && packs && tab_kernel_setting()) {
+        if (CN == 3 && packs) {
             // 12 dwords of arguments: all of them among the 14 the hardware preloads into scalar registers
             const uint32_t of = order(grid, &mgx, &mgy);
             hipLaunchKernelGGL(warp_tab_kernel, grid, dim3(NT), 0, st, (gtab_t)a.tabs, a.tab_stride, a.tab_row, a.tab_ad, (uint32_t)a.c.sstride,
                                (uint32_t)a.c.dstride, (uint32_t)a.c.sw | (uint32_t)a.c.sh << 16, (uint32_t)a.c.dw | (uint32_t)a.c.dh << 16,
                                (uint32_t)(a.c.src_aligned ? 1 : 0) | (uint32_t)(a.c.dst_aligned ? 2 : 0) | (uint32_t)a.c.border << 2 | of, mgx, mgy);
-        } else if (CN != 3 && packs && a.c.border == VS_BORDER_BLACK && plane_kernel_setting()) {
+        } else if (CN != 3 && packs && a.c.border == VS_BORDER_BLACK) {
             const dim3 pg(grid.x, (a.c.dh + PlaneCfg<CN>::THP - 1) / PlaneCfg<CN>::THP, grid.z);
             const uint32_t of = order(pg, &mgx, &mgy);
             hipLaunchKernelGGL((warp_plane_kernel<(CN == 3 ? 1 : CN)>), pg, dim3(NT), 0, st, (gtab_t)a.tabs, a.tab_stride, a.tab_row, a.tab_ad, (uint32_t)a.c.sstride,

@@ -23,7 +23,9 @@
 // push, but the device work of `batch` consecutive frames is issued together - one
 // launch per stage over all frames (argument tables in device memory), one ordered
 // tail kernel (selection + trajectory append + smoothing, state in LDS), one warp
-// launch for the frames of a batch - see run_batch().  DESIGN.md section 5 has the schedule.
+// launch for the frames of a batch.  There is ONE batch schedule, group_run(): a vs_batch
+// group runs it over the frames of all its streams, and a standalone instance in batch mode
+// owns a private group of one.  DESIGN.md section 5 has the schedule.
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -61,19 +63,16 @@ int ransac_fill_item(void* host_item, const float* d_from, const float* d_to, co
                      const RansacTables* tab, int32_t* d_counts, double* d_model, uint8_t* d_inliers, int32_t* d_info,
                      TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg, int have_prev_gray);
 int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_max, hipStream_t st);
-int launch_ransac_select_item(const void* host_item, hipStream_t st);
 size_t tail_item_bytes();
 void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out);
-int launch_ransac_tail_batch(const void* d_table, const void* d_tail, const void* d_tail_in, TrajState* traj, vs_debug_frame* dbg, int items,
-                             float* d_M_out, int smoothing_method, hipStream_t st);
 size_t tail_in_bytes();
 void ransac_item_set_tail_in(void* host_item, void* d_tail_in);
 size_t tail_seg_bytes();
-void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out, TrajState* traj, vs_debug_frame* dbg);
+void tail_fill_seg(void* host_seg, int first, int n, float* d_M_out, TrajState* traj, vs_debug_frame* dbg, int smoothing_method);
 void tail_item_set_seg(void* host_item, int seg);
 void ransac_item_set_last(void* host_item, int last);
 int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void* d_segs, const void* d_tail_in, int nsegs, int max_n, int items,
-                             int smoothing_method, hipStream_t st);
+                             int any_apart, hipStream_t st);
 size_t gftt_item_bytes();
 int gftt_fill_item(void* host_item, const uint8_t* d_gray, size_t stride, int w, int h, int max_corners, double quality,
                    double min_distance, int block_size, const GfttWork& wk, float* d_pts, int32_t* d_count);
@@ -110,11 +109,20 @@ using namespace vsd;
 
 struct vs_batch;
 int group_drain(vs_batch* g);
+int group_run(vs_batch* g);
+bool group_holds_warps(const vs_batch* g);
+vs_batch* group_new_own(vs_stab* s);
+void group_delete(vs_batch* g);
 
 struct vs_stab {
     vs_params_c p;
     int device = 0;
-    vs_batch* group = nullptr;      // member of a vs_batch: its batches are run by the group (one launch per stage over all streams)
+    // batch mode: the schedule that runs this stream's batches (one launch per stage over the frames of all its streams) - the
+    // vs_batch the stream was created in, or the private group of one a standalone instance owns (`own`, made by allocate())
+    vs_batch* group = nullptr;
+    vs_batch* own = nullptr;
+    bool member = false;            // stream of a vs_batch_create group: driven through vs_batch_* only
+    bool group_call = false;        // ... which set this around the vs_stab_* calls they make on a member
     hipStream_t st = nullptr;       // main
     hipStream_t st_pre = nullptr;
     hipStream_t st_det = nullptr;
@@ -214,9 +222,7 @@ struct vs_stab {
     std::vector<PendWarp> pend;
     size_t pend_stride = 0;
     double* d_MinvB[2] = {nullptr, nullptr};   // inverse maps of the pending frames, 12 doubles each; two sets
-    // coordinate tables of batched warp launches: [set] frame plane and [2 + set] chroma plane of the batch whose maps are in
-    // d_MinvB[set] (built behind the batch tail, used by the warps issued one run_batch later); [4] deferred warps
-    int32_t* d_tabs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t* d_tabs_def = nullptr;              // coordinate tables of a deferred warp launch
     int pend_set = 0;
     hipEvent_t ev_emit = nullptr, ev_warp[2] = {nullptr, nullptr};
     bool warp_valid[2] = {false, false};
@@ -234,39 +240,15 @@ struct vs_stab {
         int have_prev_gray;
     };
     std::vector<BFrame> bq;
-    int batch_id = 0;
     int kp_cur = 0, kp_next = 1;
     std::vector<GfttWork> gws;                       // one GFTT scratch per detection of a batch
     struct ItemBufs { float *next, *err, *vp, *vc; uint8_t *status, *inliers; int32_t *m, *info, *counts; double* model; };
     std::vector<ItemBufs> items;
-    // Host images of the argument tables of a batch, in page-locked memory so that their uploads are asynchronous (from
-    // pageable memory hipMemcpyAsync holds the host until the stream gets to the copy, and the host then no longer runs
-    // ahead of the GPU): four sets, batch k writes set k % 4 once the tail of batch k-4 has run.  On the device the tracker /
-    // scoring / tail tables exist twice (k & 1): batch k+1's are uploaded on `pre` while batch k's are still read on `main`.
-    uint8_t* h_tables = nullptr;                     // 4 x h_set_bytes
-    size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0;
-    uint8_t *d_lk_table[2] = {nullptr, nullptr}, *d_rs_table[2] = {nullptr, nullptr}, *d_gf_table = nullptr, *d_tail_table[2] = {nullptr, nullptr};
-    uint8_t* d_tail_in[2] = {nullptr, nullptr};     // per frame of a batch: what the selection leaves for the tail
-    ImgPair* d_pairs = nullptr;
-    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {};
-    bool bdet_valid[4] = {false, false, false, false};   // batch k % 4 ran a detection
-    int last_det_batch = -1;
     // what the debug getters read (last analysed frame)
     const float* dbg_prev_pts = nullptr; const float* dbg_next = nullptr;
     const uint8_t *dbg_status = nullptr, *dbg_inliers = nullptr;
     const float* dbg_det_pts = nullptr; const int32_t* dbg_det_n = nullptr;
     const int32_t* dbg_gftt_counters = nullptr;
-    // batch mode: the warps of batch k are issued during run_batch(k+1), behind the detection of batch k+1, so
-    // that the (HBM-bound) warp has the GPU to itself: pre/det of k+1 overlap the tracking and tail of k instead
-    struct ReadyWarps {
-        bool valid = false, tabs_built = false;
-        int n = 0, set = 0;
-        size_t stride = 0;
-        const uint8_t* srcs[BATCH_MAX];
-        uint8_t* dsts[BATCH_MAX];
-        int slots[BATCH_MAX];
-    } ready;
-    int last_warp_set = -1;
     // stage profiling (HIP events on the stream the stage runs on)
     int prof_mode = 0;
     struct Pending { hipEvent_t a, b; int stage; };
@@ -333,15 +315,13 @@ void out_size(const vs_stab* s, int w, int h, int* ow, int* oh) {
 }
 
 int flush_warps(vs_stab* s, bool on_main = false);
-int run_batch(vs_stab* s);
-int launch_ready(vs_stab* s);
 
 // Batch mode: everything queued so far is analysed and its warps are issued (nothing stays deferred).
 int drain_batch(vs_stab* s) {
-    if (s->group) { const int rc = group_drain(s->group); if (rc != VS_OK) s->err = get_last_error(); return rc; }
-    S_TRY(s, run_batch(s));
-    S_TRY(s, launch_ready(s));
-    return VS_OK;
+    if (!s->group) return VS_OK;
+    const int rc = group_drain(s->group);
+    if (rc != VS_OK) s->err = get_last_error();
+    return rc;
 }
 
 int sync_all(vs_stab* s) {
@@ -362,8 +342,10 @@ void free_all(vs_stab* s) {
     if (s->d_tmp) (void)hipFree(s->d_tmp);
     if (s->d_padB) (void)hipFree(s->d_padB);
     s->d_padB = nullptr;
-    if (s->h_tables) (void)hipHostFree(s->h_tables);
-    s->h_tables = nullptr;
+    if (s->own) {                       // the private schedule goes with the buffers it was sized for
+        group_delete(s->own);
+        s->own = nullptr; s->group = nullptr;
+    }
     // (d_fade, the fade history, outlives vs_stab_clean like borderHistory_ outlives Stabilizer::clean())
     if (s->d_out) (void)hipFree(s->d_out);
     for (auto& h : s->d_hold) { if (h) (void)hipFree(h); h = nullptr; }
@@ -430,8 +412,12 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     s->pyr.assign(s->npyr, Pyramid());
     s->d_pts.assign(nkp, nullptr); s->d_npts.assign(nkp, nullptr); s->pts_cap.assign(nkp, 0);
     s->items.assign(B, vs_stab::ItemBufs());
-    s->bq.clear(); s->batch_id = 0; s->kp_cur = 0; s->kp_next = 1; s->last_det_batch = -1; s->ready.valid = false; s->last_warp_set = -1;
-    for (auto& v : s->bdet_valid) v = false;
+    s->bq.clear(); s->kp_cur = 0; s->kp_next = 1;
+    if (s->batch_active && !s->group) {            // a standalone instance: a group of one runs its batches
+        s->own = group_new_own(s);
+        if (!s->own) return fail(s, VS_ERR_HIP, get_last_error());
+        s->group = s->own;
+    }
     // (the frame queue ring - 128 frames, 3.2 GB at 4K BGR8 - is allocated by the first push that copies a frame in: a
     // stream that only ever hands over device frames in zero-copy mode never needs it)
     s->free_slots.clear();
@@ -460,19 +446,11 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
         o_it[k].m = take(16); o_it[k].info = take(16); o_it[k].counts = take((size_t)s->p.ransac_max_iters * 4);
         o_it[k].model = take(48);
     }
-    const size_t o_gft = take(gftt_item_bytes() * ngw);
-    const size_t o_lkt[2] = {take(lk_item_bytes() * B), take(lk_item_bytes() * B)};
-    const size_t o_rst[2] = {take(ransac_item_bytes() * B), take(ransac_item_bytes() * B)};
-    const size_t o_tail[2] = {take(tail_item_bytes() * B), take(tail_item_bytes() * B)};
-    const size_t o_tin[2] = {take(tail_in_bytes() * B), take(tail_in_bytes() * B)};
-    const size_t o_pairs = take(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
     size_t o_traj = take(sizeof(TrajState)), o_M = take(96), o_Minv = take(96), o_dbg = take(sizeof(vs_debug_frame));
     size_t o_MinvB[2] = {take((size_t)BATCH_MAX * 96), take((size_t)BATCH_MAX * 96)};
     int tow, toh;
     out_size(s, w, h, &tow, &toh);
-    const size_t tab_bytes = warp_tabs_ints(std::max(w, tow), std::max(h, toh), BATCH_MAX) * sizeof(int32_t);
-    size_t o_tabs[5];
-    for (auto& o : o_tabs) o = take(tab_bytes);
+    const size_t o_tabs = take(warp_tabs_ints(std::max(w, tow), std::max(h, toh), WARP_BATCH_MAX) * sizeof(int32_t));
     S_HIP(s, hipMalloc((void**)&s->d_all, off));
     S_HIP(s, hipMemsetAsync(s->d_all, 0, off, s->st));
     uint8_t* b = s->d_all;
@@ -495,23 +473,10 @@ int allocate_buffers(vs_stab* s, int w, int h, int fmt) {
     s->d_next = s->items[0].next; s->d_err = s->items[0].err; s->d_vp = s->items[0].vp; s->d_vc = s->items[0].vc;
     s->d_status = s->items[0].status; s->d_inliers = s->items[0].inliers;
     s->d_m = s->items[0].m; s->d_info = s->items[0].info; s->d_counts = s->items[0].counts; s->d_model = s->items[0].model;
-    s->d_gf_table = b + o_gft;
-    for (int i = 0; i < 2; i++) { s->d_lk_table[i] = b + o_lkt[i]; s->d_rs_table[i] = b + o_rst[i]; s->d_tail_table[i] = b + o_tail[i]; s->d_tail_in[i] = b + o_tin[i]; }
-    s->d_pairs = (ImgPair*)(b + o_pairs);
-    {
-        size_t ho = 0;
-        auto htake = [&](size_t bytes) { size_t o = ho; ho += (bytes + 255) & ~(size_t)255; return o; };
-        s->ho_pairs = htake(sizeof(ImgPair) * B * (2 + 2 * MAX_PYR));
-        s->ho_lk = htake(lk_item_bytes() * B); s->ho_rs = htake(ransac_item_bytes() * B);
-        s->ho_tail = htake(tail_item_bytes() * B); s->ho_gf = htake(gftt_item_bytes() * ngw);
-        s->h_set_bytes = ho;
-        S_HIP(s, hipHostMalloc((void**)&s->h_tables, 4 * ho));
-        memset(s->h_tables, 0, 4 * ho);
-    }
     s->d_traj = (TrajState*)(b + o_traj);
     s->d_M = (float*)(b + o_M); s->d_Minv = (double*)(b + o_Minv); s->d_dbg = (vs_debug_frame*)(b + o_dbg);
     s->d_MinvB[0] = (double*)(b + o_MinvB[0]); s->d_MinvB[1] = (double*)(b + o_MinvB[1]);
-    for (int i = 0; i < 5; i++) s->d_tabs[i] = (int32_t*)(b + o_tabs[i]);
+    s->d_tabs_def = (int32_t*)(b + o_tabs);
     s->pend.clear(); s->pend_set = 0; s->warp_valid[0] = s->warp_valid[1] = false;
     // GFTT scratch sized for the larger of the two detection images
     const int gmaxw = std::max(s->aw, 480), gmaxh = std::max(s->ah, 270);
@@ -711,7 +676,7 @@ int flush_warps(vs_stab* s, bool on_main) {
     {
         StageScope t(s, VS_STAGE_WARP, ws);
         rc = launch_warp_affine_list(srcs, dsts, n, s->src_pitch, s->w, s->h, s->pend_stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[set], 12, n >= 4 ? s->d_tabs[4] : nullptr, ws);
+                                     s->d_MinvB[set], 12, n >= 4 ? s->d_tabs_def : nullptr, ws);
     }
     if (hipEventRecord(s->ev_warp[set], ws) == hipSuccess) s->warp_valid[set] = true;
     for (int i = 0; i < n; i++) {
@@ -744,82 +709,6 @@ int defer_output(vs_stab* s, int idx, const uint8_t* frame, uint8_t* d_out, size
     s->pend_stride = out_stride;
     if ((int)s->pend.size() >= s->warp_batch) S_TRY(s, flush_warps(s));
     return VS_OK;
-}
-
-// Batch mode: the warps of the batch whose tail was queued last (`what` = VS_WARP_ONLY / VS_WARP_ALL), or only the coordinate
-// tables of those warps (VS_WARP_TABLES_ONLY: queued right behind the tail, so they are ready long before the warps).
-int ready_launches(vs_stab* s, int what) {
-    vs_stab::ReadyWarps& R = s->ready;
-    hipStream_t st = s->st;
-    const vs_params_c& p = s->p;
-    const int bsz = p.border_size;
-    const bool pad = bsz > 0 && !p.crop_n_zoom;                                                       // Stabilizer.cpp:981-990
-    const bool crop = bsz > 0 && p.crop_n_zoom && s->w - 2 * bsz > 0 && s->h - 2 * bsz > 0;            // :1108-1124
-    int rc = VS_OK;
-    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes WARP_BATCH_MAX frames per launch
-        const int m = std::min(WARP_BATCH_MAX, R.n - i0);
-        const bool tabs = m >= 4;                                           // (the table set of a batch holds BATCH_MAX frames)
-        if (what == VS_WARP_TABLES_ONLY && !tabs) continue;
-        const int w = tabs ? what : VS_WARP_ALL;
-        if (pad || crop) {
-            // pad: the frames get their border first and the padded frames are warped into the (larger) results;
-            // crop-and-zoom: the frames are warped into scratch frames, whose inner part is then resized to the results
-            const uint8_t* srcs[WARP_BATCH_MAX];
-            uint8_t* dsts[WARP_BATCH_MAX];
-            const int pw = pad ? s->w + 2 * bsz : s->w, ph = pad ? s->h + 2 * bsz : s->h;
-            const size_t prow = (size_t)pw * s->cn;
-            for (int i = 0; i < m; i++) {
-                uint8_t* scratch = s->d_padB + (size_t)(i0 + i) * s->pad_frame_bytes;
-                srcs[i] = pad ? scratch : R.srcs[i0 + i];
-                dsts[i] = pad ? R.dsts[i0 + i] : scratch;
-                if (pad && what != VS_WARP_TABLES_ONLY && rc == VS_OK)
-                    rc = launch_make_border(R.srcs[i0 + i], s->src_pitch, s->w, s->h, s->cn, scratch, prow, bsz, p.border_type, st);
-            }
-            if (rc == VS_OK)
-                rc = launch_warp_affine_list(srcs, dsts, m, pad ? prow : s->src_pitch, pw, ph, pad ? R.stride : prow, pw, ph, s->cn,
-                                             s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] + i0 * warp_tabs_ints(pw, ph, 1) : nullptr, st, w);
-            for (int i = 0; crop && what != VS_WARP_TABLES_ONLY && i < m && rc == VS_OK; i++)
-                rc = launch_resize_linear(dsts[i] + ((size_t)bsz * s->w + bsz) * s->cn, prow, s->w - 2 * bsz, s->h - 2 * bsz, s->cn,
-                                          R.dsts[i0 + i], R.stride, s->orig_w, s->orig_h, st);
-            continue;
-        }
-        rc = launch_warp_affine_list(R.srcs + i0, R.dsts + i0, m, s->src_pitch, s->w, s->h, R.stride, s->w, s->h, s->cn,
-                                     s->d_MinvB[R.set] + 12 * i0, 12, tabs ? s->d_tabs[R.set] + i0 * warp_tabs_ints(s->w, s->h, 1) : nullptr, st, w);
-        if (rc == VS_OK && s->fmt == VS_FMT_NV12) {
-            // interleaved chroma plane: half size, two channels, the map with the halved translation
-            const uint8_t* us[WARP_BATCH_MAX];
-            uint8_t* ud[WARP_BATCH_MAX];
-            for (int i = 0; i < m; i++) {
-                us[i] = R.srcs[i0 + i] + src_uv(s);
-                ud[i] = R.dsts[i0 + i] + dst_uv(s, R.dsts[i0 + i], R.stride);
-            }
-            rc = launch_warp_affine_list(us, ud, m, s->src_pitch, s->w / 2, s->h / 2, R.stride, s->w / 2, s->h / 2, 2,
-                                         s->d_MinvB[R.set] + 12 * i0 + 6, 12, tabs ? s->d_tabs[2 + R.set] + i0 * warp_tabs_ints(s->w / 2, s->h / 2, 1) : nullptr, st, w);
-        }
-    }
-    if (rc != VS_OK) s->err = get_last_error();
-    return rc;
-}
-
-int launch_ready(vs_stab* s) {
-    vs_stab::ReadyWarps& R = s->ready;
-    if (!R.valid) return VS_OK;
-    hipStream_t st = s->st;
-    int rc;
-    {
-        StageScope t(s, VS_STAGE_WARP, st);
-        rc = ready_launches(s, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL);
-    }
-    if (hipEventRecord(s->ev_warp[R.set], st) == hipSuccess) { s->warp_valid[R.set] = true; s->last_warp_set = R.set; }
-    if (s->ev_dev_warp && hipEventRecord(s->ev_dev_warp, st) == hipSuccess) s->dev_warp_valid->store(true, std::memory_order_release);
-    for (int i = 0; i < R.n; i++) {
-        const int slot = R.slots[i];
-        if (slot < 0) continue;          // zero-copy: the frame is the caller's
-        if (hipEventRecord(s->ev_slot[slot], st) == hipSuccess) { s->slot_valid[slot] = true; }
-        s->free_slots.push_back(slot);
-    }
-    R.valid = false;
-    return rc;
 }
 
 // applyNextSmoothTransform (Stabilizer.cpp:763-1137) into d_out (device), on `main`
@@ -959,226 +848,11 @@ int batch_enqueue(vs_stab* s, const uint8_t* frame, int slot, int f, uint8_t* d_
         *produced = 1;
     }
     s->bq.push_back(b);
-    if (!s->group && (int)s->bq.size() >= s->batch) S_TRY(s, run_batch(s));     // (a group runs its members' batches together)
-    return VS_OK;
-}
-
-int run_batch(vs_stab* s) {
-    const int n = (int)s->bq.size();
-    if (n == 0) return VS_OK;
-    const vs_params_c& p = s->p;
-    const int k = s->batch_id++;
-    // host images of this batch's tables: the set batch k-4 used (its tail, the last reader of anything uploaded from it, has run
-    // by now unless the host is four batches ahead of the GPU - then it waits here)
-    if (k >= 4) S_HIP(s, hipEventSynchronize(s->ev_blk[k % 4]));
-    uint8_t* hset = s->h_tables + (size_t)(k % 4) * s->h_set_bytes;
-    ImgPair* h_pairs = reinterpret_cast<ImgPair*>(hset + s->ho_pairs);
-    uint8_t *h_lk = hset + s->ho_lk, *h_rs = hset + s->ho_rs, *h_tail = hset + s->ho_tail, *h_gf = hset + s->ho_gf;
-    const int dset = k & 1;
-    // ---- pre: gray images and pyramids of all frames of the batch, one launch per stage and level
-    if (k >= 2) {
-        // ring reuse: these slots were read by the analysis two batches ago (npyr = 2*batch + 2)
-        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_blk[(k - 2) % 4], 0));
-        if (s->bdet_valid[(k - 2) % 4]) S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_bdet[(k - 2) % 4], 0));
+    // a full batch runs (a vs_batch runs the batches of its streams together: vs_batch_push_dev decides)
+    if (s->group == s->own && (int)s->bq.size() >= s->batch) {
+        const int rc = group_run(s->group);
+        if (rc != VS_OK) { s->err = get_last_error(); return rc; }
     }
-    if (s->ev_dev_warp && s->dev_warp_valid->load(std::memory_order_acquire) && lab_env("VS_STAB_NO_WARP_GUARD") == nullptr && lab_env("VS_STAB_OWN_WARP_GUARD") == nullptr) {
-        // several instances share the streams: the last batched warp of ANY of them (the instances' launches interleave in
-        // the shared queues, so that is the one in front of this batch's kernels)
-        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_dev_warp, 0));
-    } else if (s->last_warp_set >= 0 && lab_env("VS_STAB_NO_WARP_GUARD") == nullptr) {
-        // keep the HBM-bound warp alone on the GPU even when the host runs batches ahead: this batch's gray /
-        // pyramid / detection kernels start after the warps issued during the previous run_batch (batch k-2's)
-        S_HIP(s, hipStreamWaitEvent(s->st_pre, s->ev_warp[s->last_warp_set], 0));
-    }
-    // ---- argument tables of the tracker, the scoring and the tail: filled here (they do not depend on this batch's images),
-    // uploaded at the end of `pre`; the device copies alternate because `main` may still be in the batch before.
-    int n_max = 0;
-    for (int i = 0; i < n; i++) {
-        const vs_stab::BFrame& b = s->bq[i];
-        const vs_stab::ItemBufs& it = s->items[i];
-        LKLevel L[MAX_PYR];
-        for (int l = 0; l <= s->levels; l++) {
-            L[l].prev = s->pyr[b.pv].img[l]; L[l].next = s->pyr[b.c].img[l]; L[l].deriv = s->pyr[b.pv].der[l];
-            L[l].w = s->lw[l]; L[l].h = s->lh[l]; L[l].stride = s->lw[l];
-        }
-        const int cap = std::max(b.lk_cap, 0);
-        n_max = std::max(n_max, cap);
-        S_TRY(s, lk_fill_item(h_lk + lk_item_bytes() * i, L, s->levels, s->d_pts[b.lk_buf], cap, s->d_npts[b.lk_buf],
-                              it.next, it.status, it.err, p.lk_win_size, p.lk_max_iters, p.lk_epsilon));   // :611-619
-        S_TRY(s, ransac_fill_item(h_rs + ransac_item_bytes() * i, s->d_pts[b.lk_buf], it.next, it.status, cap,
-                                  s->d_npts[b.lk_buf], it.vp, it.vc, it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab,
-                                  it.counts, it.model, it.inliers, it.info, s->d_traj, &s->tp, s->d_dbg, b.have_prev_gray));
-        ransac_item_set_tail_in(h_rs + ransac_item_bytes() * i, s->d_tail_in[dset] + tail_in_bytes() * i);
-    }
-    // the tail's table as well (which outputs become due and where their maps go is known on the host)
-    S_TRY(s, flush_warps(s));                      // the list of pending warps starts empty
-    const int set = s->pend_set;
-    bool tail_any = false;
-    for (int i = 0; i < n; i++) tail_any |= s->bq[i].out_due;
-    for (int i = 0; i < n; i++) {
-        const vs_stab::BFrame& b = s->bq[i];
-        double* minv = nullptr;
-        if (b.out_due) {
-            if (!s->pend.empty() && s->pend_stride != b.out_stride) return fail(s, VS_ERR_INVALID_ARG, "batch mode: the output stride must not change within a batch");
-            minv = s->d_MinvB[set] + 12 * s->pend.size();
-            s->pend.push_back({b.out_frame, b.d_out, b.out_slot});
-            s->pend_stride = b.out_stride;
-        }
-        tail_fill_item(h_tail + tail_item_bytes() * i, b.out_due ? 1 : 0, b.out_idx, minv);
-    }
-    if (s->bq[0].prev_small) {   // :598-603 (once: 480x270 -> analysis size)
-        StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
-        S_TRY(s, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[s->bq[0].pv].img[0], s->aw, s->aw, s->ah, s->st_pre));
-        S_TRY(s, build_pyramid(s, s->bq[0].pv, s->st_pre));
-    }
-    {
-        // pair tables: [0] frame -> img[0]; [1..levels] img[l-1] -> img[l]; [levels+1 ..] img[l] -> der[l]
-        const int L = s->levels;
-        int aligned = 1;
-        // level-0 pairs: the frames that re-detect first, so that the detector can start after a first, smaller launch
-        int n_first = 0, n_rest = 0;
-        for (int i = 0; i < n; i++) n_first += s->bq[i].detect ? 1 : 0;
-        const int n_detect = n_first;
-        n_first = 0;
-        for (int i = 0; i < n; i++) {
-            const vs_stab::BFrame& b = s->bq[i];
-            const Pyramid& P = s->pyr[b.c];
-            const int slot = b.detect ? n_first++ : n_detect + n_rest++;
-            h_pairs[slot] = ImgPair{b.frame, P.img[0]};
-            if ((uintptr_t)b.frame % 8) aligned = 0;
-            for (int l = 1; l <= L; l++) h_pairs[(size_t)l * n + i] = ImgPair{P.img[l - 1], P.img[l]};
-            for (int l = 0; l <= L; l++) h_pairs[(size_t)(L + 1 + l) * n + i] = ImgPair{P.img[l], P.der[l]};
-        }
-        S_HIP(s, hipMemcpyAsync(s->d_pairs, h_pairs, sizeof(ImgPair) * n * (2 * L + 2), hipMemcpyHostToDevice, s->st_pre));
-        {
-            StageScope t(s, VS_STAGE_GRAY, s->st_pre);
-            // NV12: the Y plane is the gray image (SURVEY G1: no reference path; same policy as the per-frame pipeline)
-            const int gfmt = s->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s->fmt;
-            const int n_a = (n_detect > 0 && n_detect < n) ? n_detect : n;
-            S_TRY(s, launch_resize_gray_batch(s->d_pairs, n_a, s->src_pitch, s->w, s->h, gfmt, s->aw, s->aw, s->ah, aligned, s->st_pre));  // :448-450
-            S_HIP(s, hipEventRecord(s->ev_bgray, s->st_pre));  // the detector needs the analysis images of its frames only
-            if (n_a < n)
-                S_TRY(s, launch_resize_gray_batch(s->d_pairs + n_a, n - n_a, s->src_pitch, s->w, s->h, gfmt, s->aw, s->aw, s->ah, aligned, s->st_pre));
-        }
-        // the tracker / scoring / tail tables go up here, in the middle of `pre` (which has slack): on `main` they sat between
-        // the tail of the batch before and its warps; in front of the gray stage they delayed the detector; at the end of
-        // `pre` they delayed the event the warps wait for
-        S_HIP(s, hipMemcpyAsync(s->d_lk_table[dset], h_lk, lk_item_bytes() * n, hipMemcpyHostToDevice, s->st_pre));
-        S_HIP(s, hipMemcpyAsync(s->d_rs_table[dset], h_rs, ransac_item_bytes() * n, hipMemcpyHostToDevice, s->st_pre));
-        S_HIP(s, hipMemcpyAsync(s->d_tail_table[dset], h_tail, tail_item_bytes() * n, hipMemcpyHostToDevice, s->st_pre));
-        StageScope t(s, VS_STAGE_PYRAMID, s->st_pre);
-        // One launch per level (pyr_level_kernel): derivatives of level l and the image of level l+1 from one staged read of
-        // level l.  83.0 k -> 92.2 k frames/s at 1080p against the two stencils as separate launches (VS_STAB_SPLIT_PYRAMID=1,
-        // the schedule before): 3 launches instead of 5, level 0 of a batch 35 us instead of 37 + 61, and the detector's
-        // min-eigenvalue launch no longer shares the GPU with a 60 us pyrDown.  (The first version of the kernel, with
-        // byte-wide LDS reads, took 81 us for level 0 and lost: 77.6 k.)
-        if (lab_env("VS_STAB_SPLIT_PYRAMID") != nullptr) {
-            for (int l = 1; l <= L; l++)
-                S_TRY(s, launch_pyr_down_batch(s->d_pairs + (size_t)l * n, n, s->lw[l - 1], s->lw[l - 1], s->lh[l - 1], s->lw[l], s->st_pre));
-            for (int l = 0; l <= L; l++)
-                S_TRY(s, launch_scharr_batch(s->d_pairs + (size_t)(L + 1 + l) * n, n, s->lw[l], s->lw[l], s->lh[l], s->st_pre));
-        } else {
-            // one launch per level: derivatives of level l and the image of level l+1 from one staged read of level l
-            for (int l = 0; l <= L; l++)
-                S_TRY(s, launch_pyr_level_batch(s->d_pairs + (size_t)(L + 1 + l) * n, l < L ? s->d_pairs + (size_t)(l + 1) * n : nullptr, n,
-                                                s->lw[l], s->lw[l], s->lh[l], l < L ? s->lw[l + 1] : 0, s->st_pre));
-        }
-    }
-    S_HIP(s, hipEventRecord(s->ev_bpre, s->st_pre));
-    // ---- det: every frame of the batch that re-detects, one launch per GFTT stage
-    int ndet = 0;
-    for (int i = 0; i < n; i++) {
-        const vs_stab::BFrame& b = s->bq[i];
-        if (!b.detect) continue;
-        S_TRY(s, gftt_fill_item(h_gf + gftt_item_bytes() * ndet, s->pyr[b.c].img[0], s->aw, s->aw, s->ah,
-                                s->pts_cap[b.det_buf], 0.02, 15.0, 3, s->gws[ndet], s->d_pts[b.det_buf], s->d_npts[b.det_buf]));
-        s->dbg_det_pts = s->d_pts[b.det_buf]; s->dbg_det_n = s->d_npts[b.det_buf];
-        s->dbg_gftt_counters = s->gws[ndet].counters;
-        ndet++;
-    }
-    s->last_detected = s->bq[n - 1].detect;
-    if (ndet > 0) {
-        // starts as soon as the analysis images exist, next to the pyramid levels of this batch and the tracking of the
-        // previous one (VS_STAB_DET_AFTER_PRE=1: after the whole pre stage, the schedule before this was measured)
-        // (the table and the reset of the counters first: they are through by the time the analysis images are)
-        S_HIP(s, hipMemcpyAsync(s->d_gf_table, h_gf, gftt_item_bytes() * ndet, hipMemcpyHostToDevice, s->st_det));
-        // keypoint buffers are recycled after B + 4 detections (two batches): the tracking of the batch before
-        // the previous one must have read them (the GFTT scratch is only touched on this stream)
-        if (k >= 2) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 2) % 4], 0));
-        S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 1));
-        S_HIP(s, hipStreamWaitEvent(s->st_det, lab_env("VS_STAB_DET_AFTER_PRE") ? s->ev_bpre : s->ev_bgray, 0));
-        {
-            StageScope t(s, VS_STAGE_GFTT, s->st_det);
-            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 4));   // :740-744: block size 3
-            // (VS_STAB_NMS_AFTER_TAIL=1: the NMS launch waits for the ordered tail of the batch before this one - one workgroup
-            // whose chain takes 10 - 25 us alone and 85 us beside this launch.  Measured, three alternating pairs on one box:
-            // 99.5 k frames/s with the wait against 101.4 k without - the warps then start under the corner selection.)
-            if (k >= 1 && lab_env("VS_STAB_NMS_AFTER_TAIL") != nullptr) S_HIP(s, hipStreamWaitEvent(s->st_det, s->ev_blk[(k - 1) % 4], 0));
-            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 5));
-            // the wide launches of the detection are through: the warps of the batch before may go (below); the selection -
-            // one workgroup per image - runs beside them
-            S_HIP(s, hipEventRecord(s->ev_bnms, s->st_det));
-            S_TRY(s, launch_gftt_batch(s->d_gf_table, ndet, s->aw, s->ah, 3, s->st_det, 3));
-        }
-        S_HIP(s, hipEventRecord(s->ev_bdet[k % 4], s->st_det));
-        s->last_det_batch = k;
-    }
-    s->bdet_valid[k % 4] = ndet > 0;
-    // ---- main: tracking and hypothesis scoring of all frames, one launch each
-    hipStream_t st = s->st;
-    S_HIP(s, hipStreamWaitEvent(st, s->ev_bpre, 0));
-    if (s->pts_pending[0]) { S_HIP(s, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
-    const bool wait_det = s->last_det_batch >= 0 && s->last_det_batch >= k - 1;
-    const bool early = wait_det && s->last_det_batch == k && lab_env("VS_STAB_WARP_AFTER_SELECT") == nullptr;
-    if (early) S_HIP(s, hipStreamWaitEvent(st, s->ev_bnms, 0));
-    else if (wait_det) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));
-    // `main` has now waited for this batch's gray / pyramid work and the wide launches of its detection: the warps of the
-    // PREVIOUS batch go out here, before this batch's tracking, with nothing but the corner selection (16 workgroups)
-    // beside them on the GPU
-    S_TRY(s, launch_ready(s));
-    if (early) S_HIP(s, hipStreamWaitEvent(st, s->ev_bdet[s->last_det_batch % 4], 0));       // the tracker needs the selected corners
-    {
-        StageScope t(s, VS_STAGE_LK, st);
-        S_TRY(s, launch_pyr_lk_batch(s->d_lk_table[dset], n, n_max, p.lk_win_size, st));
-    }
-    {
-        StageScope t(s, VS_STAGE_RANSAC, st);
-        S_TRY(s, launch_ransac_score_batch(s->d_rs_table[dset], n, p.ransac_max_iters, n_max, st));
-    }
-    if (s->dbg_delay_us > 0) S_TRY(s, launch_spin(s->dbg_delay_us, st));
-    // ---- ordered tail, ONE launch: per frame in push order, selection + trajectory append (:644-693), then the
-    // map of the output that has become due (applyNextSmoothTransform sees exactly the transforms appended so
-    // far); all due warps of the batch then leave as one launch.
-    {
-        if (tail_any && s->warp_valid[set]) {      // the previous user of this set of maps must have read them
-            S_HIP(s, hipStreamWaitEvent(st, s->ev_warp[set], 0));
-            s->warp_valid[set] = false;
-        }
-        {
-            StageScope t(s, VS_STAGE_TRAJ, st);
-            S_TRY(s, launch_ransac_tail_batch(s->d_rs_table[dset], s->d_tail_table[dset], s->d_tail_in[dset], s->d_traj, s->d_dbg, n, s->d_M, p.smoothing_method, st));
-        }
-        // the keypoint and pyramid buffers of this batch may be recycled (two batches on) once the tail, which still reads
-        // the points and their counts, has run
-        S_HIP(s, hipEventRecord(s->ev_blk[k % 4], st));
-        // the warps of this batch wait for the next run_batch (or a drain)
-        vs_stab::ReadyWarps& R = s->ready;
-        R.n = (int)s->pend.size(); R.set = set; R.stride = s->pend_stride; R.valid = R.n > 0;
-        for (int i = 0; i < R.n; i++) { R.srcs[i] = s->pend[i].src; R.dsts[i] = s->pend[i].dst; R.slots[i] = s->pend[i].slot; }
-        s->pend.clear();
-        if (R.valid) s->pend_set = set ^ 1;
-        // the maps of these warps exist once the tail has run: their coordinate tables are built right behind it
-        R.tabs_built = false;
-        if (R.valid && lab_env("VS_STAB_TABLES_WITH_WARP") == nullptr) {
-            StageScope t(s, VS_STAGE_WARP_TABLES, st);
-            S_TRY(s, ready_launches(s, VS_WARP_TABLES_ONLY));
-            R.tabs_built = true;
-        }
-    }
-    const vs_stab::BFrame& lb = s->bq[n - 1];
-    s->dbg_prev_pts = s->d_pts[lb.lk_buf]; s->dbg_next = s->items[n - 1].next;
-    s->dbg_status = s->items[n - 1].status; s->dbg_inliers = s->items[n - 1].inliers;
-    s->bq.clear();
     return VS_OK;
 }
 
@@ -1290,9 +964,6 @@ void destroy_events(vs_stab* s) {
     for (auto& e : s->ev_slot) kill(e);
     kill(s->ev_first); kill(s->ev_hold);
     kill(s->ev_emit); kill(s->ev_warp[0]); kill(s->ev_warp[1]);
-    kill(s->ev_bpre); kill(s->ev_bgray); kill(s->ev_bnms);
-    for (auto& e : s->ev_bdet) kill(e);
-    for (auto& e : s->ev_blk) kill(e);
 }
 
 int create_events(vs_stab* s) {
@@ -1304,18 +975,12 @@ int create_events(vs_stab* s) {
     for (auto& e : s->ev_slot) S_HIP(s, mk(e));
     S_HIP(s, mk(s->ev_first)); S_HIP(s, mk(s->ev_hold));
     S_HIP(s, mk(s->ev_emit)); S_HIP(s, mk(s->ev_warp[0])); S_HIP(s, mk(s->ev_warp[1]));
-    S_HIP(s, mk(s->ev_bpre));
-    S_HIP(s, mk(s->ev_bgray));
-    S_HIP(s, mk(s->ev_bnms));
-    for (auto& e : s->ev_bdet) S_HIP(s, mk(e));
-    for (auto& e : s->ev_blk) S_HIP(s, mk(e));
     return VS_OK;
 }
 
 }  // namespace
 
-// All instances of a process on one device share ONE set of four HIP streams (unless VS_STAB_PRIVATE_STREAMS
-// is set).  Every instance's launches are already wide in batch mode, and the runtime maps HIP streams onto a
+// All instances of a process on one device share ONE set of four HIP streams.  Every instance's launches are already wide in batch mode, and the runtime maps HIP streams onto a
 // handful of hardware queues: with four private streams per instance, 2 instances ran at 0.9x and 8 instances
 // at 0.15x of ONE instance's total throughput; on shared streams the instances simply take turns.
 namespace {
@@ -1330,16 +995,6 @@ std::mutex g_pool_mutex;
 std::map<int, StreamPool> g_pools;
 
 hipError_t make_streams(hipStream_t* st, hipStream_t* pre, hipStream_t* det, hipStream_t* warp) {
-    if (const char* m = lab_env("VS_STAB_STREAM_LAYOUT")) {
-        // experiment switch: "1" = everything on one stream, "2" = pre+det share one stream, main has its own
-        hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-        if (e != hipSuccess) return e;
-        if (m[0] == '1') { *pre = *st; *det = *st; *warp = *st; return hipSuccess; }
-        e = hipStreamCreateWithFlags(pre, hipStreamNonBlocking);
-        if (e != hipSuccess) return e;
-        *det = *pre; *warp = *st;
-        return hipSuccess;
-    }
     hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(pre, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(det, hipStreamNonBlocking);
@@ -1352,7 +1007,6 @@ hipError_t make_streams(hipStream_t* st, hipStream_t* pre, hipStream_t* det, hip
 }
 
 hipError_t acquire_streams(vs_stab* s) {
-    if (lab_env("VS_STAB_PRIVATE_STREAMS")) return make_streams(&s->st, &s->st_pre, &s->st_det, &s->st_warp);
     std::lock_guard<std::mutex> g(g_pool_mutex);
     StreamPool& p = g_pools[s->device];
     if (p.refs == 0) {
@@ -1369,13 +1023,7 @@ hipError_t acquire_streams(vs_stab* s) {
 }
 
 void release_streams(vs_stab* s) {
-    if (!s->shared_streams) {
-        if (s->st) (void)hipStreamDestroy(s->st);
-        if (s->st_pre) (void)hipStreamDestroy(s->st_pre);
-        if (s->st_det) (void)hipStreamDestroy(s->st_det);
-        if (s->st_warp) (void)hipStreamDestroy(s->st_warp);
-        return;
-    }
+    if (!s->shared_streams) return;
     std::lock_guard<std::mutex> g(g_pool_mutex);
     StreamPool& p = g_pools[s->device];
     if (--p.refs == 0) {
@@ -1418,7 +1066,7 @@ int vs_stab_create(const vs_params_c* params, int device, vs_stab** out) {
 }
 
 void vs_stab_destroy(vs_stab* s) {
-    if (!s) return;
+    if (!s || s->member) return;        // (a stream of a vs_batch goes with its group: vs_batch_destroy)
     (void)hipSetDevice(s->device);
     // the destructor may race in-flight work (vsg.cpp:1374): drain all three streams first
     if (s->st_pre) (void)hipStreamSynchronize(s->st_pre);
@@ -1438,6 +1086,7 @@ void vs_stab_destroy(vs_stab* s) {
 
 int vs_stab_clean(vs_stab* s) {   // Stabilizer.cpp:221-256
     if (!s) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     S_TRY(s, sync_all(s));
     free_all(s);
     s->q_slot.clear(); s->q_idx.clear(); s->q_ptr.clear();
@@ -1457,6 +1106,7 @@ int vs_stab_out_size(const vs_stab* s, int w, int h, int* out_w, int* out_h) {
 int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride, int fmt, void* d_out,
                      size_t out_stride, int* produced) {
     if (!s || !produced) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     *produced = 0;
     if (!d_data) return VS_OK;   // empty frame -> empty result (Stabilizer.cpp:263-265)
     int rc = prepare(s, w, h, fmt, stride);
@@ -1465,7 +1115,7 @@ int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride
         // the frame is read where it is: it must stay valid and unchanged until its own result has been produced
         // one pitch for all frames in flight (the batched launches take it once): it may change when nothing is queued
         if (stride != s->src_pitch) {
-            if (!s->q_slot.empty() || !s->bq.empty() || !s->pend.empty() || s->ready.valid)
+            if (!s->q_slot.empty() || !s->bq.empty() || !s->pend.empty() || group_holds_warps(s->group))
                 return fail(s, VS_ERR_INVALID_ARG, "zero-copy mode: the row pitch may only change while no frame is queued");
             s->src_pitch = stride;
         }
@@ -1489,6 +1139,8 @@ static int flush_dev_impl(vs_stab* s, void* d_out, size_t out_stride, int* produ
 }
 
 int vs_stab_flush_dev(vs_stab* s, void* d_out, size_t out_stride, int* produced) {   // Stabilizer.cpp:394-400
+    if (!s || !produced) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     return flush_dev_impl(s, d_out, out_stride, produced, true);
 }
 
@@ -1569,6 +1221,7 @@ static int push_host_pipelined(vs_stab* s, const uint8_t* data, int w, int h, si
 int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, int fmt, uint8_t* out,
                  size_t out_stride, int* produced) {
     if (!s || !produced) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     *produced = 0;
     if (!data) return VS_OK;
     int rc = prepare(s, w, h, fmt, stride);
@@ -1610,6 +1263,7 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
 
 int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced) {
     if (!s || !produced) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     *produced = 0;
     if (!s->allocated) return VS_OK;
     if (s->hold_valid) {      // host pipeline: the frame the last push computed
@@ -1644,6 +1298,7 @@ int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced) {
 // consecutive calls overlap each other and the device work.  To be chosen while no frame is queued.
 int vs_stab_set_host_pipeline(vs_stab* s, int enable) {
     if (!s) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     if (!s->q_slot.empty() || s->hold_valid) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_host_pipeline: the frame queue must be empty");
     s->host_pipe = enable != 0;
     return VS_OK;
@@ -1653,6 +1308,7 @@ int vs_stab_set_host_pipeline(vs_stab* s, int enable) {
 // launch.  A result is complete after vs_stab_sync(); every push must then be given its own d_out.
 int vs_stab_set_warp_batch(vs_stab* s, int frames) {
     if (!s || frames < 1 || frames > WARP_BATCH_MAX) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     if (s->allocated) { S_HIP(s, hipSetDevice(s->device)); S_TRY(s, flush_warps(s)); }
     s->warp_batch = frames;
     return VS_OK;
@@ -1663,6 +1319,7 @@ int vs_stab_set_warp_batch(vs_stab* s, int frames) {
 // vs_stab_set_warp_batch(frames)).  To be chosen before the first frame (or after vs_stab_clean).
 int vs_stab_set_batch(vs_stab* s, int frames) {
     if (!s || frames < 1 || frames > BATCH_MAX) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     if (s->allocated) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_batch: call before the first frame or after vs_stab_clean");
     s->batch = frames;
     if (frames > 1) s->warp_batch = std::min(frames, WARP_BATCH_MAX);
@@ -1675,6 +1332,7 @@ int vs_stab_set_batch(vs_stab* s, int frames) {
 // the batch depth and a vs_stab_sync, or until vs_stab_flush_dev has drained the queue.  Tightly packed frames.
 int vs_stab_set_zero_copy(vs_stab* s, int enable) {
     if (!s) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     if (!s->q_slot.empty()) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_zero_copy: the frame queue must be empty");
     s->zero_copy = enable != 0;
     s->src_pitch = s->row_bytes;
@@ -1685,6 +1343,7 @@ int vs_stab_set_zero_copy(vs_stab* s, int enable) {
 // UV plane with a common pitch, the UV plane `uv_offset` bytes behind the Y pointer.  0 = contiguous (h * pitch).
 int vs_stab_set_nv12_layout(vs_stab* s, size_t in_uv_offset, size_t out_uv_offset) {
     if (!s) return VS_ERR_INVALID_ARG;
+    if (s->member && !s->group_call) return fail(s, VS_ERR_INVALID_ARG, "this stream belongs to a vs_batch: drive it through vs_batch_* (its getters remain available)");
     if (!s->q_slot.empty()) return fail(s, VS_ERR_INVALID_ARG, "vs_stab_set_nv12_layout: the frame queue must be empty");
     s->in_uv_off = in_uv_offset;
     s->out_uv_off = out_uv_offset;
@@ -1801,30 +1460,46 @@ int vs_stab_get_stage_times(vs_stab* s, double* total_ms, int64_t* launches) {
 
 }  // extern "C"
 
-// ---- vs_batch: several streams of one device scheduled together (BASELINE configs[4]: 64 streams = 8 per GPU) ------------
-// N instances that each run their own batches take turns on the device's streams: every stage is launched once per instance,
-// and the chains of one instance queue behind the waits of another (8 instances: 101.7 k frames/s in total against 109.1 k for
-// one, round 2).  A group runs ONE schedule for its members: the frames that all of them have queued since the last step go
-// into one argument table per stage - the tables hold one block per frame anyway, and a block names its frame's buffers, so
-// a launch does not care whose frame it is -, the ordered tails run as one launch with a workgroup per stream, and all due
-// warps leave in launches of 32 frames.  The members stay ordinary vs_stab instances (queues, pyramid rings, keypoint
-// buffers, trajectory state, counters and debug records of their own); what a standalone instance keeps per batch - host and
-// device tables, the events of the batch schedule, the inverse maps and coordinate tables of the pending warps - the group
-// keeps once.  group_run is run_batch with "for each member" around its per-frame loops.
+// ---- the batch schedule -------------------------------------------------------------------------------------------------
+// ONE schedule runs every batch: a vs_batch steps the frames that all its streams have queued (BASELINE configs[4]: 64 streams =
+// 8 per GPU), and a standalone instance in batch mode owns a private group of one (vs_stab::own).  N instances that each ran
+// their own batches took turns on the device's streams: every stage launched once per instance, the chains of one queued behind
+// the waits of another (8 instances: 101.7 k frames/s in total against 109.1 k for one, round 2).  A group goes through ONE
+// step for its members: the frames that all of them have queued since the last step go into one argument table per stage - the
+// tables hold one block per frame anyway, and a block names its frame's buffers, so a launch does not care whose frame it is -,
+// the ordered tails run as one launch with a workgroup per stream, and all due warps leave in launches of 32 frames.  The members
+// stay ordinary vs_stab instances (queues, pyramid rings, keypoint buffers, trajectory state, counters and debug records of
+// their own); host and device tables, the events of the schedule, the inverse maps and coordinate tables of the pending warps
+// belong to the group.
+//
+// One step (group_run), three streams:
+//   pre :  gray(n, two parts: re-detecting frames first) -> table uploads -> pyramid level(n) x levels
+//   det :  zero -> min_eigen -> nms -> select                 (starts behind the first gray part)
+//   main:  [warps of the PREVIOUS step] -> LK(n x 200 waves) -> RANSAC score -> select(n waves) -> ordered tail (1 WG per stream)
+//          -> releases (1 WG per push) -> coordinate tables of this step's warps
+// `main` waits for `pre` and for the wide launches of `det` of the same step, then issues the warps of the step before: at that
+// point the rest of pre/det of this step is done (it overlapped the tracking and tail of the step before) and its tracking has
+// not started, and `pre` of the next step waits for these warps - the HBM-bound warp has the GPU to itself (on a stream of its
+// own it overlapped the tracker, which holds ~90 KB of LDS per CU: 3 warp workgroups per CU instead of 8).
 struct vs_batch {
     int device = 0, S = 0, B = 0, cap = 0;
+    bool own = false;                       // the private schedule of one standalone instance
     std::vector<vs_stab*> m;
     std::string err;
     hipStream_t st = nullptr, st_pre = nullptr, st_det = nullptr;
     bool allocated = false;
+    // Host images of the argument tables of a step, in page-locked memory so that their uploads are asynchronous (from pageable
+    // memory hipMemcpyAsync holds the host until the stream gets to the copy, and the host then no longer runs ahead of the
+    // GPU): four sets, step k writes set k % 4 once the tail of step k-4 has run.  On the device the tracker / scoring / tail
+    // tables exist twice (k & 1): step k+1's are uploaded on `pre` while step k's are still read on `main`.
     uint8_t* h_tables = nullptr;
     size_t h_set_bytes = 0, ho_pairs = 0, ho_lk = 0, ho_rs = 0, ho_tail = 0, ho_gf = 0, ho_seg = 0;
     uint8_t* d_all = nullptr;
     uint8_t *d_lk[2] = {nullptr, nullptr}, *d_rs[2] = {nullptr, nullptr}, *d_tail[2] = {nullptr, nullptr}, *d_seg[2] = {nullptr, nullptr}, *d_gf = nullptr;
-    uint8_t* d_tin[2] = {nullptr, nullptr};
+    uint8_t* d_tin[2] = {nullptr, nullptr};         // per frame of a step: what the selection leaves for the tail
     ImgPair* d_pairs = nullptr;
-    double* d_MinvB[2] = {nullptr, nullptr};
-    int32_t* d_tabs[4] = {nullptr, nullptr, nullptr, nullptr};     // [set] frame plane, [2 + set] chroma plane
+    double* d_MinvB[2] = {nullptr, nullptr};        // inverse maps of the due frames of a step, 12 doubles each; two sets
+    int32_t* d_tabs[4] = {nullptr, nullptr, nullptr, nullptr};     // coordinate tables: [set] frame plane, [2 + set] chroma plane
     hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {}, ev_warp[2] = {};
     bool bdet_valid[4] = {false, false, false, false}, warp_valid[2] = {false, false};
     int last_det_batch = -1, last_warp_set = -1, batch_id = 0, pend_set = 0;
@@ -1834,7 +1509,7 @@ struct vs_batch {
         size_t stride = 0;
         std::vector<const uint8_t*> srcs;
         std::vector<uint8_t*> dsts;
-        std::vector<int> slots;
+        std::vector<int> slots, pad_idx;       // pad_idx: which of its owner's scratch frames (border pad / crop-and-zoom)
         std::vector<vs_stab*> owner;
     } ready, next;          // ready: the step whose tails are queued (its warps go out with the next step); next: the step being built
 };
@@ -1864,6 +1539,25 @@ void group_free(vs_batch* g) {
     g->allocated = false;
 }
 
+bool group_make_events(vs_batch* g) {
+    auto mk = [&](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+    bool ok = mk(g->ev_bpre) && mk(g->ev_bgray) && mk(g->ev_bnms) && mk(g->ev_warp[0]) && mk(g->ev_warp[1]);
+    for (auto& e : g->ev_bdet) ok = ok && mk(e);
+    for (auto& e : g->ev_blk) ok = ok && mk(e);
+    return ok;
+}
+
+// What the members must agree on: everything that shapes a launch (frame and analysis geometry, pitch, input mode, pyramid
+// depth, tracking window, hypothesis count, border mode).  Smoothing radius and method, horizon lock, the drone filters'
+// settings, corner count and thresholds are per stream: they live in each frame's argument block or in the stream's state.
+bool same_launch_shape(const vs_stab* a, const vs_stab* b) {
+    const vs_params_c &p = a->p, &q = b->p;
+    return a->w == b->w && a->h == b->h && a->fmt == b->fmt && a->src_pitch == b->src_pitch && a->zero_copy == b->zero_copy &&
+           a->in_uv_off == b->in_uv_off && a->out_uv_off == b->out_uv_off && a->aw == b->aw && a->ah == b->ah && a->levels == b->levels &&
+           p.lk_win_size == q.lk_win_size && p.ransac_max_iters == q.ransac_max_iters && p.border_size == q.border_size &&
+           p.crop_n_zoom == q.crop_n_zoom && (p.border_size <= 0 || p.border_type == q.border_type);
+}
+
 // Tables and workspaces for cap = S * B frames per step, once the members know their geometry.
 int group_allocate(vs_batch* g) {
     const vs_stab* s0 = g->m[0];
@@ -1878,7 +1572,9 @@ int group_allocate(vs_batch* g) {
     const size_t o_ti[2] = {take(tail_in_bytes() * cap), take(tail_in_bytes() * cap)};
     const size_t o_pairs = take(sizeof(ImgPair) * cap * (2 + 2 * MAX_PYR));
     const size_t o_minv[2] = {take((size_t)cap * 96), take((size_t)cap * 96)};
-    const size_t tab_bytes = warp_tabs_ints(s0->w, s0->h, cap) * sizeof(int32_t);
+    int tow, toh;
+    out_size(s0, s0->w, s0->h, &tow, &toh);
+    const size_t tab_bytes = warp_tabs_ints(std::max(s0->w, tow), std::max(s0->h, toh), cap) * sizeof(int32_t);
     size_t o_tabs[4];
     for (auto& o : o_tabs) o = take(tab_bytes);
     G_HIP(g, hipMalloc((void**)&g->d_all, off));
@@ -1900,24 +1596,56 @@ int group_allocate(vs_batch* g) {
     G_HIP(g, hipHostMalloc((void**)&g->h_tables, 4 * ho));
     memset(g->h_tables, 0, 4 * ho);
     G_HIP(g, hipStreamSynchronize(g->st));
-    for (vs_batch::Ready* r : {&g->ready, &g->next}) { r->srcs.assign(cap, nullptr); r->dsts.assign(cap, nullptr); r->slots.assign(cap, -1); r->owner.assign(cap, nullptr); }
+    for (vs_batch::Ready* r : {&g->ready, &g->next}) {
+        r->srcs.assign(cap, nullptr); r->dsts.assign(cap, nullptr); r->slots.assign(cap, -1); r->pad_idx.assign(cap, 0); r->owner.assign(cap, nullptr);
+    }
     g->allocated = true;
     return VS_OK;
 }
 
-// The warps of the step whose tails were queued last, 32 frames per launch (or only their coordinate tables).
+// The warps of the step whose tails were queued last, 32 frames per launch (`what` = VS_WARP_ONLY / VS_WARP_ALL), or only their
+// coordinate tables (VS_WARP_TABLES_ONLY: queued right behind the tail, so they are ready long before the warps).
 int group_ready_launches(vs_batch* g, int what) {
     vs_batch::Ready& R = g->ready;
     const vs_stab* s0 = g->m[0];
+    const vs_params_c& p = s0->p;
+    hipStream_t st = g->st;
+    const int bsz = p.border_size;
+    const bool pad = bsz > 0 && !p.crop_n_zoom;                                                       // Stabilizer.cpp:981-990
+    const bool crop = bsz > 0 && p.crop_n_zoom && s0->w - 2 * bsz > 0 && s0->h - 2 * bsz > 0;          // :1108-1124
     int rc = VS_OK;
-    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {
+    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes WARP_BATCH_MAX frames per launch
         const int m = std::min(WARP_BATCH_MAX, R.n - i0);
         const bool tabs = m >= 4;
         if (what == VS_WARP_TABLES_ONLY && !tabs) continue;
         const int w = tabs ? what : VS_WARP_ALL;
+        if (pad || crop) {
+            // pad: the frames get their border first and the padded frames are warped into the (larger) results;
+            // crop-and-zoom: the frames are warped into scratch frames, whose inner part is then resized to the results
+            const uint8_t* srcs[WARP_BATCH_MAX];
+            uint8_t* dsts[WARP_BATCH_MAX];
+            const int pw = pad ? s0->w + 2 * bsz : s0->w, ph = pad ? s0->h + 2 * bsz : s0->h;
+            const size_t prow = (size_t)pw * s0->cn;
+            for (int i = 0; i < m; i++) {
+                const vs_stab* o = R.owner[i0 + i];
+                uint8_t* scratch = o->d_padB + (size_t)R.pad_idx[i0 + i] * o->pad_frame_bytes;
+                srcs[i] = pad ? scratch : R.srcs[i0 + i];
+                dsts[i] = pad ? R.dsts[i0 + i] : scratch;
+                if (pad && what != VS_WARP_TABLES_ONLY && rc == VS_OK)
+                    rc = launch_make_border(R.srcs[i0 + i], s0->src_pitch, s0->w, s0->h, s0->cn, scratch, prow, bsz, p.border_type, st);
+            }
+            if (rc == VS_OK)
+                rc = launch_warp_affine_list(srcs, dsts, m, pad ? prow : s0->src_pitch, pw, ph, pad ? R.stride : prow, pw, ph, s0->cn,
+                                             g->d_MinvB[R.set] + 12 * i0, 12, tabs ? g->d_tabs[R.set] + i0 * warp_tabs_ints(pw, ph, 1) : nullptr, st, w);
+            for (int i = 0; crop && what != VS_WARP_TABLES_ONLY && i < m && rc == VS_OK; i++)
+                rc = launch_resize_linear(dsts[i] + ((size_t)bsz * s0->w + bsz) * s0->cn, prow, s0->w - 2 * bsz, s0->h - 2 * bsz, s0->cn,
+                                          R.dsts[i0 + i], R.stride, R.owner[i0 + i]->orig_w, R.owner[i0 + i]->orig_h, st);
+            continue;
+        }
         rc = launch_warp_affine_list(R.srcs.data() + i0, R.dsts.data() + i0, m, s0->src_pitch, s0->w, s0->h, R.stride, s0->w, s0->h, s0->cn,
-                                     g->d_MinvB[R.set] + 12 * i0, 12, tabs ? g->d_tabs[R.set] + i0 * warp_tabs_ints(s0->w, s0->h, 1) : nullptr, g->st, w);
+                                     g->d_MinvB[R.set] + 12 * i0, 12, tabs ? g->d_tabs[R.set] + i0 * warp_tabs_ints(s0->w, s0->h, 1) : nullptr, st, w);
         if (rc == VS_OK && s0->fmt == VS_FMT_NV12) {
+            // interleaved chroma plane: half size, two channels, the map with the halved translation
             const uint8_t* us[WARP_BATCH_MAX];
             uint8_t* ud[WARP_BATCH_MAX];
             for (int i = 0; i < m; i++) {
@@ -1925,7 +1653,7 @@ int group_ready_launches(vs_batch* g, int what) {
                 ud[i] = R.dsts[i0 + i] + dst_uv(s0, R.dsts[i0 + i], R.stride);
             }
             rc = launch_warp_affine_list(us, ud, m, s0->src_pitch, s0->w / 2, s0->h / 2, R.stride, s0->w / 2, s0->h / 2, 2, g->d_MinvB[R.set] + 12 * i0 + 6, 12,
-                                         tabs ? g->d_tabs[2 + R.set] + i0 * warp_tabs_ints(s0->w / 2, s0->h / 2, 1) : nullptr, g->st, w);
+                                         tabs ? g->d_tabs[2 + R.set] + i0 * warp_tabs_ints(s0->w / 2, s0->h / 2, 1) : nullptr, st, w);
         }
     }
     if (rc != VS_OK) g->err = get_last_error();
@@ -1955,7 +1683,11 @@ int group_launch_ready(vs_batch* g) {
     return rc;
 }
 
-// One step of the group: everything its members have queued (run_batch, with "for each member" around the per-frame loops).
+}  // namespace
+
+bool group_holds_warps(const vs_batch* g) { return g && (g->ready.valid || g->next.valid); }
+
+// One step: everything the members have queued.
 int group_run(vs_batch* g) {
     std::vector<vs_stab*> act;
     int n = 0, max_n = 0;
@@ -1965,32 +1697,41 @@ int group_run(vs_batch* g) {
     G_HIP(g, hipSetDevice(g->device));
     const vs_stab* s0 = g->m[0];
     for (vs_stab* s : act)
-        if (!s->allocated || !s->batch_active || s->w != s0->w || s->h != s0->h || s->fmt != s0->fmt || s->src_pitch != s0->src_pitch ||
-            s->zero_copy != s0->zero_copy || s->in_uv_off != s0->in_uv_off || s->out_uv_off != s0->out_uv_off)
-            return gfail(g, VS_ERR_INVALID_ARG, "vs_batch: the streams of a group share one frame geometry, pitch and input mode");
+        if (!s->allocated || !s->batch_active || !s0->allocated || !same_launch_shape(s, s0))
+            return gfail(g, VS_ERR_INVALID_ARG, "vs_batch: the streams of a group share one frame geometry, pitch, input mode and launch shape "
+                                                "(analysis size, pyramid depth, tracking window, hypothesis count, border mode)");
     if (n > g->cap || max_n > BATCH_MAX) return gfail(g, VS_ERR_CAPACITY, "vs_batch: more frames queued than a step holds");
     if (!g->allocated) G_TRY(g, group_allocate(g));
-    const vs_params_c& p = s0->p;
     const int k = g->batch_id++;
+    // host images of this step's tables: the set step k-4 used (its tail, the last reader of anything uploaded from it, has run
+    // by now unless the host is four steps ahead of the GPU - then it waits here)
     if (k >= 4) G_HIP(g, hipEventSynchronize(g->ev_blk[k % 4]));
     uint8_t* hset = g->h_tables + (size_t)(k % 4) * g->h_set_bytes;
     ImgPair* h_pairs = reinterpret_cast<ImgPair*>(hset + g->ho_pairs);
     uint8_t *h_lk = hset + g->ho_lk, *h_rs = hset + g->ho_rs, *h_tail = hset + g->ho_tail, *h_gf = hset + g->ho_gf, *h_seg = hset + g->ho_seg;
     const int dset = k & 1;
-    // ---- pre
+    // ---- pre: gray images and pyramids of all frames of the step, one launch per stage and level
     if (k >= 2) {
+        // ring reuse: these pyramid slots were read by the analysis two steps ago (npyr = 2 * batch + 2)
         G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_blk[(k - 2) % 4], 0));
         if (g->bdet_valid[(k - 2) % 4]) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_bdet[(k - 2) % 4], 0));
     }
+    // keep the HBM-bound warp alone on the GPU even when the host runs steps ahead: this step's gray / pyramid / detection
+    // kernels start after the warps issued during the previous step.  Several schedules share the device's streams: the last
+    // batched warp of ANY of them (their launches interleave in the shared queues, so that is the one in front of this step's
+    // kernels).  (Without the guard: 99.0 - 102.4 k frames/s against 112.4 - 114.2 k, warps 182 us instead of 86, round 3.)
     if (s0->ev_dev_warp && s0->dev_warp_valid->load(std::memory_order_acquire)) G_HIP(g, hipStreamWaitEvent(g->st_pre, s0->ev_dev_warp, 0));
     else if (g->last_warp_set >= 0) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_warp[g->last_warp_set], 0));
-    // ---- argument tables: tracker, scoring, tail (segment = member)
+    // ---- argument tables of the tracker, the scoring and the tail (segment = stream): filled here (they do not depend on this
+    // step's images), uploaded in the middle of `pre`; which outputs become due and where their maps go is known on the host
     const int set = g->pend_set;
     vs_batch::Ready& R = g->next;           // (g->ready still holds the warps of the step before: they go out further down)
-    int idx = 0, n_max = 0, npend = 0, nseg = 0;
+    int idx = 0, n_max = 0, npend = 0, nseg = 0, any_apart = 0;
     size_t pend_stride = 0;
     for (vs_stab* s : act) {
+        const vs_params_c& p = s->p;
         const int ns = (int)s->bq.size(), first = idx;
+        int npad = 0;
         for (int i = 0; i < ns; i++, idx++) {
             const vs_stab::BFrame& b = s->bq[i];
             const vs_stab::ItemBufs& it = s->items[i];
@@ -2002,7 +1743,7 @@ int group_run(vs_batch* g) {
             const int cap = std::max(b.lk_cap, 0);
             n_max = std::max(n_max, cap);
             G_TRY(g, lk_fill_item(h_lk + lk_item_bytes() * idx, L, s->levels, s->d_pts[b.lk_buf], cap, s->d_npts[b.lk_buf], it.next, it.status, it.err,
-                                  p.lk_win_size, p.lk_max_iters, p.lk_epsilon));
+                                  p.lk_win_size, p.lk_max_iters, p.lk_epsilon));                                    // :611-619
             G_TRY(g, ransac_fill_item(h_rs + ransac_item_bytes() * idx, s->d_pts[b.lk_buf], it.next, it.status, cap, s->d_npts[b.lk_buf], it.vp, it.vc,
                                       it.m, 4, p.ransac_threshold, p.ransac_max_iters, s->tab, it.counts, it.model, it.inliers, it.info, s->d_traj,
                                       &s->tp, s->d_dbg, b.have_prev_gray));
@@ -2010,25 +1751,29 @@ int group_run(vs_batch* g) {
             ransac_item_set_tail_in(h_rs + ransac_item_bytes() * idx, g->d_tin[dset] + tail_in_bytes() * idx);
             double* minv = nullptr;
             if (b.out_due) {
-                if (npend > 0 && pend_stride != b.out_stride) return gfail(g, VS_ERR_INVALID_ARG, "vs_batch: one output pitch per step");
+                if (npend > 0 && pend_stride != b.out_stride) return gfail(g, VS_ERR_INVALID_ARG, "batch mode: one output pitch per step");
                 minv = g->d_MinvB[set] + 12 * npend;
-                R.srcs[npend] = b.out_frame; R.dsts[npend] = b.d_out; R.slots[npend] = b.out_slot; R.owner[npend] = s;
+                R.srcs[npend] = b.out_frame; R.dsts[npend] = b.d_out; R.slots[npend] = b.out_slot; R.owner[npend] = s; R.pad_idx[npend] = npad++;
                 pend_stride = b.out_stride;
                 npend++;
             }
             tail_fill_item(h_tail + tail_item_bytes() * idx, b.out_due ? 1 : 0, b.out_idx, minv);
             tail_item_set_seg(h_tail + tail_item_bytes() * idx, nseg);
         }
-        tail_fill_seg(h_seg + tail_seg_bytes() * nseg, first, ns, s->d_M, s->d_traj, s->d_dbg);
+        tail_fill_seg(h_seg + tail_seg_bytes() * nseg, first, ns, s->d_M, s->d_traj, s->d_dbg, p.smoothing_method);
+        any_apart |= p.smoothing_method != VS_SMOOTH_KALMAN;
         nseg++;
         if (s->bq[0].prev_small) {   // Stabilizer.cpp:598-603 (once per stream: 480x270 -> analysis size)
+            StageScope t(g->m[0], VS_STAGE_PYRAMID, g->st_pre);
             G_TRY(g, launch_resize_gray(s->d_first_gray, 480, 480, 270, VS_FMT_GRAY8, s->pyr[s->bq[0].pv].img[0], s->aw, s->aw, s->ah, g->st_pre));
             G_TRY(g, build_pyramid(s, s->bq[0].pv, g->st_pre));
         }
     }
     {
+        // pair tables: [0] frame -> img[0]; [1..levels] img[l-1] -> img[l]; [levels+1 ..] img[l] -> der[l]
         const int L = s0->levels;
         int aligned = 1, n_detect = 0;
+        // level-0 pairs: the frames that re-detect first, so that the detector can start after a first, smaller launch
         for (vs_stab* s : act) for (const vs_stab::BFrame& b : s->bq) n_detect += b.detect ? 1 : 0;
         int n_first = 0, n_rest = 0, i = 0;
         for (vs_stab* s : act)
@@ -2043,30 +1788,38 @@ int group_run(vs_batch* g) {
             }
         G_HIP(g, hipMemcpyAsync(g->d_pairs, h_pairs, sizeof(ImgPair) * n * (2 * L + 2), hipMemcpyHostToDevice, g->st_pre));
         {
+            StageScope t(g->m[0], VS_STAGE_GRAY, g->st_pre);
+            // NV12: the Y plane is the gray image (SURVEY G1: no reference path; same policy as the per-frame pipeline)
             const int gfmt = s0->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s0->fmt;
             const int n_a = (n_detect > 0 && n_detect < n) ? n_detect : n;
-            G_TRY(g, launch_resize_gray_batch(g->d_pairs, n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));
-            G_HIP(g, hipEventRecord(g->ev_bgray, g->st_pre));
+            G_TRY(g, launch_resize_gray_batch(g->d_pairs, n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));  // :448-450
+            G_HIP(g, hipEventRecord(g->ev_bgray, g->st_pre));      // the detector needs the analysis images of its frames only
             if (n_a < n)
                 G_TRY(g, launch_resize_gray_batch(g->d_pairs + n_a, n - n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));
         }
+        // the tracker / scoring / tail tables go up here, in the middle of `pre` (which has slack): on `main` they sat between
+        // the tail of the step before and its warps; in front of the gray stage they delayed the detector; at the end of
+        // `pre` they delayed the event the warps wait for
         G_HIP(g, hipMemcpyAsync(g->d_lk[dset], h_lk, lk_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
         G_HIP(g, hipMemcpyAsync(g->d_rs[dset], h_rs, ransac_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
         G_HIP(g, hipMemcpyAsync(g->d_tail[dset], h_tail, tail_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
         G_HIP(g, hipMemcpyAsync(g->d_seg[dset], h_seg, tail_seg_bytes() * nseg, hipMemcpyHostToDevice, g->st_pre));
+        StageScope t(g->m[0], VS_STAGE_PYRAMID, g->st_pre);
+        // One launch per level (pyr_level_kernel): derivatives of level l and the image of level l+1 from one staged read of
+        // level l.  (83.0 k -> 92.2 k frames/s at 1080p against the two stencils as separate launches, round 2.)
         for (int l = 0; l <= L; l++)
             G_TRY(g, launch_pyr_level_batch(g->d_pairs + (size_t)(L + 1 + l) * n, l < L ? g->d_pairs + (size_t)(l + 1) * n : nullptr, n, s0->lw[l], s0->lw[l],
                                             s0->lh[l], l < L ? s0->lw[l + 1] : 0, g->st_pre));
     }
     G_HIP(g, hipEventRecord(g->ev_bpre, g->st_pre));
-    // ---- det
+    // ---- det: every frame of the step that re-detects, one launch per GFTT stage
     int ndet = 0;
     for (vs_stab* s : act) {
         int local = 0;
         for (const vs_stab::BFrame& b : s->bq) {
             if (!b.detect) continue;
             G_TRY(g, gftt_fill_item(h_gf + gftt_item_bytes() * ndet, s->pyr[b.c].img[0], s->aw, s->aw, s->ah, s->pts_cap[b.det_buf], 0.02, 15.0, 3,
-                                    s->gws[local], s->d_pts[b.det_buf], s->d_npts[b.det_buf]));
+                                    s->gws[local], s->d_pts[b.det_buf], s->d_npts[b.det_buf]));                      // :740-744
             s->dbg_det_pts = s->d_pts[b.det_buf]; s->dbg_det_n = s->d_npts[b.det_buf];
             s->dbg_gftt_counters = s->gws[local].counters;
             local++; ndet++;
@@ -2075,7 +1828,11 @@ int group_run(vs_batch* g) {
     }
     hipStream_t sd = g->st_det;
     if (ndet > 0) {
+        // starts as soon as the analysis images of its frames exist, next to the pyramid levels of this step and the tracking of
+        // the previous one (the table and the reset of the counters first: they are through by the time the images are)
         G_HIP(g, hipMemcpyAsync(g->d_gf, h_gf, gftt_item_bytes() * ndet, hipMemcpyHostToDevice, sd));
+        // keypoint buffers are recycled after B + 4 detections (two steps): the tracking of the step before the previous one
+        // must have read them (the GFTT scratch is only touched on this stream)
         if (k >= 2) G_HIP(g, hipStreamWaitEvent(sd, g->ev_blk[(k - 2) % 4], 0));
         G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 1));
         G_HIP(g, hipStreamWaitEvent(sd, g->ev_bgray, 0));
@@ -2083,6 +1840,8 @@ int group_run(vs_batch* g) {
             StageScope t(g->m[0], VS_STAGE_GFTT, sd);
             G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 4));
             G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 5));
+            // the wide launches of the detection are through: the warps of the step before may go (below); the selection -
+            // one workgroup per image - runs beside them
             G_HIP(g, hipEventRecord(g->ev_bnms, sd));
             G_TRY(g, launch_gftt_batch(g->d_gf, ndet, s0->aw, s0->ah, 3, sd, 3));
         }
@@ -2090,7 +1849,7 @@ int group_run(vs_batch* g) {
         g->last_det_batch = k;
     }
     g->bdet_valid[k % 4] = ndet > 0;
-    // ---- main
+    // ---- main: tracking and hypothesis scoring of all frames, one launch each
     hipStream_t st = g->st;
     G_HIP(g, hipStreamWaitEvent(st, g->ev_bpre, 0));
     for (vs_stab* s : act)
@@ -2100,26 +1859,34 @@ int group_run(vs_batch* g) {
     if (early) G_HIP(g, hipStreamWaitEvent(st, g->ev_bnms, 0));
     else if (wait_det) G_HIP(g, hipStreamWaitEvent(st, g->ev_bdet[g->last_det_batch % 4], 0));
     // `main` has waited for this step's gray / pyramid work and the wide launches of its detection: the warps of the PREVIOUS
-    // step go out here, before this step's tracking
+    // step go out here, before this step's tracking, with nothing but the corner selection (a workgroup per image) beside them
     G_TRY(g, group_launch_ready(g));
-    if (early) G_HIP(g, hipStreamWaitEvent(st, g->ev_bdet[g->last_det_batch % 4], 0));
+    if (early) G_HIP(g, hipStreamWaitEvent(st, g->ev_bdet[g->last_det_batch % 4], 0));       // the tracker needs the selected corners
     {
         StageScope t(g->m[0], VS_STAGE_LK, st);
-        G_TRY(g, launch_pyr_lk_batch(g->d_lk[dset], n, n_max, p.lk_win_size, st));
+        G_TRY(g, launch_pyr_lk_batch(g->d_lk[dset], n, n_max, s0->p.lk_win_size, st));
     }
     {
         StageScope t(g->m[0], VS_STAGE_RANSAC, st);
-        G_TRY(g, launch_ransac_score_batch(g->d_rs[dset], n, p.ransac_max_iters, n_max, st));
+        G_TRY(g, launch_ransac_score_batch(g->d_rs[dset], n, s0->p.ransac_max_iters, n_max, st));
     }
-    if (npend > 0 && g->warp_valid[set]) {
+    for (vs_stab* s : act)
+        if (s->dbg_delay_us > 0) { G_TRY(g, launch_spin(s->dbg_delay_us, st)); break; }
+    // ---- ordered tails, ONE launch (a workgroup per stream): per frame in push order the trajectory append (:644-693), then
+    // the map of the output that has become due (applyNextSmoothTransform sees exactly the transforms appended so far)
+    if (npend > 0 && g->warp_valid[set]) {         // the previous user of this set of maps must have read them
         G_HIP(g, hipStreamWaitEvent(st, g->ev_warp[set], 0));
         g->warp_valid[set] = false;
     }
     {
         StageScope t(g->m[0], VS_STAGE_TRAJ, st);
-        G_TRY(g, launch_ransac_tail_group(g->d_rs[dset], g->d_tail[dset], g->d_seg[dset], g->d_tin[dset], nseg, max_n, n, p.smoothing_method, st));
+        G_TRY(g, launch_ransac_tail_group(g->d_rs[dset], g->d_tail[dset], g->d_seg[dset], g->d_tin[dset], nseg, max_n, n, any_apart, st));
     }
+    // the keypoint and pyramid buffers of this step may be recycled (two steps on) once the tail, which still reads the points
+    // and their counts, has run
     G_HIP(g, hipEventRecord(g->ev_blk[k % 4], st));
+    // the warps of this step wait for the next one (or a drain); their maps exist once the tail has run: the coordinate tables
+    // are built right behind it
     R.n = npend; R.set = set; R.stride = pend_stride; R.valid = npend > 0; R.tabs_built = false;
     std::swap(g->ready, g->next);            // (the previous step's warps have been issued: g->ready was free)
     if (g->ready.valid) {
@@ -2138,8 +1905,6 @@ int group_run(vs_batch* g) {
     return VS_OK;
 }
 
-}  // namespace
-
 // Everything the members have queued is analysed and its warps are issued.  (The warps of a step normally go out with the NEXT
 // step, between its detection and its tracking; group_run issues the pending ones itself, so the step before the drained one is
 // covered too.)
@@ -2149,52 +1914,8 @@ int group_drain(vs_batch* g) {
     return group_launch_ready(g);
 }
 
-extern "C" {
-
-int vs_batch_create(int device, int n_streams, const vs_params_c* params, int frames_per_step, vs_batch** out) {
-    if (!out) return VS_ERR_INVALID_ARG;
-    *out = nullptr;
-    if (!params || n_streams < 1 || n_streams > 256 || frames_per_step < 1 || frames_per_step > BATCH_MAX) {
-        set_last_error("vs_batch_create: 1..256 streams, 1..64 frames per stream and step");
-        return VS_ERR_INVALID_ARG;
-    }
-    if (params->adaptive_smoothing || params->border_size > 0 || (params->enable_virtual_canvas && !params->crop_n_zoom)) {
-        set_last_error("vs_batch_create: adaptive smoothing, borders / crop-and-zoom and the virtual canvas are per-stream modes (use vs_stab_*)");
-        return VS_ERR_UNSUPPORTED;
-    }
-    vs_batch* g = new (std::nothrow) vs_batch();
-    if (!g) return VS_ERR_HIP;
-    g->device = device; g->S = n_streams; g->B = frames_per_step; g->cap = n_streams * frames_per_step;
-    for (int i = 0; i < n_streams; i++) {
-        vs_stab* s = nullptr;
-        int rc = vs_stab_create(params, device, &s);
-        if (rc == VS_OK) rc = vs_stab_set_batch(s, frames_per_step);
-        if (rc != VS_OK) { if (s) vs_stab_destroy(s); vs_batch_destroy(g); return rc; }
-        s->group = g;
-        g->m.push_back(s);
-    }
-    if (!g->m[0]->shared_streams) {
-        set_last_error("vs_batch_create: needs the device's shared stream set (VS_STAB_PRIVATE_STREAMS is set)");
-        vs_batch_destroy(g);
-        return VS_ERR_UNSUPPORTED;
-    }
-    g->st = g->m[0]->st; g->st_pre = g->m[0]->st_pre; g->st_det = g->m[0]->st_det;
-    auto mk = [&](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
-    bool ok = mk(g->ev_bpre) && mk(g->ev_bgray) && mk(g->ev_bnms) && mk(g->ev_warp[0]) && mk(g->ev_warp[1]);
-    for (auto& e : g->ev_bdet) ok = ok && mk(e);
-    for (auto& e : g->ev_blk) ok = ok && mk(e);
-    if (!ok) { set_last_error("vs_batch_create: hipEventCreate failed"); vs_batch_destroy(g); return VS_ERR_HIP; }
-    *out = g;
-    return VS_OK;
-}
-
-void vs_batch_destroy(vs_batch* g) {
+void group_delete(vs_batch* g) {
     if (!g) return;
-    (void)hipSetDevice(g->device);
-    if (g->st_pre) (void)hipStreamSynchronize(g->st_pre);
-    if (g->st_det) (void)hipStreamSynchronize(g->st_det);
-    if (g->st) (void)hipStreamSynchronize(g->st);
-    for (vs_stab* s : g->m) { s->group = nullptr; s->bq.clear(); vs_stab_destroy(s); }
     group_free(g);
     auto kill = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };
     kill(g->ev_bpre); kill(g->ev_bgray); kill(g->ev_bnms); kill(g->ev_warp[0]); kill(g->ev_warp[1]);
@@ -2203,19 +1924,94 @@ void vs_batch_destroy(vs_batch* g) {
     delete g;
 }
 
+// The private schedule of a standalone instance in batch mode: a group of one, steps of `batch` frames.
+vs_batch* group_new_own(vs_stab* s) {
+    vs_batch* g = new (std::nothrow) vs_batch();
+    if (!g) { set_last_error("out of host memory"); return nullptr; }
+    g->device = s->device; g->S = 1; g->B = s->batch; g->cap = s->batch; g->own = true;
+    g->m.push_back(s);
+    g->st = s->st; g->st_pre = s->st_pre; g->st_det = s->st_det;
+    if (!group_make_events(g)) { set_last_error("hipEventCreate failed"); group_delete(g); return nullptr; }
+    return g;
+}
+
+namespace {
+// vs_stab_* calls that vs_batch_* makes on a member
+struct MemberCall {
+    vs_stab* s;
+    explicit MemberCall(vs_stab* s_) : s(s_) { s->group_call = true; }
+    ~MemberCall() { s->group_call = false; }
+};
+}  // namespace
+
+extern "C" {
+
+// params: ONE block for all streams (per_stream = 0) or n_streams blocks.  Per-stream blocks may differ in everything that does
+// not shape a launch (same_launch_shape): smoothing radius and method, horizon lock, the drone filters' settings, corner count.
+static int batch_create(int device, int n_streams, const vs_params_c* params, int per_stream, int frames_per_step, vs_batch** out) {
+    if (!out) return VS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!params || n_streams < 1 || n_streams > 256 || frames_per_step < 1 || frames_per_step > BATCH_MAX) {
+        set_last_error("vs_batch_create: 1..256 streams, 1..64 frames per stream and step");
+        return VS_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < (per_stream ? n_streams : 1); i++) {
+        const vs_params_c& p = params[i];
+        if (p.struct_size != (int32_t)sizeof(vs_params_c)) { set_last_error("params: struct_size mismatch"); return VS_ERR_INVALID_ARG; }
+        // modes whose outputs depend on each other or on a host decision per output run in the per-frame pipeline only
+        if (p.adaptive_smoothing || (p.border_size > 0 && !p.crop_n_zoom && p.border_type == VS_BORDER_FADE) || (p.enable_virtual_canvas && !p.crop_n_zoom)) {
+            set_last_error("vs_batch_create: adaptive smoothing, the fade border and the virtual canvas are per-stream modes (use vs_stab_*)");
+            return VS_ERR_UNSUPPORTED;
+        }
+    }
+    vs_batch* g = new (std::nothrow) vs_batch();
+    if (!g) return VS_ERR_HIP;
+    g->device = device; g->S = n_streams; g->B = frames_per_step; g->cap = n_streams * frames_per_step;
+    for (int i = 0; i < n_streams; i++) {
+        vs_stab* s = nullptr;
+        int rc = vs_stab_create(&params[per_stream ? i : 0], device, &s);
+        if (rc == VS_OK) rc = vs_stab_set_batch(s, frames_per_step);
+        if (rc != VS_OK) { if (s) vs_stab_destroy(s); vs_batch_destroy(g); return rc; }
+        s->group = g; s->member = true;
+        g->m.push_back(s);
+    }
+    g->st = g->m[0]->st; g->st_pre = g->m[0]->st_pre; g->st_det = g->m[0]->st_det;
+    if (!group_make_events(g)) { set_last_error("vs_batch_create: hipEventCreate failed"); vs_batch_destroy(g); return VS_ERR_HIP; }
+    *out = g;
+    return VS_OK;
+}
+
+int vs_batch_create(int device, int n_streams, const vs_params_c* params, int frames_per_step, vs_batch** out) {
+    return batch_create(device, n_streams, params, 0, frames_per_step, out);
+}
+
+int vs_batch_create_params(int device, int n_streams, const vs_params_c* params_per_stream, int frames_per_step, vs_batch** out) {
+    return batch_create(device, n_streams, params_per_stream, 1, frames_per_step, out);
+}
+
+void vs_batch_destroy(vs_batch* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->st_pre) (void)hipStreamSynchronize(g->st_pre);
+    if (g->st_det) (void)hipStreamSynchronize(g->st_det);
+    if (g->st) (void)hipStreamSynchronize(g->st);
+    for (vs_stab* s : g->m) { s->group = nullptr; s->member = false; s->bq.clear(); vs_stab_destroy(s); }
+    group_delete(g);
+}
+
 int vs_batch_streams(const vs_batch* g) { return g ? g->S : 0; }
 vs_stab* vs_batch_stream(vs_batch* g, int i) { return (g && i >= 0 && i < g->S) ? g->m[(size_t)i] : nullptr; }
 const char* vs_batch_last_error(const vs_batch* g) { return g ? g->err.c_str() : ""; }
 
 int vs_batch_set_zero_copy(vs_batch* g, int enable) {
     if (!g) return VS_ERR_INVALID_ARG;
-    for (vs_stab* s : g->m) { const int rc = vs_stab_set_zero_copy(s, enable); if (rc != VS_OK) { g->err = s->err; return rc; } }
+    for (vs_stab* s : g->m) { MemberCall mc(s); const int rc = vs_stab_set_zero_copy(s, enable); if (rc != VS_OK) { g->err = s->err; return rc; } }
     return VS_OK;
 }
 
 int vs_batch_set_nv12_layout(vs_batch* g, size_t in_uv_offset, size_t out_uv_offset) {
     if (!g) return VS_ERR_INVALID_ARG;
-    for (vs_stab* s : g->m) { const int rc = vs_stab_set_nv12_layout(s, in_uv_offset, out_uv_offset); if (rc != VS_OK) { g->err = s->err; return rc; } }
+    for (vs_stab* s : g->m) { MemberCall mc(s); const int rc = vs_stab_set_nv12_layout(s, in_uv_offset, out_uv_offset); if (rc != VS_OK) { g->err = s->err; return rc; } }
     return VS_OK;
 }
 
@@ -2227,6 +2023,7 @@ int vs_batch_push_dev(vs_batch* g, const void* const* d_frames, int w, int h, si
     for (int i = 0; i < g->S; i++) {
         if (!d_frames[i]) continue;                       // no frame for this stream in this call
         vs_stab* s = g->m[(size_t)i];
+        MemberCall mc(s);
         const int rc = vs_stab_push_dev(s, d_frames[i], w, h, stride, fmt, d_outs[i], out_stride, &produced[i]);
         if (rc != VS_OK) { g->err = s->err; return rc; }
         full |= (int)s->bq.size() >= g->B;
@@ -2241,6 +2038,7 @@ int vs_batch_flush_dev(vs_batch* g, void* const* d_outs, size_t out_stride, int*
     if (rc != VS_OK) return rc;
     for (int i = 0; i < g->S; i++) {
         produced[i] = 0;
+        MemberCall mc(g->m[(size_t)i]);
         rc = vs_stab_flush_dev(g->m[(size_t)i], d_outs[i], out_stride, &produced[i]);
         if (rc != VS_OK) { g->err = g->m[(size_t)i]->err; return rc; }
     }

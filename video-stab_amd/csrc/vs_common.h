@@ -57,9 +57,10 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 // cv::warpAffine's inversion of the forward 2x3 matrix, in double (imgwarp.cpp).  The same
 // IEEE operation sequence on host and device (no FMA contraction in either build).
-// The measurement switches of scratch/ (kernel variants, schedule variants, timing-only skips) are read only in a process that
-// sets VS_LAB=1: a production process has exactly one configuration of this library.  (The documented runtime settings -
-// VS_STAB_DEVICE, VS_STAB_HOST_PIPELINE, VS_STAB_HELPER_SPIN_US - are ordinary environment variables.)
+// The library has one configuration: kernel and schedule variants measured in earlier rounds live in scratch/ as patches, not
+// behind switches.  What remains behind VS_LAB=1 are two test hooks (VS_STAB_DEBUG_DELAY_US: a spin kernel that widens a window
+// an ordering test looks into; VS_STAB_HOST_HELPER=0: the pipelined host call without its helper thread).  (The documented
+// runtime settings - VS_STAB_DEVICE, VS_STAB_HOST_PIPELINE, VS_STAB_HELPER_SPIN_US - are ordinary environment variables.)
 inline const char* lab_env(const char* name) {
     const char* e = std::getenv("VS_LAB");
     return (e && e[0] == '1') ? std::getenv(name) : nullptr;
@@ -103,8 +104,6 @@ int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int
 struct ImgPair { const void* src; void* dst; };
 int launch_resize_gray_batch(const ImgPair* d_pairs, int items, size_t sstride, int sw, int sh, int fmt, size_t dstride,
                              int dw, int dh, int aligned, hipStream_t st);
-int launch_pyr_down_batch(const ImgPair* d_pairs, int items, size_t sstride, int sw, int sh, size_t dstride, hipStream_t st);
-int launch_scharr_batch(const ImgPair* d_pairs, int items, size_t sstride, int w, int h, hipStream_t st);
 int launch_pyr_level_batch(const ImgPair* d_scharr_pairs, const ImgPair* d_pyr_pairs, int items, size_t sstride, int w, int h,
                            size_t dstride, hipStream_t st);
 int launch_pyr_down(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst,

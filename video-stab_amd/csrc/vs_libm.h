@@ -4,7 +4,9 @@
 // std::atan2(float, float) (/root/reference/src/Stabilizer.cpp:662, 902-908, 1689): glibc's cosf / sinf / atan2f.  The
 // device's libm rounds some arguments the other way in the last place, and one ulp in a matrix entry moves the 1/1024-px
 // coordinate of a whole pixel column across a rounding boundary - the only thing that stood between this library's frames
-// and the oracle's, bit for bit.  These are restatements of glibc's algorithms (2.28 and later):
+// and the oracle's, bit for bit.  These are restatements of glibc's algorithms as shipped from 2.28 on and verified against
+// 2.35 on x86-64 with FMA (2.41 replaces atanf / atan2f with correctly rounded versions; x86 hosts without FMA run an unfused
+// sincosf - tests/test_libm.py skips its host comparison there and says why):
 //   cosf / sinf   sysdeps/ieee754/flt-32/s_cosf.c, s_sinf.c, sincosf.h (the ARM optimized-routines kernels: the argument in
 //                 double, reduction by pi/2, one of two degree-8 / degree-7 polynomials); multiply-adds fused, which is what the
 //                 x86-64 (FMA ifunc variants) and aarch64 builds execute;
@@ -18,7 +20,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VS_LIBM_HD __host__ __device__ __forceinline__
 #else
 #define VS_LIBM_HD inline

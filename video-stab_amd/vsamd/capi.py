@@ -202,6 +202,7 @@ class VsLib:
         L.vs_stab_get_stage_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         try:
             L.vs_batch_create.argtypes = [C.c_int, C.c_int, C.POINTER(VsParams), C.c_int, C.POINTER(vp)]
+            L.vs_batch_create_params.argtypes = [C.c_int, C.c_int, C.POINTER(VsParams), C.c_int, C.POINTER(vp)]
             L.vs_batch_destroy.argtypes = [vp]
             L.vs_batch_destroy.restype = None
             L.vs_batch_streams.argtypes = [vp]
@@ -934,9 +935,15 @@ class Batch:
     """vs_batch: n_streams streams of one device scheduled together (one launch per stage over the frames of all of them)."""
 
     def __init__(self, vs, params, n_streams, frames_per_step, device=0):
+        """params: one VsParams for all streams, or a list of n_streams of them (vs_batch_create_params)."""
         self.vs, self.lib, self.n = vs, vs.lib, n_streams
         h = C.c_void_p()
-        vs.check(self.lib.vs_batch_create(device, n_streams, C.byref(params), frames_per_step, C.byref(h)))
+        if isinstance(params, (list, tuple)):
+            assert len(params) == n_streams
+            arr = (VsParams * n_streams)(*params)
+            vs.check(self.lib.vs_batch_create_params(device, n_streams, arr, frames_per_step, C.byref(h)))
+        else:
+            vs.check(self.lib.vs_batch_create(device, n_streams, C.byref(params), frames_per_step, C.byref(h)))
         self.h = h
         self._produced = (C.c_int32 * n_streams)()
 
