@@ -249,8 +249,16 @@ def tables_pass(ss, roof, steps):
     ss.sync()
     ms, n = ss.stage_totals()
     ss.set_profiling(1)
-    if n[capi.STAGE_WARP_TABLES] == 0 or n[capi.STAGE_WARP] == 0:
-        roof["tables_note"] = "no table launches (per-frame pipeline)"
+    if n[capi.STAGE_WARP] == 0:
+        roof["tables_note"] = "no warp launches in the tables pass"
+        return
+    if n[capi.STAGE_WARP_TABLES] == 0:
+        # round 4: the coordinate tables of a frame's warp are built by the workgroup that computes the frame's inverse map
+        # (release kernel of the batch tail, k_ransac.hip): no launch of their own, nothing to add to the warp kernel's time
+        roof["tables_us_per_launch"] = 0.0
+        roof["stage_frac"] = roof["frac"]
+        roof["stage_note"] = ("stage_frac = frac: the coordinate tables are built inside the batch tail's release kernel "
+                              "(no launch of their own on the warp's stream); the warp stage is the warp kernel(s)")
         return
     # a batch's tables are built by one event-bracketed group of launches (one per 32 frames and plane), like its warps
     per_launch = max(1, (ss.WB_frames + 31) // 32)

@@ -1,11 +1,12 @@
 """HIP path vs CPU oracle, through the C ABI (libvideo-stab.so), on a real MI355X.
 
-Bar (north_star): bit-exact for every integer/byte/index output (gray, pyramid,
-derivatives, warped pixels under an identical matrix, feature lists and their
-order, LK status, inlier masks, chosen hypothesis); float outputs are compared
-bit-exactly where both sides run the same IEEE operation sequence (eigenvalue
-map, LK positions, refined model) and within the stated tolerance where a libm
-function is involved (atan2f / sinf / cosf: 1e-6 relative).
+Bar: bit-exact for EVERY compared output.  Integer/byte/index outputs (gray,
+pyramid, derivatives, warped pixels under an identical matrix, feature lists and
+their order, LK status, inlier masks, chosen hypothesis) and float outputs alike
+(eigenvalue map, LK positions, refined model: the same IEEE operation sequence on
+both sides; atan2f / sinf / cosf: one frozen restatement of glibc's algorithms on
+both sides, vs_libm.h, held against the host libm by tests/test_libm.py).  No
+tolerance is used anywhere in this file.
 """
 import numpy as np
 import pytest
@@ -159,6 +160,33 @@ def test_warp_nv12(gpu, oracle, clip_small):
     nv = synth.bgr_to_nv12(clip_small[0])
     M = [0.99998, -0.006, 2.5, 0.006, 0.99998, -3.0]
     assert np.array_equal(gpu.warp_affine_nv12(nv, 320, 240, M), oracle.warp_affine_nv12(nv, 320, 240, M))
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (6, 4), (18, 130), (240, 322), (34, 130), (270, 482), (64, 128), (66, 132), (96, 516), (130, 1024), (128, 256)])
+def test_warp_nv12_surfaces_in_one_launch(gpu, oracle, shape):
+    """Four and more NV12 surfaces per call: luma and chroma tiles of all of them in ONE grid (warp_nv12_kernel; the frames'
+    table blocks hold the luma table followed by the chroma table).  Sizes around the tile edges of both planes (128 x 64 luma,
+    128 x 32 chroma pixels), planes smaller than a tile, and every matrix class: interior tiles, tiles leaving the surface on
+    every side, boxes that do not fit the staging area (direct path), a surface entirely out of view."""
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    surf = rng.integers(0, 256, (len(MATS), h * 3 // 2, w), dtype=np.uint8)
+    Ms = np.array(MATS, np.float32)
+    out = gpu.warp_affine_nv12(surf, w, h, Ms)
+    for i in range(len(MATS)):
+        assert np.array_equal(out[i], oracle.warp_affine_nv12(surf[i], w, h, Ms[i])), (shape, i)
+
+
+def test_warp_nv12_33_surfaces_span_two_launches(gpu, oracle):
+    """33 surfaces: a launch of 32 and one of a single surface (plane by plane, no tables)."""
+    w, h = 322, 242 - 2
+    rng = np.random.default_rng(77)
+    surf = rng.integers(0, 256, (33, h * 3 // 2, w), dtype=np.uint8)
+    ang = rng.normal(0, 0.004, 33)
+    Ms = np.array([[np.cos(a), -np.sin(a), dx, np.sin(a), np.cos(a), dy] for a, dx, dy in zip(ang, rng.normal(0, 5, 33), rng.normal(0, 5, 33))], np.float32)
+    out = gpu.warp_affine_nv12(surf, w, h, Ms)
+    for i in range(33):
+        assert np.array_equal(out[i], oracle.warp_affine_nv12(surf[i], w, h, Ms[i])), i
 
 
 # ---- G1/G2 resize + gray --------------------------------------------------------

@@ -27,6 +27,7 @@
 #include "traj_device.h"
 #include "traj_emit_device.h"
 #include "vs_common.h"
+#include "warp_tab.h"
 
 namespace vsd {
 
@@ -419,7 +420,9 @@ struct TailItem {
     int out_due, out_idx;
     double* Minv_out;
     int ncnt, seg;               // ncnt: written by the tail - transforms appended after this push (read by the release kernel);
-                                 // seg: group launches - index of the frame's stream segment
+                                 // seg: index of the frame's stream segment
+    WarpTabJob tab[2];           // coordinate tables of the due frame's warp (frame plane; chroma plane of an NV12 surface), built
+                                 // by the release workgroup as soon as the inverse maps exist (tabs == nullptr: not wanted)
 };
 // A step's frames belong to one or more streams (a standalone instance is a group of one): the items of stream s are
 // table[first .. first + n), workgroup s of the tail takes them, and the stream's frame matrix goes to its own M_out.
@@ -574,10 +577,12 @@ __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArg
 // The releases of a step whose appends ransac_tail_batch_kernel has made (segments with `apart`): workgroup f = push f.  Each sees
 // the trajectory as long as it was after its push (TailItem::ncnt); the last due one of a stream leaves its record and matrix
 // behind, like the last release of the one-kernel tail.
-__global__ __launch_bounds__(64) void ransac_release_batch_kernel(const RansacArgs* __restrict__ table, const TailItem* __restrict__ tail,
-                                                                  const TailSeg* __restrict__ segs) {
+constexpr int RELEASE_NT = 256;
+__global__ __launch_bounds__(RELEASE_NT) void ransac_release_batch_kernel(const RansacArgs* __restrict__ table, const TailItem* __restrict__ tail,
+                                                                          const TailSeg* __restrict__ segs) {
     __shared__ vs_debug_frame l_dbg_unused;
     __shared__ float l_M[12];
+    __shared__ double l_minv[12];
     int f = blockIdx.x;
     const TailItem t = tail[f];
     if (!t.out_due) return;
@@ -587,7 +592,15 @@ __global__ __launch_bounds__(64) void ransac_release_batch_kernel(const RansacAr
     int last_due = -1;
     for (int i = 0; i < sg.n; i++) if (tail[i].out_due) last_due = i;
     const bool last = f == last_due;
-    traj_emit_device(table[0].traj, table[0].tp, t.out_idx, last ? sg.M_out : l_M, t.Minv_out, last ? table[0].dbg : &l_dbg_unused, nullptr, t.ncnt);
+    // wave 0: smoothing around the released frame, its matrix and inverse maps (12 doubles: frame plane, chroma plane)
+    traj_emit_device(table[0].traj, table[0].tp, t.out_idx, last ? sg.M_out : l_M, l_minv, last ? table[0].dbg : &l_dbg_unused, nullptr, t.ncnt);
+    __syncthreads();
+    if (threadIdx.x < 12) t.Minv_out[threadIdx.x] = l_minv[threadIdx.x];
+    // all waves: the coordinate tables of the frame's warp from the maps lane 0 has left in LDS (cv::warpAffine's adelta /
+    // bdelta / X0 / Y0, warp_tab.h).  As a launch of their own behind the tail they cost 4 - 5 us of kernel and an event gap of
+    // 6.5 us per 32 frames on the critical stream (round 3: 4 points of the warp stage's HBM fraction).
+    wt_build_plane(t.tab[0], l_minv, threadIdx.x, RELEASE_NT);
+    wt_build_plane(t.tab[1], l_minv + 6, threadIdx.x, RELEASE_NT);
 }
 
 }  // namespace
@@ -647,9 +660,14 @@ int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_m
 
 size_t tail_item_bytes() { return sizeof(TailItem); }
 
-void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out) {
+// tabs: nullptr, or the two table jobs of the due frame (frame plane, chroma plane)
+void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out, const WarpTabJob* tabs) {
     TailItem& t = *static_cast<TailItem*>(host_item);
     t.out_due = out_due; t.out_idx = out_idx; t.Minv_out = d_Minv_out; t.ncnt = 0; t.seg = 0;
+    for (int i = 0; i < 2; i++) {
+        if (tabs) t.tab[i] = tabs[i];
+        else { t.tab[i].tabs = nullptr; t.tab[i].src = nullptr; t.tab[i].dst = nullptr; t.tab[i].dw = 0; t.tab[i].dh = 0; }
+    }
 }
 
 // ---- group launches (vs_batch: the frames of several streams in one table) ----
@@ -678,7 +696,7 @@ int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void
     const TailSeg* sg = static_cast<const TailSeg*>(d_segs);
     const TailIn* ti = static_cast<const TailIn*>(d_tail_in);
     hipLaunchKernelGGL(ransac_tail_batch_kernel, dim3(nsegs), dim3(threads), 0, st, tb, tl, sg, ti);
-    if (any_apart) hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(64), 0, st, tb, tl, sg);
+    if (any_apart) hipLaunchKernelGGL(ransac_release_batch_kernel, dim3(items), dim3(RELEASE_NT), 0, st, tb, tl, sg);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

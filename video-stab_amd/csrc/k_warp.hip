@@ -29,15 +29,17 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "vs_common.h"
+#include "warp_tab.h"
 
 namespace vsd {
 
 namespace {
 
-constexpr int TW = 128;      // output tile width  (pixels)
-constexpr int TH = 16;       // output tile height (rows)
+constexpr int TW = WT_TW;    // output tile width  (pixels)
+constexpr int TH = WT_TH;    // output tile height (rows)
 constexpr int PX = 4;        // consecutive output pixels per lane
 constexpr int NT = 256;      // threads per workgroup
 constexpr int TXN = TW / PX; // 32 lanes along x
@@ -349,9 +351,8 @@ __device__ __forceinline__ void emit_fast(const WarpCore& c, uint8_t* __restrict
     }
 }
 
-// hal::warpAffine / WarpAffineInvoker coordinate terms in one form: round((p*v + q) * 1024)
-// (columns: adelta = round(M0*x*1024) with q = 0; rows: round((M1*y + M2)*1024) + round_delta).
-__device__ __forceinline__ int coord_term(double p, double q, double v) { return d_round((p * v + q) * 1024); }
+// hal::warpAffine / WarpAffineInvoker coordinate terms in one form: round((p*v + q) * 1024)  (warp_tab.h)
+__device__ __forceinline__ int coord_term(double p, double q, double v) { return wt_coord_term(p, q, v); }
 
 // The inverse map of frame bz (wave-uniform: scalar loads or kernel arguments).
 __device__ __forceinline__ void load_map(const WarpArgs& a, int bz, double* m) {
@@ -366,63 +367,21 @@ __device__ __forceinline__ void load_map(const WarpArgs& a, int bz, double* m) {
     }
 }
 
-// Coordinate tables of a frame, once per frame instead of once per tile (WarpAffineInvoker's adelta / bdelta / X0 / Y0:
-// double arithmetic, one rounding each; ~6000 terms per 1080p frame).  The warp kernels then hold no double-precision
-// arithmetic at all.  Layout of a frame's table (ints):
-//   [0, 8 gx)                  per tile column: source and destination pointer of the frame, adelta and bdelta of its first
-//                              and last column  (src, dst, ad0, ad1, bd0, bd1)
-//   [tab_row, + 4 gy)          per tile row: X0, Y0 of its first and last row                 (Xa, Xb, Ya, Yb)
-//   [tab_ad, + dw) adelta(x); [+dw) bdelta(x); [+dh) X0(y); [+dh) Y0(y)
-// so that everything a tile needs before its staging loads comes with ONE 32-byte and ONE 16-byte scalar load.
-constexpr int TAB_COL = 8;     // ints per tile column record
-struct TabLayout { int row, ad, stride; };
-inline TabLayout tab_layout(int dw, int dh) {
-    const int gx = (dw + TW - 1) / TW, gy = (dh + TH - 1) / TH;
-    TabLayout t;
-    t.row = TAB_COL * gx;
-    t.ad = t.row + 4 * gy;
-    t.stride = (t.ad + 2 * dw + 2 * dh + 3) & ~3;
-    return t;
-}
+// Coordinate tables of the frames of a launch, once per frame instead of once per tile (layout and arithmetic: warp_tab.h).
+// The batch schedule has them built by the kernel that computes the inverse maps (k_ransac.hip, release workgroups); this
+// launch serves the standalone operator, deferred warps and steps whose maps come out of a one-kernel tail (Kalman).
+constexpr int TAB_COL = WT_COL;
 
 __global__ __launch_bounds__(NT) void warp_tables_kernel(WarpArgs a) {
     const int bz = blockIdx.y;
     double m[6];
     load_map(a, bz, m);
-    int32_t* T = a.tabs + (size_t)bz * a.tab_stride;
-    const int dw = a.c.dw, dh = a.c.dh;
-    const int gx = (dw + TW - 1) / TW, gy = (dh + TH - 1) / TH;
-    int j = blockIdx.x * NT + threadIdx.x;
-    if (j < dw) {
-        const double dv = (double)j;
-        T[a.tab_ad + j] = coord_term(m[0], 0.0, dv);
-        T[a.tab_ad + dw + j] = coord_term(m[3], 0.0, dv);
-        return;
-    }
-    j -= dw;
-    if (j < dh) {
-        const double dv = (double)j;
-        T[a.tab_ad + 2 * dw + j] = coord_term(m[1], m[2], dv) + 16;
-        T[a.tab_ad + 2 * dw + dh + j] = coord_term(m[4], m[5], dv) + 16;
-        return;
-    }
-    j -= dh;
-    if (j < gx) {
-        const double v0 = (double)(j * TW), v1 = (double)(min(j * TW + TW, dw) - 1);
-        int32_t* C = T + TAB_COL * j;
-        *reinterpret_cast<const uint8_t**>(C) = a.use_list ? a.srcs[bz] : a.src + (size_t)bz * a.sframe;
-        *reinterpret_cast<uint8_t**>(C + 2) = a.use_list ? a.dsts[bz] : a.dst + (size_t)bz * a.dframe;
-        C[4] = coord_term(m[0], 0.0, v0); C[5] = coord_term(m[0], 0.0, v1);
-        C[6] = coord_term(m[3], 0.0, v0); C[7] = coord_term(m[3], 0.0, v1);
-        return;
-    }
-    j -= gx;
-    if (j < gy) {
-        const double v0 = (double)(j * TH), v1 = (double)(min(j * TH + TH, dh) - 1);
-        int32_t* R = T + a.tab_row + 4 * j;
-        R[0] = coord_term(m[1], m[2], v0) + 16; R[1] = coord_term(m[1], m[2], v1) + 16;
-        R[2] = coord_term(m[4], m[5], v0) + 16; R[3] = coord_term(m[4], m[5], v1) + 16;
-    }
+    TabLayout L;
+    L.row = a.tab_row; L.ad = a.tab_ad; L.stride = a.tab_stride;
+    const int j = blockIdx.x * NT + threadIdx.x;
+    if (j < wt_entries(a.c.dw, a.c.dh))
+        wt_build_entry(a.tabs + (size_t)bz * a.tab_stride, L, m, a.c.dw, a.c.dh, a.use_list ? a.srcs[bz] : a.src + (size_t)bz * a.sframe,
+                       a.use_list ? a.dsts[bz] : a.dst + (size_t)bz * a.dframe, j);
 }
 
 template <int CN, bool TABS>
@@ -980,33 +939,24 @@ __device__ __attribute__((noinline)) void plane_direct_tile(WarpCore c, const ui
                              min(y0 + TH * j + TH - 1, y1), bx0a, by0, bw, tid);
 }
 
+// One tile of a plane: tile (tx, ty) of the frame whose plane table starts at Ts (column records) / Tg (the per-column and
+// per-row terms).  tile / lut / s_row: the workgroup's LDS.
 template <int CN>
-__global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
-                                                        uint32_t swh, uint32_t dwh, uint32_t flags, uint32_t mgx, uint32_t mgy) {
+__device__ __forceinline__ void plane_tile(const WarpCore& c, const __attribute__((address_space(4))) int32_t* Ts, gtab_t Tg, int tab_row, int tx, int tyl,
+                                           uint8_t* tile, uint8_t* lut, int2* s_row, int tid) {
     typedef PlaneCfg<CN> P;
-    __shared__ __attribute__((aligned(16))) uint8_t tile[P::ROWS * P::PB];
-    __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
-    __shared__ __attribute__((aligned(16))) int2 s_row[P::THP];                 // (X0, Y0) of the tile's rows
-    typedef const __attribute__((address_space(4))) int32_t* cptr;
     typedef __attribute__((address_space(1))) uint8_t* gptr;
-    const int tid = threadIdx.x;
     const int L = tid & 31, ty = tid >> 5;
     int ad[4], bd[4];
-    WarpCore c;
-    c.sstride = sstride; c.dstride = dstride;
-    c.sw = swh & 0xFFFFu; c.sh = swh >> 16; c.dw = dwh & 0xFFFFu; c.dh = dwh >> 16;
-    c.src_aligned = flags & 1u; c.dst_aligned = (flags >> 1) & 1u; c.border = (flags >> 2) & 7u;
-    const TileId tq = tile_id(flags, (uint32_t)(c.dw + TW - 1) / TW, (uint32_t)(c.dh + P::THP - 1) / P::THP, mgx, mgy);
-    const int x0 = tq.x * TW, y0 = tq.y * P::THP;
+    const int x0 = tx * TW, y0 = tyl * P::THP;
     const int x1 = min(x0 + TW, c.dw) - 1, y1 = min(y0 + P::THP, c.dh) - 1;
     const uint8_t* src;
     uint8_t* dst;
     int ad0, ad1, bd0, bd1, Xa, Xb, Ya, Yb;
     {
-        cptr Ts = (cptr)(const int32_t*)(tabs + (size_t)tq.z * tab_stride);
         typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
         typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-        const i32x8 cc = *(const __attribute__((address_space(4))) i32x8*)(Ts + TAB_COL * tq.x);
+        const i32x8 cc = *(const __attribute__((address_space(4))) i32x8*)(Ts + TAB_COL * tx);
         const i32x4 r0 = *(const __attribute__((address_space(4))) i32x4*)(Ts + tab_row + 4 * (y0 / TH));
         const i32x4 r1 = *(const __attribute__((address_space(4))) i32x4*)(Ts + tab_row + 4 * (y1 / TH));
         src = (const uint8_t*)(gptr)((unsigned long long)(uint32_t)cc[0] | (unsigned long long)(uint32_t)cc[1] << 32);
@@ -1021,7 +971,6 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
             make_uint4(wlo, wlo << 16, __float_as_uint((float)(32u - f) * 0x1p121f), __float_as_uint((float)f * 0x1p121f));
         *reinterpret_cast<uint32_t*>(lut + f * LUT_STRIDE + 16) = (32u - f) | (f << 16);
     }
-    gtab_t Tg = tabs + (size_t)tq.z * tab_stride + tab_ad;
     // source box of the tile (the maps are monotone in x and in y separately)
     int bx0a, by0, bw, bh;
     bool fit;
@@ -1099,7 +1048,73 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
     }
     __syncthreads();
     // ---- output
-    plane_blend_rows<CN>(c, tile, lut, s_row, ad, bd, L, ty, dst, dstride, x0, y0, x1, y1);
+    plane_blend_rows<CN>(c, tile, lut, s_row, ad, bd, L, ty, dst, (uint32_t)c.dstride, x0, y0, x1, y1);
+}
+
+template <int CN>
+__global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_stride, int tab_row, int tab_ad, uint32_t sstride, uint32_t dstride,
+                                                        uint32_t swh, uint32_t dwh, uint32_t flags, uint32_t mgx, uint32_t mgy) {
+    typedef PlaneCfg<CN> P;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[P::ROWS * P::PB];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
+    __shared__ __attribute__((aligned(16))) int2 s_row[P::THP];                 // (X0, Y0) of the tile's rows
+    typedef const __attribute__((address_space(4))) int32_t* cptr;
+    WarpCore c;
+    c.sstride = sstride; c.dstride = dstride;
+    c.sw = swh & 0xFFFFu; c.sh = swh >> 16; c.dw = dwh & 0xFFFFu; c.dh = dwh >> 16;
+    c.src_aligned = flags & 1u; c.dst_aligned = (flags >> 1) & 1u; c.border = (flags >> 2) & 7u;
+    const TileId tq = tile_id(flags, (uint32_t)(c.dw + TW - 1) / TW, (uint32_t)(c.dh + P::THP - 1) / P::THP, mgx, mgy);
+    plane_tile<CN>(c, (cptr)(const int32_t*)(tabs + (size_t)tq.z * tab_stride), tabs + (size_t)tq.z * tab_stride + tab_ad, tab_row, tq.x, tq.y,
+                   tile, lut, s_row, threadIdx.x);
+}
+
+// ---- NV12 surfaces: luma and chroma tiles of all frames in ONE launch ---------------------------------------------------------
+// As two launches per 32 surfaces (warp_plane_kernel<1>, then <2>) the warp had two launch tails and two table walks, and the
+// luma launch - bound by its blend's instruction count - never shared a CU with the chroma launch, which is bound by its memory
+// phase.  Here the launch is a sequence of tiles (frame, plane, tile row, tile column): a frame's luma tiles, then its chroma
+// tiles; workgroup `lin` takes tile seq(lin) of that sequence, the XCD-aware order as in tile_id (XCD c = lin mod 8 takes the
+// c-th contiguous eighth).  A frame's tables lie in one block (warp_tab.h): luma table, then chroma table, `tab_stride` ints from
+// frame to frame.  The chroma plane's geometry is the luma plane's halved (surfaces share one pitch); flags as in the plane
+// kernels plus the frame count in bits 16...  mtpf = ceil(2^32 / tiles per frame), mgx1 / mgx2 likewise for the tile columns.
+__global__ __launch_bounds__(NT, 8) void warp_nv12_kernel(gtab_t tabs, int tab_stride, uint32_t sstride, uint32_t dstride, uint32_t swh, uint32_t dwh,
+                                                       uint32_t flags, uint32_t mtpf, uint32_t mgx1, uint32_t mgx2) {
+    typedef PlaneCfg<1> P1;
+    typedef PlaneCfg<2> P2;
+    constexpr int TILE_BYTES = P1::ROWS * P1::PB > P2::ROWS * P2::PB ? P1::ROWS * P1::PB : P2::ROWS * P2::PB;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[32 * LUT_STRIDE];
+    __shared__ __attribute__((aligned(16))) int2 s_row[P1::THP];
+    typedef const __attribute__((address_space(4))) int32_t* cptr;
+    WarpCore c;
+    c.sstride = sstride; c.dstride = dstride;
+    c.sw = swh & 0xFFFFu; c.sh = swh >> 16; c.dw = dwh & 0xFFFFu; c.dh = dwh >> 16;
+    c.src_aligned = flags & 1u; c.dst_aligned = (flags >> 1) & 1u; c.border = (flags >> 2) & 7u;
+    const uint32_t gx1 = (uint32_t)(c.dw + TW - 1) / TW, gy1 = (uint32_t)(c.dh + P1::THP - 1) / P1::THP;
+    const uint32_t dw2 = (uint32_t)c.dw >> 1, dh2 = (uint32_t)c.dh >> 1;
+    const uint32_t gx2 = (dw2 + TW - 1) / TW, gy2 = (dh2 + P2::THP - 1) / P2::THP;
+    const uint32_t n1 = gx1 * gy1, tpf = n1 + gx2 * gy2, n = tpf * (flags >> 16);
+    const uint32_t lin = blockIdx.x;
+    uint32_t seq = lin;
+    if (flags & 0x100u) {
+        const uint32_t cx = lin & 7u, k = lin >> 3, q = n >> 3, r = n & 7u;
+        seq = cx * q + (cx < r ? cx : r) + k;
+    }
+    const uint32_t f = __umulhi(seq, mtpf);
+    uint32_t t = seq - f * tpf;
+    gtab_t T = tabs + (size_t)f * tab_stride;
+    if (t < n1) {
+        const TabLayout L = tab_layout(c.dw, c.dh);
+        const uint32_t row = gx1 == 1 ? t : __umulhi(t, mgx1);
+        plane_tile<1>(c, (cptr)(const int32_t*)T, T + L.ad, L.row, (int)(t - row * gx1), (int)row, tile, lut, s_row, threadIdx.x);
+    } else {
+        t -= n1;
+        T += tab_layout(c.dw, c.dh).stride;
+        c.sw >>= 1; c.sh >>= 1; c.dw = (int)dw2; c.dh = (int)dh2;
+        c.src_aligned = (flags >> 5) & 1u; c.dst_aligned = (flags >> 6) & 1u;
+        const TabLayout L = tab_layout(c.dw, c.dh);
+        const uint32_t row = gx2 == 1 ? t : __umulhi(t, mgx2);
+        plane_tile<2>(c, (cptr)(const int32_t*)T, T + L.ad, L.row, (int)(t - row * gx2), (int)row, tile, lut, s_row, threadIdx.x);
+    }
 }
 
 // Ints of table workspace per frame of dw x dh (see warp_tables_kernel).
@@ -1107,11 +1122,12 @@ inline int tab_stride_of(int dw, int dh) { return tab_layout(dw, dh).stride; }
 
 // what: VS_WARP_ALL = tables (when d_tabs is given) and warp; VS_WARP_TABLES_ONLY / VS_WARP_ONLY = the two halves apart, so
 // that a caller whose maps are ready long before it warps (the batch tail of the stabilizer) builds the tables then.
+// tab_stride: ints from one frame's table to the next (0: the tables are packed; NV12 blocks hold two planes' tables per frame)
 template <int CN>
-void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, int what, hipStream_t st) {
+void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, int what, hipStream_t st, int tab_stride) {
     a.tabs = d_tabs;
     const TabLayout tl = tab_layout(a.c.dw, a.c.dh);
-    a.tab_stride = tl.stride; a.tab_row = tl.row; a.tab_ad = tl.ad;
+    a.tab_stride = tab_stride > 0 ? tab_stride : tl.stride; a.tab_row = tl.row; a.tab_ad = tl.ad;
     if (d_tabs) {
         if (what != VS_WARP_ONLY)
             hipLaunchKernelGGL(warp_tables_kernel, dim3((a.c.dw + a.c.dh + grid.x + grid.y + NT - 1) / NT, grid.z), dim3(NT), 0, st, a);
@@ -1146,10 +1162,10 @@ void launch_one(WarpArgs& a, dim3 grid, int32_t* d_tabs, int what, hipStream_t s
     }
 }
 
-void launch_cn(WarpArgs& a, dim3 grid, int cn, int32_t* d_tabs, hipStream_t st, int what = VS_WARP_ALL) {
-    if (cn == 3) launch_one<3>(a, grid, d_tabs, what, st);
-    else if (cn == 1) launch_one<1>(a, grid, d_tabs, what, st);
-    else launch_one<2>(a, grid, d_tabs, what, st);
+void launch_cn(WarpArgs& a, dim3 grid, int cn, int32_t* d_tabs, hipStream_t st, int what = VS_WARP_ALL, int tab_stride = 0) {
+    if (cn == 3) launch_one<3>(a, grid, d_tabs, what, st, tab_stride);
+    else if (cn == 1) launch_one<1>(a, grid, d_tabs, what, st, tab_stride);
+    else launch_one<2>(a, grid, d_tabs, what, st, tab_stride);
 }
 
 void fill_common(WarpArgs& a, const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh, uint8_t* d_dst,
@@ -1225,7 +1241,7 @@ int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int 
 // all share one geometry.  d_Minv: inverse maps on the device, minv_stride doubles apart.
 int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
                             size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, int32_t* d_tabs,
-                            hipStream_t st, int what) {
+                            hipStream_t st, int what, int tab_stride) {
     if ((what != VS_WARP_ALL && !d_tabs) || n < 1 || n > MAXB || !srcs || !dsts || bad_args(srcs[0], dsts[0], d_Minv, sstride, sw, sh, dstride, dw, dh, cn, n)) {
         set_last_error("warp_affine_list: invalid argument");
         return VS_ERR_INVALID_ARG;
@@ -1243,7 +1259,42 @@ int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, in
     a.Minv_dev = d_Minv;
     a.minv_stride = minv_stride;
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, n);
-    launch_cn(a, grid, cn, d_tabs, st, what);
+    launch_cn(a, grid, cn, d_tabs, st, what, tab_stride);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// NV12 surfaces of one geometry and pitch, luma and chroma planes in ONE launch (warp_nv12_kernel).  ys / yd: the surfaces (luma
+// plane first), the interleaved chroma plane src_uv / dst_uv bytes behind them.  d_tabs: the frames' table blocks (warp_tab.h:
+// luma table, then chroma table; nv12_tab_ints(w, h) ints per frame), ALREADY BUILT (the release workgroups of the batch tail,
+// or launch_warp_affine_list(.., VS_WARP_TABLES_ONLY, nv12_tab_ints) per plane).  Returns VS_ERR_UNSUPPORTED when the geometry
+// is outside what the kernel packs (the caller then launches the planes one by one).
+int launch_warp_nv12_list(const uint8_t* const* ys, uint8_t* const* yd, int n, size_t sstride, size_t dstride, int w, int h, size_t src_uv,
+                          size_t dst_uv, const int32_t* d_tabs, hipStream_t st) {
+    if (!ys || !yd || !d_tabs || n < 1 || w < 2 || h < 2 || (w & 1) || (h & 1)) { set_last_error("warp_nv12_list: invalid argument"); return VS_ERR_INVALID_ARG; }
+    typedef PlaneCfg<1> P1;
+    typedef PlaneCfg<2> P2;
+    const unsigned long long gx1 = (w + TW - 1) / TW, gy1 = (h + P1::THP - 1) / P1::THP, gx2 = (w / 2 + TW - 1) / TW, gy2 = (h / 2 + P2::THP - 1) / P2::THP;
+    const unsigned long long tpf = gx1 * gy1 + gx2 * gy2, total = tpf * (unsigned long long)n;
+    if (w >= 65536 || h >= 65536 || sstride >= (1ull << 24) || dstride >= (1ull << 24) || n >= 65536 || total * std::max(tpf, std::max(gx1, gx2)) >= (1ull << 31))
+        return VS_ERR_UNSUPPORTED;
+    uint32_t al = 0xFu;          // bit 0 / 1: luma source / destination 4-byte aligned; bit 2 / 3: chroma 8-byte aligned
+    if (sstride % 4) al &= ~1u;
+    if (dstride % 4) al &= ~2u;
+    if (sstride % 8 || src_uv % 8) al &= ~4u;
+    if (dstride % 8 || dst_uv % 8) al &= ~8u;
+    for (int i = 0; i < n; i++) {
+        if (!ys[i] || !yd[i]) { set_last_error("warp_nv12_list: null frame"); return VS_ERR_INVALID_ARG; }
+        if ((uintptr_t)ys[i] % 4) al &= ~1u;
+        if ((uintptr_t)yd[i] % 4) al &= ~2u;
+        if ((uintptr_t)ys[i] % 8) al &= ~4u;
+        if ((uintptr_t)yd[i] % 8) al &= ~8u;
+    }
+    const uint32_t flags = (al & 1u) | (al & 2u) | (uint32_t)VS_BORDER_BLACK << 2 | ((al >> 2) & 1u) << 5 | ((al >> 3) & 1u) << 6 | 0x100u | (uint32_t)n << 16;
+    const uint32_t mtpf = (uint32_t)((0x100000000ull + tpf - 1) / tpf), mgx1 = (uint32_t)((0x100000000ull + gx1 - 1) / gx1),
+                   mgx2 = (uint32_t)((0x100000000ull + gx2 - 1) / gx2);
+    hipLaunchKernelGGL(warp_nv12_kernel, dim3((unsigned)total), dim3(NT), 0, st, (gtab_t)d_tabs, nv12_tab_ints(w, h), (uint32_t)sstride, (uint32_t)dstride,
+                       (uint32_t)w | (uint32_t)h << 16, (uint32_t)w | (uint32_t)h << 16, flags, mtpf, mgx1, mgx2);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -1274,6 +1325,59 @@ int launch_warp_affine_hostM(const uint8_t* d_src, size_t sstride, size_t sframe
         launch_cn(a, grid, cn, d_tabs, st);
         VS_HIP_TRY(hipGetLastError());
     }
+    return VS_OK;
+}
+
+// NV12 surfaces (luma plane, interleaved chroma plane h * pitch behind it), host matrices: launches of four and more frames build
+// both planes' tables (chroma: the map with the halved translation) and warp them in ONE grid; fewer frames go plane by plane.
+int launch_warp_nv12_hostM(const uint8_t* d_src, size_t sstride, size_t sframe, uint8_t* d_dst, size_t dstride, size_t dframe, int w, int h,
+                           const float* h_M, int batch, hipStream_t st) {
+    if (!d_src || !d_dst || !h_M || w < 2 || h < 2 || (w & 1) || (h & 1) || batch <= 0 || sstride < (size_t)w || dstride < (size_t)w) {
+        set_last_error("warp_affine_nv12: invalid argument (w and h must be even)");
+        return VS_ERR_INVALID_ARG;
+    }
+    std::vector<float> Mc((size_t)batch * 6);
+    for (int b = 0; b < batch; b++) {
+        const float* m = h_M + 6 * b;
+        float* c = &Mc[6 * (size_t)b];
+        c[0] = m[0]; c[1] = m[1]; c[2] = m[2] * 0.5f;
+        c[3] = m[3]; c[4] = m[4]; c[5] = m[5] * 0.5f;
+    }
+    const size_t suv = (size_t)h * sstride, duv = (size_t)h * dstride;
+    const int block = nv12_tab_ints(w, h), sy = tab_layout(w, h).stride;
+    for (int b0 = 0; b0 < batch; b0 += MAXB) {
+        const int nb = std::min(MAXB, batch - b0);
+        int one = VS_ERR_UNSUPPORTED;
+        if (nb >= 4) {
+            int32_t* d_tabs = nullptr;
+            VS_TRY(op_tabs(st, (size_t)block * nb * sizeof(int32_t), &d_tabs));
+            const uint8_t* ys[MAXB];
+            uint8_t* yd[MAXB];
+            for (int plane = 0; plane < 2; plane++) {
+                WarpArgs a;
+                fill_common(a, d_src + (size_t)b0 * sframe + (plane ? suv : 0), sstride, sframe, plane ? w / 2 : w, plane ? h / 2 : h,
+                            d_dst + (size_t)b0 * dframe + (plane ? duv : 0), dstride, dframe, plane ? w / 2 : w, plane ? h / 2 : h, plane ? 2 : 1);
+                a.Minv_dev = nullptr;
+                const float* Ms = plane ? Mc.data() : h_M;
+                for (int b = 0; b < MAXB; b++) {
+                    if (b < nb) warp_invert(Ms + (size_t)(b0 + b) * 6, a.Minv_val + 6 * b);
+                    else for (int i = 0; i < 6; i++) a.Minv_val[6 * b + i] = 0.;
+                }
+                dim3 grid((a.c.dw + TW - 1) / TW, (a.c.dh + TH - 1) / TH, nb);
+                launch_cn(a, grid, plane ? 2 : 1, d_tabs + (plane ? sy : 0), st, VS_WARP_TABLES_ONLY, block);
+            }
+            for (int b = 0; b < nb; b++) { ys[b] = d_src + (size_t)(b0 + b) * sframe; yd[b] = d_dst + (size_t)(b0 + b) * dframe; }
+            one = launch_warp_nv12_list(ys, yd, nb, sstride, dstride, w, h, suv, duv, d_tabs, st);
+            if (one != VS_OK && one != VS_ERR_UNSUPPORTED) return one;
+        }
+        if (one == VS_ERR_UNSUPPORTED) {
+            VS_TRY(launch_warp_affine_hostM(d_src + (size_t)b0 * sframe, sstride, sframe, w, h, d_dst + (size_t)b0 * dframe, dstride, dframe, w, h, 1,
+                                            h_M + (size_t)b0 * 6, nb, st));
+            VS_TRY(launch_warp_affine_hostM(d_src + (size_t)b0 * sframe + suv, sstride, sframe, w / 2, h / 2, d_dst + (size_t)b0 * dframe + duv, dstride,
+                                            dframe, w / 2, h / 2, 2, Mc.data() + (size_t)b0 * 6, nb, st));
+        }
+    }
+    VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
 

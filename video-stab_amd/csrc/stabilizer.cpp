@@ -42,6 +42,7 @@
 #include "host_helper.h"
 #include "traj_state.h"
 #include "vs_common.h"
+#include "warp_tab.h"
 
 namespace vsd {
 
@@ -64,7 +65,7 @@ int ransac_fill_item(void* host_item, const float* d_from, const float* d_to, co
                      TrajState* traj, const TrajParams* tp, vs_debug_frame* dbg, int have_prev_gray);
 int launch_ransac_score_batch(const void* d_table, int items, int iters, int n_max, hipStream_t st);
 size_t tail_item_bytes();
-void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out);
+void tail_fill_item(void* host_item, int out_due, int out_idx, double* d_Minv_out, const WarpTabJob* tabs);
 size_t tail_in_bytes();
 void ransac_item_set_tail_in(void* host_item, void* d_tail_in);
 size_t tail_seg_bytes();
@@ -1499,7 +1500,8 @@ struct vs_batch {
     uint8_t* d_tin[2] = {nullptr, nullptr};         // per frame of a step: what the selection leaves for the tail
     ImgPair* d_pairs = nullptr;
     double* d_MinvB[2] = {nullptr, nullptr};        // inverse maps of the due frames of a step, 12 doubles each; two sets
-    int32_t* d_tabs[4] = {nullptr, nullptr, nullptr, nullptr};     // coordinate tables: [set] frame plane, [2 + set] chroma plane
+    int32_t* d_tabs[2] = {nullptr, nullptr};        // coordinate tables of those frames (warp_tab.h), tab_ints per frame; two sets
+    int tab_ints = 0;                               // one plane's table, or an NV12 surface's block of two
     hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {}, ev_warp[2] = {};
     bool bdet_valid[4] = {false, false, false, false}, warp_valid[2] = {false, false};
     int last_det_batch = -1, last_warp_set = -1, batch_id = 0, pend_set = 0;
@@ -1574,9 +1576,9 @@ int group_allocate(vs_batch* g) {
     const size_t o_minv[2] = {take((size_t)cap * 96), take((size_t)cap * 96)};
     int tow, toh;
     out_size(s0, s0->w, s0->h, &tow, &toh);
-    const size_t tab_bytes = warp_tabs_ints(std::max(s0->w, tow), std::max(s0->h, toh), cap) * sizeof(int32_t);
-    size_t o_tabs[4];
-    for (auto& o : o_tabs) o = take(tab_bytes);
+    g->tab_ints = s0->fmt == VS_FMT_NV12 ? nv12_tab_ints(s0->w, s0->h) : (int)warp_tabs_ints(std::max(s0->w, tow), std::max(s0->h, toh), 1);
+    size_t o_tabs[2];
+    for (auto& o : o_tabs) o = take((size_t)g->tab_ints * cap * sizeof(int32_t));
     G_HIP(g, hipMalloc((void**)&g->d_all, off));
     G_HIP(g, hipMemsetAsync(g->d_all, 0, off, g->st));
     uint8_t* b = g->d_all;
@@ -1586,7 +1588,7 @@ int group_allocate(vs_batch* g) {
         g->d_MinvB[i] = (double*)(b + o_minv[i]);
     }
     g->d_pairs = (ImgPair*)(b + o_pairs);
-    for (int i = 0; i < 4; i++) g->d_tabs[i] = (int32_t*)(b + o_tabs[i]);
+    for (int i = 0; i < 2; i++) g->d_tabs[i] = (int32_t*)(b + o_tabs[i]);
     size_t ho = 0;
     auto htake = [&](size_t bytes) { size_t o = ho; ho += (bytes + 255) & ~(size_t)255; return o; };
     g->ho_pairs = htake(sizeof(ImgPair) * cap * (2 + 2 * MAX_PYR));
@@ -1603,8 +1605,18 @@ int group_allocate(vs_batch* g) {
     return VS_OK;
 }
 
+// Where the frames of a step's warps come from and go to (border pad: the padded scratch frame is the source; crop-and-zoom: the
+// scratch frame is the destination, resized into the result afterwards).
+struct WarpEnds { const uint8_t* src; uint8_t* dst; };
+WarpEnds warp_ends(const vs_stab* o, const uint8_t* frame, uint8_t* d_out, int pad_idx, bool pad, bool crop) {
+    if (!pad && !crop) return {frame, d_out};
+    uint8_t* scratch = o->d_padB + (size_t)pad_idx * o->pad_frame_bytes;
+    return pad ? WarpEnds{scratch, d_out} : WarpEnds{frame, scratch};
+}
+
 // The warps of the step whose tails were queued last, 32 frames per launch (`what` = VS_WARP_ONLY / VS_WARP_ALL), or only their
-// coordinate tables (VS_WARP_TABLES_ONLY: queued right behind the tail, so they are ready long before the warps).
+// coordinate tables (VS_WARP_TABLES_ONLY: steps whose release workgroups have not built them - a Kalman stream's releases stay
+// inside its tail workgroup).  The frames' tables lie tab_ints apart in d_tabs[set].
 int group_ready_launches(vs_batch* g, int what) {
     vs_batch::Ready& R = g->ready;
     const vs_stab* s0 = g->m[0];
@@ -1613,48 +1625,63 @@ int group_ready_launches(vs_batch* g, int what) {
     const int bsz = p.border_size;
     const bool pad = bsz > 0 && !p.crop_n_zoom;                                                       // Stabilizer.cpp:981-990
     const bool crop = bsz > 0 && p.crop_n_zoom && s0->w - 2 * bsz > 0 && s0->h - 2 * bsz > 0;          // :1108-1124
+    const int pw = pad ? s0->w + 2 * bsz : s0->w, ph = pad ? s0->h + 2 * bsz : s0->h;
+    const size_t prow = (size_t)pw * s0->cn;
     int rc = VS_OK;
-    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernel takes WARP_BATCH_MAX frames per launch
+    for (int i0 = 0; i0 < R.n && rc == VS_OK; i0 += WARP_BATCH_MAX) {      // the warp kernels take WARP_BATCH_MAX frames per launch
         const int m = std::min(WARP_BATCH_MAX, R.n - i0);
         const bool tabs = m >= 4;
         if (what == VS_WARP_TABLES_ONLY && !tabs) continue;
         const int w = tabs ? what : VS_WARP_ALL;
-        if (pad || crop) {
-            // pad: the frames get their border first and the padded frames are warped into the (larger) results;
-            // crop-and-zoom: the frames are warped into scratch frames, whose inner part is then resized to the results
-            const uint8_t* srcs[WARP_BATCH_MAX];
-            uint8_t* dsts[WARP_BATCH_MAX];
-            const int pw = pad ? s0->w + 2 * bsz : s0->w, ph = pad ? s0->h + 2 * bsz : s0->h;
-            const size_t prow = (size_t)pw * s0->cn;
-            for (int i = 0; i < m; i++) {
-                const vs_stab* o = R.owner[i0 + i];
-                uint8_t* scratch = o->d_padB + (size_t)R.pad_idx[i0 + i] * o->pad_frame_bytes;
-                srcs[i] = pad ? scratch : R.srcs[i0 + i];
-                dsts[i] = pad ? R.dsts[i0 + i] : scratch;
-                if (pad && what != VS_WARP_TABLES_ONLY && rc == VS_OK)
-                    rc = launch_make_border(R.srcs[i0 + i], s0->src_pitch, s0->w, s0->h, s0->cn, scratch, prow, bsz, p.border_type, st);
-            }
-            if (rc == VS_OK)
-                rc = launch_warp_affine_list(srcs, dsts, m, pad ? prow : s0->src_pitch, pw, ph, pad ? R.stride : prow, pw, ph, s0->cn,
-                                             g->d_MinvB[R.set] + 12 * i0, 12, tabs ? g->d_tabs[R.set] + i0 * warp_tabs_ints(pw, ph, 1) : nullptr, st, w);
-            for (int i = 0; crop && what != VS_WARP_TABLES_ONLY && i < m && rc == VS_OK; i++)
-                rc = launch_resize_linear(dsts[i] + ((size_t)bsz * s0->w + bsz) * s0->cn, prow, s0->w - 2 * bsz, s0->h - 2 * bsz, s0->cn,
-                                          R.dsts[i0 + i], R.stride, R.owner[i0 + i]->orig_w, R.owner[i0 + i]->orig_h, st);
-            continue;
+        int32_t* T = tabs ? g->d_tabs[R.set] + (size_t)i0 * g->tab_ints : nullptr;
+        const uint8_t* srcs[WARP_BATCH_MAX];
+        uint8_t* dsts[WARP_BATCH_MAX];
+        for (int i = 0; i < m; i++) {
+            const WarpEnds e = warp_ends(R.owner[i0 + i], R.srcs[i0 + i], R.dsts[i0 + i], R.pad_idx[i0 + i], pad, crop);
+            srcs[i] = e.src; dsts[i] = e.dst;
+            // pad: the frames get their border first and the padded frames are warped into the (larger) results
+            if (pad && what != VS_WARP_TABLES_ONLY && rc == VS_OK)
+                rc = launch_make_border(R.srcs[i0 + i], s0->src_pitch, s0->w, s0->h, s0->cn, const_cast<uint8_t*>(e.src), prow, bsz, p.border_type, st);
         }
-        rc = launch_warp_affine_list(R.srcs.data() + i0, R.dsts.data() + i0, m, s0->src_pitch, s0->w, s0->h, R.stride, s0->w, s0->h, s0->cn,
-                                     g->d_MinvB[R.set] + 12 * i0, 12, tabs ? g->d_tabs[R.set] + i0 * warp_tabs_ints(s0->w, s0->h, 1) : nullptr, st, w);
-        if (rc == VS_OK && s0->fmt == VS_FMT_NV12) {
-            // interleaved chroma plane: half size, two channels, the map with the halved translation
+        if (rc != VS_OK) break;
+        if (s0->fmt == VS_FMT_NV12) {
+            // interleaved chroma plane: half size, two channels, the map with the halved translation (Minv + 6)
+            const size_t suv = src_uv(s0);
             const uint8_t* us[WARP_BATCH_MAX];
             uint8_t* ud[WARP_BATCH_MAX];
+            bool same_duv = true;
             for (int i = 0; i < m; i++) {
-                us[i] = R.srcs[i0 + i] + src_uv(s0);
-                ud[i] = R.dsts[i0 + i] + dst_uv(s0, R.dsts[i0 + i], R.stride);
+                us[i] = srcs[i] + suv;
+                ud[i] = dsts[i] + dst_uv(s0, dsts[i], R.stride);
+                same_duv &= dst_uv(s0, dsts[i], R.stride) == dst_uv(s0, dsts[0], R.stride);
             }
-            rc = launch_warp_affine_list(us, ud, m, s0->src_pitch, s0->w / 2, s0->h / 2, R.stride, s0->w / 2, s0->h / 2, 2, g->d_MinvB[R.set] + 12 * i0 + 6, 12,
-                                         tabs ? g->d_tabs[2 + R.set] + i0 * warp_tabs_ints(s0->w / 2, s0->h / 2, 1) : nullptr, st, w);
+            const int sy = tab_layout(s0->w, s0->h).stride;
+            if (tabs && w != VS_WARP_ONLY) {       // the tables by a launch per plane
+                rc = launch_warp_affine_list(srcs, dsts, m, s0->src_pitch, s0->w, s0->h, R.stride, s0->w, s0->h, 1, g->d_MinvB[R.set] + 12 * i0, 12, T, st,
+                                             VS_WARP_TABLES_ONLY, g->tab_ints);
+                if (rc == VS_OK)
+                    rc = launch_warp_affine_list(us, ud, m, s0->src_pitch, s0->w / 2, s0->h / 2, R.stride, s0->w / 2, s0->h / 2, 2,
+                                                 g->d_MinvB[R.set] + 12 * i0 + 6, 12, T + sy, st, VS_WARP_TABLES_ONLY, g->tab_ints);
+            }
+            if (w == VS_WARP_TABLES_ONLY || rc != VS_OK) continue;
+            // luma and chroma tiles of the launch's frames in ONE grid
+            int one = tabs && same_duv ? launch_warp_nv12_list(srcs, dsts, m, s0->src_pitch, R.stride, s0->w, s0->h, suv, dst_uv(s0, dsts[0], R.stride), T, st)
+                                       : VS_ERR_UNSUPPORTED;
+            if (one == VS_ERR_UNSUPPORTED) {       // (geometry outside what that kernel packs, or fewer than four frames: plane by plane)
+                rc = launch_warp_affine_list(srcs, dsts, m, s0->src_pitch, s0->w, s0->h, R.stride, s0->w, s0->h, 1, g->d_MinvB[R.set] + 12 * i0, 12, T, st,
+                                             tabs ? VS_WARP_ONLY : VS_WARP_ALL, g->tab_ints);
+                if (rc == VS_OK)
+                    rc = launch_warp_affine_list(us, ud, m, s0->src_pitch, s0->w / 2, s0->h / 2, R.stride, s0->w / 2, s0->h / 2, 2,
+                                                 g->d_MinvB[R.set] + 12 * i0 + 6, 12, tabs ? T + sy : nullptr, st, tabs ? VS_WARP_ONLY : VS_WARP_ALL, g->tab_ints);
+            } else rc = one;
+            continue;
         }
+        rc = launch_warp_affine_list(srcs, dsts, m, pad ? prow : s0->src_pitch, pw, ph, crop ? prow : R.stride, pw, ph, s0->cn,
+                                     g->d_MinvB[R.set] + 12 * i0, 12, T, st, w, g->tab_ints);
+        // crop-and-zoom: the inner part of the warped scratch frames is resized to the results
+        for (int i = 0; crop && what != VS_WARP_TABLES_ONLY && i < m && rc == VS_OK; i++)
+            rc = launch_resize_linear(dsts[i] + ((size_t)bsz * s0->w + bsz) * s0->cn, prow, s0->w - 2 * bsz, s0->h - 2 * bsz, s0->cn,
+                                      R.dsts[i0 + i], R.stride, R.owner[i0 + i]->orig_w, R.owner[i0 + i]->orig_h, st);
     }
     if (rc != VS_OK) g->err = get_last_error();
     return rc;
@@ -1726,8 +1753,17 @@ int group_run(vs_batch* g) {
     // step's images), uploaded in the middle of `pre`; which outputs become due and where their maps go is known on the host
     const int set = g->pend_set;
     vs_batch::Ready& R = g->next;           // (g->ready still holds the warps of the step before: they go out further down)
-    int idx = 0, n_max = 0, npend = 0, nseg = 0, any_apart = 0;
+    int idx = 0, n_max = 0, npend = 0, nseg = 0, any_apart = 0, all_apart = 1, ndue = 0;
     size_t pend_stride = 0;
+    for (vs_stab* s : act) {
+        for (const vs_stab::BFrame& b : s->bq) ndue += b.out_due ? 1 : 0;
+        if (s->p.smoothing_method == VS_SMOOTH_KALMAN) all_apart = 0;
+    }
+    // the coordinate tables of a due frame's warp are built by the workgroup that releases the frame (every stream but a Kalman
+    // one: those maps come out of the tail workgroup, and the step's tables are a launch of their own behind it)
+    const vs_params_c& p0 = s0->p;
+    const bool pad = p0.border_size > 0 && !p0.crop_n_zoom;
+    const bool crop = p0.border_size > 0 && p0.crop_n_zoom && s0->w - 2 * p0.border_size > 0 && s0->h - 2 * p0.border_size > 0;
     for (vs_stab* s : act) {
         const vs_params_c& p = s->p;
         const int ns = (int)s->bq.size(), first = idx;
@@ -1750,14 +1786,24 @@ int group_run(vs_batch* g) {
             ransac_item_set_last(h_rs + ransac_item_bytes() * idx, i == ns - 1 ? 1 : 0);
             ransac_item_set_tail_in(h_rs + ransac_item_bytes() * idx, g->d_tin[dset] + tail_in_bytes() * idx);
             double* minv = nullptr;
+            WarpTabJob jobs[2] = {{nullptr, nullptr, nullptr, 0, 0}, {nullptr, nullptr, nullptr, 0, 0}};
             if (b.out_due) {
                 if (npend > 0 && pend_stride != b.out_stride) return gfail(g, VS_ERR_INVALID_ARG, "batch mode: one output pitch per step");
                 minv = g->d_MinvB[set] + 12 * npend;
-                R.srcs[npend] = b.out_frame; R.dsts[npend] = b.d_out; R.slots[npend] = b.out_slot; R.owner[npend] = s; R.pad_idx[npend] = npad++;
+                R.srcs[npend] = b.out_frame; R.dsts[npend] = b.d_out; R.slots[npend] = b.out_slot; R.owner[npend] = s; R.pad_idx[npend] = npad;
+                // (launches of fewer than four frames - the rest of a step's due frames beyond a multiple of 32 - run without tables)
+                if (all_apart && std::min(WARP_BATCH_MAX, ndue - npend / WARP_BATCH_MAX * WARP_BATCH_MAX) >= 4) {
+                    const WarpEnds e = warp_ends(s, b.out_frame, b.d_out, npad, pad, crop);
+                    int32_t* T = g->d_tabs[set] + (size_t)npend * g->tab_ints;
+                    jobs[0] = WarpTabJob{T, e.src, e.dst, pad ? s->w + 2 * p0.border_size : s->w, pad ? s->h + 2 * p0.border_size : s->h};
+                    if (s->fmt == VS_FMT_NV12)
+                        jobs[1] = WarpTabJob{T + tab_layout(s->w, s->h).stride, e.src + src_uv(s), e.dst + dst_uv(s, e.dst, b.out_stride), s->w / 2, s->h / 2};
+                }
+                npad++;
                 pend_stride = b.out_stride;
                 npend++;
             }
-            tail_fill_item(h_tail + tail_item_bytes() * idx, b.out_due ? 1 : 0, b.out_idx, minv);
+            tail_fill_item(h_tail + tail_item_bytes() * idx, b.out_due ? 1 : 0, b.out_idx, minv, jobs);
             tail_item_set_seg(h_tail + tail_item_bytes() * idx, nseg);
         }
         tail_fill_seg(h_seg + tail_seg_bytes() * nseg, first, ns, s->d_M, s->d_traj, s->d_dbg, p.smoothing_method);
@@ -1887,13 +1933,15 @@ int group_run(vs_batch* g) {
     G_HIP(g, hipEventRecord(g->ev_blk[k % 4], st));
     // the warps of this step wait for the next one (or a drain); their maps exist once the tail has run: the coordinate tables
     // are built right behind it
-    R.n = npend; R.set = set; R.stride = pend_stride; R.valid = npend > 0; R.tabs_built = false;
+    R.n = npend; R.set = set; R.stride = pend_stride; R.valid = npend > 0; R.tabs_built = all_apart != 0;
     std::swap(g->ready, g->next);            // (the previous step's warps have been issued: g->ready was free)
     if (g->ready.valid) {
         g->pend_set = set ^ 1;
-        StageScope t(g->m[0], VS_STAGE_WARP_TABLES, st);
-        G_TRY(g, group_ready_launches(g, VS_WARP_TABLES_ONLY));
-        g->ready.tabs_built = true;
+        if (!g->ready.tabs_built) {          // (a Kalman stream in the step: the tables as a launch behind the tail)
+            StageScope t(g->m[0], VS_STAGE_WARP_TABLES, st);
+            G_TRY(g, group_ready_launches(g, VS_WARP_TABLES_ONLY));
+            g->ready.tabs_built = true;
+        }
     }
     for (vs_stab* s : act) {
         const vs_stab::BFrame& lb = s->bq.back();

@@ -274,19 +274,21 @@ __device__ __forceinline__ void traj_emit_device(TrajState* s, const TrajParams&
     __shared__ __attribute__((aligned(16))) float l_path[TRAJ_RING][3], l_tr[TRAJ_RING][3];
     const int n = n_seen >= 0 ? n_seen : s->n;
     static_assert((TRAJ_RING * 3) % (4 * 64) == 0 && offsetof(TrajState, transforms) % 16 == 0 && offsetof(TrajState, path) % 16 == 0, "ring copy");
-    if (blockDim.x == 64 && ((uintptr_t)s & 15) == 0) {
-        // one wave (the release kernel, the per-frame emit): three 16-byte loads per ring and lane, all in flight before the first
-        // LDS store - as a loop over blockDim the compiler made load - wait - store of each of its 12 rounds (24 round trips)
+    if (((uintptr_t)s & 15) == 0) {
+        // the first wave (the release kernel, the per-frame emit): three 16-byte loads per ring and lane, all in flight before the
+        // first LDS store - as a loop over blockDim the compiler made load - wait - store of each of its 12 rounds (24 round trips)
         constexpr int NV = TRAJ_RING * 3 / (4 * 64);
         const float4* gp = reinterpret_cast<const float4*>(&s->path[0][0]);
         const float4* gt = reinterpret_cast<const float4*>(&s->transforms[0][0]);
-        float4 a[NV], b[NV];
+        if (threadIdx.x < 64) {
+            float4 a[NV], b[NV];
 #pragma unroll
-        for (int k = 0; k < NV; k++) { a[k] = gp[threadIdx.x + 64 * k]; b[k] = gt[threadIdx.x + 64 * k]; }
+            for (int k = 0; k < NV; k++) { a[k] = gp[threadIdx.x + 64 * k]; b[k] = gt[threadIdx.x + 64 * k]; }
 #pragma unroll
-        for (int k = 0; k < NV; k++) {
-            reinterpret_cast<float4*>(&l_path[0][0])[threadIdx.x + 64 * k] = a[k];
-            reinterpret_cast<float4*>(&l_tr[0][0])[threadIdx.x + 64 * k] = b[k];
+            for (int k = 0; k < NV; k++) {
+                reinterpret_cast<float4*>(&l_path[0][0])[threadIdx.x + 64 * k] = a[k];
+                reinterpret_cast<float4*>(&l_tr[0][0])[threadIdx.x + 64 * k] = b[k];
+            }
         }
     } else {
         for (int i = threadIdx.x; i < TRAJ_RING * 3; i += blockDim.x) {

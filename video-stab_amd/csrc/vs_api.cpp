@@ -25,6 +25,8 @@ int ensure_device() {
     return VS_OK;
 }
 
+int launch_warp_nv12_hostM(const uint8_t* d_src, size_t sstride, size_t sframe, uint8_t* d_dst, size_t dstride, size_t dframe, int w, int h,
+                           const float* h_M, int batch, hipStream_t st);
 int launch_warp_affine_hostM(const uint8_t* d_src, size_t sstride, size_t sframe, int sw, int sh,
                              uint8_t* d_dst, size_t dstride, size_t dframe, int dw, int dh, int cn,
                              const float* h_M, int batch, hipStream_t st);
@@ -208,27 +210,9 @@ int vs_op_warp_affine_nv12(const void* d_src, size_t src_stride, void* d_dst, si
                            int w, int h, const float* M, int batch, size_t src_frame_bytes,
                            size_t dst_frame_bytes, void* stream) {
     VS_TRY(ensure_device());
-    if (!M || (w & 1) || (h & 1) || batch <= 0) {
-        set_last_error("warp_affine_nv12: w and h must be even");
-        return VS_ERR_INVALID_ARG;
-    }
-    // luma: full matrix
-    VS_TRY(launch_warp_affine_hostM((const uint8_t*)d_src, src_stride, src_frame_bytes, w, h,
-                                    (uint8_t*)d_dst, dst_stride, dst_frame_bytes, w, h, 1, M, batch,
-                                    (hipStream_t)stream));
-    // chroma: half-size two-channel plane, same rotation, translation halved
-    std::vector<float> Mc((size_t)batch * 6);
-    for (int b = 0; b < batch; b++) {
-        const float* m = M + 6 * b;
-        float* c = &Mc[6 * (size_t)b];
-        c[0] = m[0]; c[1] = m[1]; c[2] = m[2] * 0.5f;
-        c[3] = m[3]; c[4] = m[4]; c[5] = m[5] * 0.5f;
-    }
-    return launch_warp_affine_hostM((const uint8_t*)d_src + (size_t)h * src_stride, src_stride,
-                                    src_frame_bytes, w / 2, h / 2,
-                                    (uint8_t*)d_dst + (size_t)h * dst_stride, dst_stride,
-                                    dst_frame_bytes, w / 2, h / 2, 2, Mc.data(), batch,
-                                    (hipStream_t)stream);
+    // luma: the full matrix; chroma: the half-size two-channel plane, same rotation, translation halved
+    return launch_warp_nv12_hostM((const uint8_t*)d_src, src_stride, src_frame_bytes, (uint8_t*)d_dst, dst_stride, dst_frame_bytes, w, h, M, batch,
+                                  (hipStream_t)stream);
 }
 
 int vs_op_resize_gray(const void* d_src, size_t src_stride, int sw, int sh, int fmt, void* d_dst,

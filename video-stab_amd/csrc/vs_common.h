@@ -94,9 +94,13 @@ int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int 
                        const double* d_Minv, int batch, int32_t* d_tabs, hipStream_t st);
 // what: the whole launch, or its two halves apart (tables of the frames now, the warp later from the same d_tabs).
 enum { VS_WARP_ALL = 0, VS_WARP_TABLES_ONLY = 1, VS_WARP_ONLY = 2 };
+// tab_stride: ints between the tables of consecutive frames in d_tabs (0: packed, warp_tabs_ints(dw, dh, 1))
 int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
                             size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, int32_t* d_tabs,
-                            hipStream_t st, int what = VS_WARP_ALL);
+                            hipStream_t st, int what = VS_WARP_ALL, int tab_stride = 0);
+// NV12: both planes of n surfaces in one launch, from table blocks (warp_tab.h) that have been built
+int launch_warp_nv12_list(const uint8_t* const* ys, uint8_t* const* yd, int n, size_t sstride, size_t dstride, int w, int h, size_t src_uv,
+                          size_t dst_uv, const int32_t* d_tabs, hipStream_t st);
 int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
                        uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st);
 // Batched forms (batch mode): the images of `items` frames in one launch; d_pairs = device table of

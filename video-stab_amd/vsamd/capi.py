@@ -351,12 +351,15 @@ class VsLib:
         return d_out.download(img.shape, np.uint8)
 
     def warp_affine_nv12(self, img, w, h, M):
+        """img: one NV12 surface (h * 3 / 2 rows of w bytes) and one matrix, or a stack of n surfaces and n matrices (launches
+        of four and more surfaces warp both planes in one grid)."""
         img = np.ascontiguousarray(img)
-        M = np.ascontiguousarray(M, np.float32).reshape(1, 6)
+        M = np.ascontiguousarray(M, np.float32).reshape(-1, 6)
+        n = M.shape[0]
+        fb = img.nbytes // n
         d_in = DevBuf.from_array(self, img)
         d_out = DevBuf(self, img.nbytes)
-        self.check(self.lib.vs_op_warp_affine_nv12(d_in.ptr, w, d_out.ptr, w, w, h, _p(M, f32p), 1,
-                                                   img.nbytes, img.nbytes, None))
+        self.check(self.lib.vs_op_warp_affine_nv12(d_in.ptr, w, d_out.ptr, w, w, h, _p(M, f32p), n, fb, fb, None))
         self.sync()
         return d_out.download(img.shape, np.uint8)
 
