@@ -69,9 +69,10 @@ def clip_order(n_frames, n_steps):
     return [fwd[i % len(fwd)] for i in range(n_steps)]
 
 
-def cpu_baseline(width, height, frames, order_fn):
+def cpu_baseline(width, height, frames, order_fn, keep=0):
     """The oracle (CPU restatement of src/Stabilizer.cpp, kind "port") on the same workload,
-    single thread, bounded sample."""
+    single thread, bounded sample.  Also returns the push order and the first `keep` frames the oracle
+    produced, for check_outputs()."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     o = oracle_lib.load()
@@ -81,13 +82,19 @@ def cpu_baseline(width, height, frames, order_fn):
     s = o.stabilizer(p)
     warm, timed = 34, 90
     order = order_fn(len(frames), warm + timed)
+    kept = []
     for i in order[:warm]:
-        s.push(frames[i])
+        r = s.push(frames[i])
+        if r is not None and len(kept) < keep:
+            kept.append(r)
     t0 = time.perf_counter()
     n_out = 0
     for i in order[warm:]:
-        if s.push(frames[i]) is not None:
+        r = s.push(frames[i])
+        if r is not None:
             n_out += 1
+            if len(kept) < keep:
+                kept.append(r)
     dt = time.perf_counter() - t0
     s.close()
     # all-core variant of the same port (resize / corner response / LK points / warp rows spread over threads)
@@ -103,13 +110,35 @@ def cpu_baseline(width, height, frames, order_fn):
     dt_mt = time.perf_counter() - t1
     s.close()
     o.lib.vso_set_threads(1)
-    return {
+    return order, kept, {
         "value": round(timed / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": "%d steady-state stabilize() calls on %d frames of the same %dx%d clip, oracle/ single thread" % (
             timed, len(frames), width, height),
         "all_cores": {"value": round(60 / dt_mt, 3), "cores": nthr, "host_cores": ncores,
                       "note": "same port, threaded stages spread over %d threads" % nthr},
     }
+
+
+def check_outputs(vs, device, params, clip, w, h, batch, order, ref):
+    """The HIP path with the bench's own settings (batch mode, zero-copy, the resident clip of stream 0) over the pushes the
+    cpu_baseline leg has just put through the oracle: its first len(ref) outputs must equal the oracle's, byte for byte.  The
+    oracle is the checker here, nothing else; a mismatch ends the run."""
+    fb = w * h * 3
+    s = vs.stabilizer(params, device=device)
+    s.set_batch(batch)
+    s.set_zero_copy(True)
+    d_out = capi.DevBuf(vs, fb * (len(order) + 1))
+    k = 0
+    for i in order:
+        k += s.push_dev(clip.ptr + i * fb, w, h, w * 3, capi.FMT_BGR8, d_out.ptr + k * fb, w * 3)
+    s.sync()
+    n = min(k, len(ref))
+    for j in range(n):
+        if not np.array_equal(d_out.download((h, w, 3), np.uint8, j * fb), ref[j]):
+            raise SystemExit("bench.py: output %d of the HIP path differs from the oracle's (batch %d, zero-copy)" % (j, batch))
+    s.close()
+    d_out.free()
+    return n
 
 
 class StreamSet:
@@ -575,7 +604,7 @@ def main():
                        "streams_grouped": ss.grouped,
                        "clip": "%d distinct frames per stream rendered on the device, played in a cycle" % NF,
                        "warp_batch": ss.WB, "zero_copy": bool(args.zero_copy),
-                       "timed_frames_per_rank": [int(r[1]) for r in per_rank], "build": vs.lib.vs_build_tag().decode()},
+                       "timed_frames_per_region_per_rank": [int(r[1]) for r in per_rank], "timed_regions": args.regions, "build": vs.lib.vs_build_tag().decode()},
             "regions": {"count": args.regions, "value": "median", "frames_per_s": [round(total_frames / e, 1) for e in elapsed]},
             "roofline": roof,
             "whole_step": {"bytes_per_frame": round(whole_bytes), "achieved": round(whole, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -589,15 +618,27 @@ def main():
             names = ["copy_in", "gray", "pyramid", "lk", "ransac", "traj", "gftt", "warp", "warp_tables"]
             out["stage_us_per_launch"] = {names[k]: round(stage_ms[k] / max(stage_n[k], 1) * 1e3, 2) for k in range(capi.STAGE_COUNT)}
             out["stage_launches"] = {names[k]: stage_n[k] for k in range(capi.STAGE_COUNT)}
-    host_frames = ss.host_frames(0, 32) if rank == 0 and n_gpus == 1 and not args.config else []
-    ss.close()
+    baseline = rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not args.config
+    # (the CPU leg replays the FIRST pushes of the timed clip in the timed order: as many distinct frames as it pushes)
+    host_frames = ss.host_frames(0, 124 if baseline else 12) if rank == 0 and n_gpus == 1 and not args.config else []
+    ss.close(free_clips=False)
     if rank == 0:
+        if baseline:
+            N_CHECK = 48
+            order, ref, out["cpu_baseline"] = cpu_baseline(W, H, host_frames, lambda nf, n: [i % nf for i in range(n)], keep=N_CHECK)
+            out["outputs_checked"] = check_outputs(vs, local_rank, params, clips[0], W, H, max(1, min(64, args.batch)), order, ref)
+            out["outputs_note"] = ("the first %d stabilized frames of the timed clip (stream 0, the timed push order and settings: batch %d, "
+                                   "zero-copy) equal the frames the oracle produced for the same pushes in the cpu_baseline leg, byte for byte"
+                                   % (out["outputs_checked"], max(1, min(64, args.batch))))
+            del ref
         if n_gpus == 1 and not args.no_extras and not args.config:
             out["with_pcie"] = host_api_rate(vs, local_rank, params, host_frames[:12])
             out["with_pcie"]["cpp_class"] = cpp_class_rate(local_rank)
+    for c in clips:
+        c.free()
+    if rank == 0:
+        if n_gpus == 1 and not args.no_extras and not args.config:
             out["configs"] = {"configs[2]": config2(vs, comm, local_rank, args)}
-        if n_gpus == 1 and not args.no_cpu_baseline and not args.config:
-            out["cpu_baseline"] = cpu_baseline(W, H, host_frames, clip_order)
         print(json.dumps(out), flush=True)
     comm.close()
 

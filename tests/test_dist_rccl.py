@@ -55,4 +55,4 @@ def test_bench_step_through_the_rccl_communicator(gpu):
               "--no-extras", "--no-cpu-baseline"])
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["timed_frames_per_rank"] == [128]
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["timed_frames_per_region_per_rank"] == [128]

@@ -1183,3 +1183,91 @@ def test_members_of_a_vs_batch_are_driven_through_the_group_only(gpu):
     b.sync()
     assert m.counters().frames_in == 1
     b.close()
+
+
+def _oracle_outputs(oracle, frames, order, **params):
+    """The oracle's stabilized frames for the pushes `order` of `frames`, flush included (8 threads)."""
+    oracle.lib.vso_set_threads(8)
+    try:
+        so = oracle.stabilizer(oracle.params(**params))
+        out = []
+        for i in order:
+            r = so.push(frames[i])
+            if r is not None:
+                out.append(r)
+        while True:
+            r = so.flush(frames[0])
+            if r is None:
+                break
+            out.append(r)
+        so.close()
+        return out
+    finally:
+        oracle.lib.vso_set_threads(1)
+
+
+def test_bench_settings_full_hd_batches_of_64_against_oracle(gpu, oracle):
+    """What bench.py times, proven: BASELINE configs[1] with the bench's own settings - 1920x1080 BGR8, 200 corners, 21x21 LK,
+    smoothing radius 30, batches of 64, zero-copy input, a closed-loop clip rendered on the device (synth.make_clip_dev, here
+    downloaded for the oracle) - over two FULL batches (each batch's warps are two 32-frame warp_tab_kernel launches with their
+    halves of the batch's table set), a partial third one and the drain.  Every output frame array_equal to the oracle's."""
+    W, H, NF = 1920, 1080, 40
+    fb = W * H * 3
+    clip = synth.make_clip_dev(gpu, synth.SEED_CONFIG2, W, H, NF)
+    frames = [clip.download((H, W, 3), np.uint8, i * fb) for i in range(NF)]
+    n = 1 + 64 + 64 + 37                      # first frame, two full batches, a partial one
+    order = [i % NF for i in range(n)]
+    params = dict(max_corners=200, lk_win_size=21, lk_max_level=2, lk_max_iters=20, lk_epsilon=0.03, smoothing_radius=30)
+    ref = _oracle_outputs(oracle, frames, order, **params)
+    s = gpu.stabilizer(gpu.params(**params))
+    s.set_batch(64)
+    s.set_zero_copy(True)
+    d_out = capi.DevBuf(gpu, fb * (n + 1))
+    k = 0
+    for i in order:
+        k += s.push_dev(clip.ptr + i * fb, W, H, W * 3, capi.FMT_BGR8, d_out.ptr + k * fb, W * 3)
+    while s.flush_dev(d_out.ptr + k * fb, W * 3):
+        k += 1
+    s.sync()
+    assert k == len(ref) == n
+    for j in range(k):
+        assert np.array_equal(d_out.download((H, W, 3), np.uint8, j * fb), ref[j]), j
+    s.close()
+    clip.free()
+    d_out.free()
+
+
+def test_vs_batch_full_hd_8_streams_of_8_frames_against_oracle(gpu, oracle):
+    """BASELINE configs[4], one GPU's share at its real size: a vs_batch of 8 streams of 1920x1080, 8 frames per stream and step
+    (what `bench.py --streams 8` times), every stream's frames against the ORACLE directly (the small-size group tests compare
+    with standalone instances).  Each stream plays its own device-rendered clip; 44 pushes per stream: the 29-frame warm-up of
+    radius 30 and two steps of 64 due frames (two 32-frame warp launches each), then the drain."""
+    W, H, NF, S, n = 1920, 1080, 12, 8, 46
+    fb = W * H * 3
+    params = dict(max_corners=200, lk_win_size=21, lk_max_level=2, lk_max_iters=20, lk_epsilon=0.03, smoothing_radius=30)
+    order = [i % NF if (i // NF) % 2 == 0 else NF - 1 - i % NF for i in range(n)]
+    clips = [synth.make_clip_dev(gpu, synth.SEED_CONFIG2 + g, W, H, NF) for g in range(S)]
+    b = gpu.batch(gpu.params(**params), S, 8)
+    b.set_zero_copy(True)
+    d_out = [capi.DevBuf(gpu, fb * (n + 1)) for _ in range(S)]
+    k = [0] * S
+    for i in order:
+        prod = b.push_dev([c.ptr + i * fb for c in clips], W, H, W * 3, capi.FMT_BGR8, [d_out[g].ptr + k[g] * fb for g in range(S)], W * 3)
+        for g in range(S):
+            k[g] += prod[g]
+    while True:
+        prod = b.flush_dev([d_out[g].ptr + k[g] * fb for g in range(S)], W * 3)
+        for g in range(S):
+            k[g] += prod[g]
+        if not any(prod):
+            break
+    b.sync()
+    for g in range(S):
+        frames = [clips[g].download((H, W, 3), np.uint8, i * fb) for i in range(NF)]
+        ref = _oracle_outputs(oracle, frames, order, **params)
+        assert k[g] == len(ref) == n, g
+        for j in range(n):
+            assert np.array_equal(d_out[g].download((H, W, 3), np.uint8, j * fb), ref[j]), (g, j)
+    b.close()
+    for buf in clips + d_out:
+        buf.free()
