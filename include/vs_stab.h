@@ -454,6 +454,16 @@ int vs_roll_correct(vs_roll* r, const uint8_t* data, int w, int h, size_t stride
 int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t stride,
                         void* d_out, size_t out_stride);
 int vs_roll_sync(vs_roll* r);
+/* autoCorrectRoll for an NV12 surface in HBM (BASELINE configs[2]: decoder surfaces), ASYNCHRONOUS.  The reference has no NV12
+ * path; defined as the BGR operator's geometry applied per plane: the line search (resize x scale_factor, Canny, HoughLines,
+ * RollCorrection.cpp:35-119) runs on the luma plane (a gray picture: no cvtColor), the rotation about the picture centre
+ * (:141-149, BORDER_REPLICATE) is applied to the luma plane and, with the translation halved, to the half-size interleaved
+ * chroma plane.  uv_offset / out_uv_offset: where the chroma plane starts (0 = h * pitch).  The call queues the frame's
+ * line search and returns; the smoothed angle advances in call order on the host (its inputs - 24 bytes per frame - arrive
+ * asynchronously) and the rotation of call k is queued by call k + 4 or by vs_roll_sync.  Results are complete after
+ * vs_roll_sync; surfaces and result buffers must stay untouched until then.  vs_roll_get_state reports the last CLOSED frame. */
+int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset,
+                             void* d_out, size_t out_pitch, size_t out_uv_offset);
 /* smoothed angle (sSmoothedAngle), the angle detected on the last frame, lines found / used */
 int vs_roll_get_state(const vs_roll* r, double* smoothed_deg, double* detected_deg,
                       int* n_lines, int* n_used);
@@ -488,6 +498,17 @@ int vs_azc_apply(vs_azc* a, const uint8_t* data, int w, int h, size_t stride, in
 int vs_azc_apply_dev(vs_azc* a, const void* d_data, int w, int h, size_t stride, int cn,
                      void* d_out, size_t out_stride, int* out_w, int* out_h);
 int vs_azc_sync(vs_azc* a);
+/* autoZoomCrop for an NV12 surface in HBM, ASYNCHRONOUS (the BGR operator's geometry per plane: content mask from the luma
+ * plane, gray > 1; the crop rectangle as it is for the luma plane and halved (x/2, y/2, max(1, w/2), max(1, h/2)) for the
+ * half-size interleaved chroma plane; each plane scaled to its share of 640 x 360 by the reference's scale matrix,
+ * AutoZoomCrop.cpp:246-270).  d_out receives 640 x 360 (chroma 320 x 180 at out_uv_offset) or, on the fall-back paths, the
+ * unchanged w x h surface: out_pitch >= max(w, 640), out_uv_offset >= max(h, 360) * out_pitch.  The call queues the mask
+ * kernels and returns a ticket; the contour logic runs on the object's worker threads (it is host work in the reference too,
+ * :141-147), which then queue the crop-and-scale.  vs_azc_result(ticket) waits for that frame's host part and tells what
+ * came out; the pixels are complete after vs_azc_sync.  At most 8 frames in flight, results of the last 1024 tickets kept. */
+int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset,
+                          void* d_out, size_t out_pitch, size_t out_uv_offset, int64_t* ticket);
+int vs_azc_result(vs_azc* a, int64_t ticket, int* out_w, int* out_h, int32_t* info8);
 /* info8 = {n_contours, contour_points, crop_x, crop_y, crop_w, crop_h, iterations, cropped} */
 int vs_azc_get_info(const vs_azc* a, int32_t* info8);
 /* cvtColor + threshold(gray,1,255,BINARY) + morphologyEx(MORPH_CLOSE, 5x5 ellipse) -

@@ -115,6 +115,11 @@ typedef struct vso_roll vso_roll;
 vso_roll* vso_roll_create(const vs_roll_params_c* p);
 void vso_roll_destroy(vso_roll* r);
 int  vso_roll_correct(vso_roll* r, const uint8_t* data, int w, int h, size_t stride, uint8_t* out, size_t out_stride);
+/* NV12 surfaces (no reference path: the BGR operators' geometry per plane, see the definitions) */
+int  vso_roll_correct_nv12(vso_roll* r, const uint8_t* data, int w, int h, size_t stride, size_t uv_offset, uint8_t* out, size_t out_stride,
+                           size_t out_uv_offset);
+int  vso_azc_apply_nv12(const uint8_t* src, int w, int h, size_t stride, size_t uv_offset, uint8_t* out, size_t out_stride, size_t out_uv_offset,
+                        int32_t* out_w, int32_t* out_h, int32_t* info);
 void vso_roll_get(const vso_roll* r, double* smoothed, double* detected, int* n_lines, int* n_used);
 
 /* ---- vs::AutoZoomCrop restated (src/AutoZoomCrop.cpp:10-283) ------------------- */

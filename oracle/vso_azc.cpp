@@ -274,4 +274,33 @@ int vso_azc_apply(const uint8_t* src, int w, int h, size_t stride, int cn, uint8
     return 1;
 }
 
+// autoZoomCrop on an NV12 surface (luma plane of w x h, interleaved chroma plane of w/2 x h/2 pairs `uv_offset` bytes behind it,
+// one row pitch).  The reference has no NV12 path (its cvtColor(BGR2GRAY) throws on one channel): DEFINED as the BGR operator's
+// geometry applied per plane - content mask from the luma plane (gray > 1, the threshold of :121-127 on a picture that is gray
+// already), the crop rectangle (x, y, w, h) for the luma plane and (x/2, y/2, max(1, w/2), max(1, h/2)) for the chroma plane,
+// each plane scaled to its share of 640 x 360 (320 x 180 pairs) by the reference's scale matrix (:251-270, a CV_32F matrix).
+// out: luma rows of out_stride bytes, the chroma plane at out_uv_offset.  Returns 1 when cropped (else the surface is copied).
+int vso_azc_apply_nv12(const uint8_t* src, int w, int h, size_t stride, size_t uv_offset, uint8_t* out, size_t out_stride, size_t out_uv_offset,
+                       int32_t* out_w, int32_t* out_h, int32_t* info) {
+    int32_t inf[8];
+    std::vector<uint8_t> cm((size_t)w * h);
+    content_mask(src, w, h, stride, 1, cm.data());
+    azc_crop_rect(cm.data(), w, h, inf);
+    if (info) memcpy(info, inf, sizeof inf);
+    if (!inf[7]) {
+        for (int y = 0; y < h; y++) memcpy(out + (size_t)y * out_stride, src + (size_t)y * stride, (size_t)w);
+        for (int y = 0; y < h / 2; y++) memcpy(out + out_uv_offset + (size_t)y * out_stride, src + uv_offset + (size_t)y * stride, (size_t)w);
+        *out_w = w; *out_h = h;
+        return 0;
+    }
+    const int ux = inf[2] / 2, uy = inf[3] / 2, uw = std::max(1, inf[4] / 2), uh = std::max(1, inf[5] / 2);
+    const double My[6] = {(double)(float)(640.0 / inf[4]), 0, 0, 0, (double)(float)(360.0 / inf[5]), 0};
+    const double Mu[6] = {(double)(float)(320.0 / uw), 0, 0, 0, (double)(float)(180.0 / uh), 0};
+    warp_affine_d(src + (size_t)inf[3] * stride + (size_t)inf[2], inf[4], inf[5], stride, 1, out, 640, 360, out_stride, My, VS_BORDER_BLACK, g_threads);
+    warp_affine_d(src + uv_offset + (size_t)uy * stride + (size_t)ux * 2, uw, uh, stride, 2, out + out_uv_offset, 320, 180, out_stride, Mu,
+                  VS_BORDER_BLACK, g_threads);
+    *out_w = 640; *out_h = 360;
+    return 1;
+}
+
 }  // extern "C"

@@ -257,4 +257,57 @@ int vso_roll_correct(vso_roll* r, const uint8_t* data, int w, int h, size_t stri
     return 1;
 }
 
+// autoCorrectRoll on an NV12 surface.  The reference has no NV12 path: DEFINED as the BGR operator's geometry applied per plane -
+// the line search of :35-119 on the luma plane (resize, then Canny and HoughLines on it: a gray picture needs no cvtColor), the
+// angle recurrence unchanged (:76-77, :106-135), the rotation about the picture centre (:141-149, BORDER_REPLICATE) applied to
+// the luma plane and, with the translation halved, to the half-size interleaved chroma plane.
+int vso_roll_correct_nv12(vso_roll* r, const uint8_t* data, int w, int h, size_t stride, size_t uv_offset, uint8_t* out, size_t out_stride,
+                          size_t out_uv_offset) {
+    if (!data || w <= 0 || h <= 0) return 0;
+    const vs_roll_params_c& p = r->p;
+    if (r->first) { r->first = false; r->smoothed = 0.0; }
+    const int sw = (int)(w * p.scale_factor), sh = (int)(h * p.scale_factor);
+    std::vector<uint8_t> small;
+    const uint8_t* g = data;
+    int aw = w, ah = h;
+    size_t gs = stride;
+    if (sw > 0 && sh > 0) {
+        small.resize((size_t)sw * sh);
+        resize_linear_u8(data, w, h, stride, 1, small.data(), sw, sh, (size_t)sw);
+        g = small.data(); aw = sw; ah = sh; gs = (size_t)sw;
+    }
+    std::vector<uint8_t> edges((size_t)aw * ah);
+    canny(g, aw, ah, gs, p.canny_threshold_low, p.canny_threshold_high, edges.data());
+    std::vector<float> lines;
+    const int n = hough_lines(edges.data(), aw, ah, aw, p.hough_rho, p.hough_theta, p.hough_threshold, lines);
+    r->last_lines = n; r->last_used = 0; r->last_detected = 0.0;
+    double sum = 0.0;
+    int count = 0;
+    for (int i = 0; i < n; i++) {
+        const float theta = lines[2 * i + 1];
+        const double deg = (theta * 180.0 / CV_PI_D) - 90.0;
+        if (deg >= p.angle_filter_min && deg <= p.angle_filter_max) { sum += deg; ++count; }
+    }
+    r->last_used = count;
+    if (n == 0 || count == 0) {
+        r->smoothed *= p.angle_decay;
+    } else {
+        const double detected = sum / count;
+        r->last_detected = detected;
+        double na = p.angle_smoothing_alpha * detected + (1.0 - p.angle_smoothing_alpha) * r->smoothed;
+        double diff = na - r->smoothed;
+        if (std::fabs(diff) > p.max_angle_change_deg && p.max_angle_change_deg > 0.0) {
+            diff = (diff > 0) ? p.max_angle_change_deg : -p.max_angle_change_deg;
+            na = r->smoothed + diff;
+        }
+        r->smoothed = na;
+    }
+    double M[6];
+    rotation_matrix(w / 2.0f, h / 2.0f, r->smoothed, M);
+    const double Mc[6] = {M[0], M[1], M[2] * 0.5, M[3], M[4], M[5] * 0.5};
+    warp_affine_d(data, w, h, stride, 1, out, w, h, out_stride, M, VS_BORDER_REPLICATE, g_threads);
+    warp_affine_d(data + uv_offset, w / 2, h / 2, stride, 2, out + out_uv_offset, w / 2, h / 2, out_stride, Mc, VS_BORDER_REPLICATE, g_threads);
+    return 1;
+}
+
 }  // extern "C"

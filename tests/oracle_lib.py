@@ -311,6 +311,19 @@ class Oracle:
         shape = (oh.value, ow.value) if cn == 1 else (oh.value, ow.value, 3)
         return buf[:oh.value * ow.value * cn].reshape(shape).copy(), info
 
+    def auto_zoom_crop_nv12(self, surf, w, h):
+        """surf: (h * 3 / 2, w) NV12 surface -> the (360 * 3 / 2, 640) result (or the unchanged surface on the fall-back paths), info."""
+        surf = np.ascontiguousarray(surf)
+        ow_max, oh_max = max(w, 640), max(h, 360)
+        buf = np.zeros((oh_max * 3 // 2, ow_max), np.uint8)
+        ow, oh = C.c_int32(), C.c_int32()
+        info = np.zeros(8, np.int32)
+        self.lib.vso_azc_apply_nv12.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, u8p, C.c_size_t, C.c_size_t, i32p, i32p, i32p]
+        self.lib.vso_azc_apply_nv12(_p(surf, u8p), w, h, w, w * h, _p(buf, u8p), ow_max, ow_max * oh_max, C.byref(ow), C.byref(oh), _p(info, i32p))
+        W, H = ow.value, oh.value
+        out = np.concatenate([buf[:H, :W], buf[oh_max:oh_max + H // 2, :W]])
+        return out, info
+
     # ---- enhancer (vso_enhance.cpp) ---------------------------------------
     def enh_params(self, **kw):
         from vsamd.capi import VsEnhParams
@@ -465,6 +478,14 @@ class OracleRoll:
         h, w = frame.shape[:2]
         out = np.empty_like(frame)
         self.lib.vso_roll_correct(self.h, _p(frame, u8p), w, h, w * 3, _p(out, u8p), w * 3)
+        return out
+
+    def correct_nv12(self, surf, w, h):
+        """surf: (h * 3 / 2, w) NV12 surface, packed."""
+        surf = np.ascontiguousarray(surf)
+        out = np.empty_like(surf)
+        self.lib.vso_roll_correct_nv12.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, u8p, C.c_size_t, C.c_size_t]
+        self.lib.vso_roll_correct_nv12(self.h, _p(surf, u8p), w, h, w, w * h, _p(out, u8p), w, w * h)
         return out
 
     def state(self):

@@ -313,3 +313,41 @@ def test_roll_then_zoom_chain(gpu, oracle):
         assert np.array_equal(a, b)
         ref, _ = oracle.auto_zoom_crop(a)
         assert np.array_equal(ref, az.apply(b))
+
+
+@pytest.mark.gpu
+def test_auto_zoom_crop_nv12_async_matches_oracle(gpu, oracle):
+    """vs_azc_apply_nv12_dev: the mask kernels of a frame are queued by the call, the contour logic runs on worker threads (four
+    frames at a time), which queue the crop-and-scale of both planes.  Twelve surfaces - rotated content in black corners at
+    several angles and sizes of the black object, an all-black one (no contour: the surface comes back unchanged), an all-content
+    one - pushed without waiting; tickets, rectangles and planes against the oracle."""
+    from vsamd.capi import DevBuf
+    from vsamd import synth
+    w, h = 800, 450
+    frames = [rotated_frame(oracle, w, h, deg, seed=i) for i, deg in enumerate([4.0, -2.5, 1.0, 7.5, -6.0, 0.5, 3.0, -1.0, 2.0, -4.5])]
+    frames.insert(3, np.zeros((h, w, 3), np.uint8))
+    frames.insert(8, np.full((h, w, 3), 200, np.uint8))
+    surfs = [synth.bgr_to_nv12(f) for f in frames]
+    for s, f in zip(surfs, frames):
+        s[:h][(f == 0).all(axis=2)] = 0              # (BT.601 black is 16; the warp's black border in an NV12 stream is 0)
+    sb = w * h * 3 // 2
+    op, oh_max = 800, 450
+    ob = op * oh_max * 3 // 2
+    d_in = DevBuf.from_array(gpu, np.stack(surfs))
+    d_out = DevBuf(gpu, ob * len(surfs))
+    az = gpu.auto_zoom_crop()
+    tickets = [az.apply_nv12_dev(d_in.ptr + i * sb, w, h, w, d_out.ptr + i * ob, op, op * oh_max) for i in range(len(surfs))]
+    assert tickets == list(range(len(surfs)))
+    az.sync()
+    got = d_out.download((len(surfs), oh_max * 3 // 2, op), np.uint8)
+    cropped = 0
+    for i, s in enumerate(surfs):
+        ref, info = oracle.auto_zoom_crop_nv12(s, w, h)
+        ow, oh, ginfo = az.result(tickets[i])
+        assert ginfo.tolist() == info.tolist(), i
+        assert (ow, oh) == ((640, 360) if info[7] else (w, h)), i
+        assert np.array_equal(got[i, :oh, :ow], ref[:oh]), i
+        assert np.array_equal(got[i, oh_max:oh_max + oh // 2, :ow], ref[oh:]), i
+        cropped += int(info[7])
+    assert 9 <= cropped <= 11
+    az.close()

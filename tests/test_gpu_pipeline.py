@@ -1271,3 +1271,79 @@ def test_vs_batch_full_hd_8_streams_of_8_frames_against_oracle(gpu, oracle):
     b.close()
     for buf in clips + d_out:
         buf.free()
+
+
+def test_config3_chain_4k_nv12_roll_stabilize_zoomcrop_against_oracle(gpu, oracle):
+    """BASELINE configs[2] as ONE chain on decoder surfaces: 3840x2160 NV12, RollCorrection -> stabilize (400 corners, batch
+    mode) -> AutoZoomCrop, the reference's order of operators (examples/vs.cpp:553-562), every stage through its device entry
+    point without a wait per frame: the roll stage closes a frame four calls later, the stabilizer runs batches of 8, the zoom
+    stage's contour logic runs on its worker threads.  One host wait per stage and chunk.  Every 640x360 result (and the
+    stages' states) against the oracle's chain on the same surfaces."""
+    import roll_scene
+    W, H, N = 3840, 2160, 14
+    base = [synth.bgr_to_nv12(f) for f in synth.make_clip(synth.SEED_CONFIG3, W, H, 7)]
+    tilt = synth.bgr_to_nv12(roll_scene.horizon_frame(W, H, 45, seed=7))
+    surfs = []
+    for i in range(N):
+        s = base[i % 7].copy()
+        s[H // 3:H // 3 + 400] = tilt[H // 3:H // 3 + 400]          # a band with a tilted horizon: lines for the roll stage
+        surfs.append(s)
+    sb = W * H * 3 // 2
+    params = dict(smoothing_radius=5, max_corners=400)
+    # ---- oracle chain
+    oracle.lib.vso_set_threads(8)
+    try:
+        ro, so = oracle.roll_correction(), oracle.stabilizer(oracle.params(**params))
+        ref = []
+        for s in surfs:
+            r = ro.correct_nv12(s, W, H)
+            o = so.push(r, capi.FMT_NV12)
+            if o is not None:
+                ref.append(oracle.auto_zoom_crop_nv12(o, W, H))
+        while True:
+            o = so.flush(surfs[0], capi.FMT_NV12)
+            if o is None:
+                break
+            ref.append(oracle.auto_zoom_crop_nv12(o, W, H))
+        so.close()
+    finally:
+        oracle.lib.vso_set_threads(1)
+    # ---- device chain
+    rg, az = gpu.roll_correction(), gpu.auto_zoom_crop()
+    sg = gpu.stabilizer(gpu.params(**params))
+    sg.set_batch(8)
+    sg.set_zero_copy(True)
+    d_in = capi.DevBuf(gpu, sb * N)
+    for i, s in enumerate(surfs):
+        d_in.upload(s, i * sb)
+    d_roll, d_stab = capi.DevBuf(gpu, sb * N), capi.DevBuf(gpu, sb * (N + 1))
+    zp, zh = W, H                                   # result surfaces that fit the fall-back (unchanged frame) as well
+    zb = zp * zh * 3 // 2
+    d_zoom = capi.DevBuf(gpu, zb * (N + 1))
+    for i in range(N):
+        rg.correct_nv12_dev(d_in.ptr + i * sb, W, H, W, d_roll.ptr + i * sb, W)
+    rg.sync()
+    k = 0
+    for i in range(N):
+        k += sg.push_dev(d_roll.ptr + i * sb, W, H, W, capi.FMT_NV12, d_stab.ptr + k * sb, W)
+    while sg.flush_dev(d_stab.ptr + k * sb, W):
+        k += 1
+    sg.sync()
+    assert k == len(ref) == N
+    tickets = [az.apply_nv12_dev(d_stab.ptr + j * sb, W, H, W, d_zoom.ptr + j * zb, zp, zp * zh) for j in range(k)]
+    az.sync()
+    assert ro.state() == rg.state()
+    n_crop = 0
+    for j in range(k):
+        want, info = ref[j]
+        ow, oh, ginfo = az.result(tickets[j])
+        assert ginfo.tolist() == info.tolist(), j
+        assert (ow, oh) == ((640, 360) if info[7] else (W, H)), j
+        got = d_zoom.download((zh * 3 // 2, zp), np.uint8, j * zb)
+        assert np.array_equal(got[:oh, :ow], want[:oh]) and np.array_equal(got[zh:zh + oh // 2, :ow], want[oh:]), j
+        n_crop += int(info[7])
+    assert n_crop >= N - 1
+    for o in (rg, az, sg):
+        o.close()
+    for b in (d_in, d_roll, d_stab, d_zoom):
+        b.free()

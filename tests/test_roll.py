@@ -265,3 +265,70 @@ def test_roll_device_entry_point(gpu, oracle):
         rg.correct_dev(d_in.ptr, 640, 360, 640 * 3, d_out.ptr, 640 * 3)
         rg.sync()
         assert np.array_equal(ref, d_out.download(f.shape, np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,slope,padded", [((640, 360), 51, False), ((1280, 720), -33, True), ((322, 242), 20, True)])
+def test_roll_correct_nv12_async_matches_oracle(gpu, oracle, size, slope, padded):
+    """vs_roll_correct_nv12_dev: NV12 surfaces in HBM, no wait for the device per frame - the line searches of four frames are
+    in flight on worker streams, the smoothed angle advances in call order when a frame's 24-byte result has arrived, and a
+    frame's rotation (both planes) is queued four calls later or by the sync.  Eleven frames (a flat one for the decay
+    branch in the middle), decoder-style surfaces (padded pitch, chroma plane behind padding rows) in two of three cases:
+    planes and state equal the oracle's, padding untouched."""
+    from vsamd.capi import DevBuf
+    from vsamd import synth
+    w, h = size
+    thr = 100 if w >= 640 else 40
+    ro = oracle.roll_correction(oracle.roll_params(hough_threshold=thr))
+    rg = gpu.roll_correction(gpu.roll_params(hough_threshold=thr))
+    frames = [roll_scene.horizon_frame(w, h, slope + i, seed=i, offset=i - 3) for i in range(10)]
+    frames.insert(5, np.full((h, w, 3), 77, np.uint8))
+    surfs = [synth.bgr_to_nv12(f) for f in frames]
+    pitch = (w + 63) // 64 * 64 + 64 if padded else w
+    hal = h + 6 if padded else h                     # rows the luma plane is allotted
+    sb = pitch * (hal + h // 2)
+    host = np.full((len(surfs), hal + h // 2, pitch), 0xA5, np.uint8)
+    for i, s in enumerate(surfs):
+        host[i, :h, :w] = s[:h]
+        host[i, hal:hal + h // 2, :w] = s[h:]
+    d_in = DevBuf.from_array(gpu, host)
+    d_out = DevBuf(gpu, host.nbytes)
+    gpu.check(gpu.lib.vs_dev_memset(d_out.ptr, 0x5A, host.nbytes))
+    for i in range(len(surfs)):
+        rg.correct_nv12_dev(d_in.ptr + i * sb, w, h, pitch, d_out.ptr + i * sb, pitch, uv_offset=pitch * hal, out_uv_offset=pitch * hal)
+    rg.sync()
+    got = d_out.download(host.shape, np.uint8)
+    for i, s in enumerate(surfs):
+        ref = ro.correct_nv12(s, w, h)
+        assert np.array_equal(got[i, :h, :w], ref[:h]), i
+        assert np.array_equal(got[i, hal:hal + h // 2, :w], ref[h:]), i
+    assert ro.state() == rg.state() and ro.state()[0] != 0.0
+    if padded:
+        assert (got[:, :h, w:] == 0x5A).all() and (got[:, h:hal] == 0x5A).all() and (got[:, hal:, w:] == 0x5A).all()
+
+
+@pytest.mark.gpu
+def test_roll_correct_nv12_async_when_the_edge_growth_needs_many_passes(gpu, oracle):
+    """The asynchronous path checks the hysteresis flag when it closes a frame and finishes the growth then (the rare frame)."""
+    from vsamd.capi import DevBuf
+    h, w = 400, 300
+    g = np.full((h, w), 100, np.uint8)
+    xs = list(range(10, w - 20, 24))
+    for i, x in enumerate(xs):
+        g[20:h - 20, x:x + 6] = 112
+        if i + 1 < len(xs):
+            y = h - 26 if i % 2 == 0 else 20
+            g[y:y + 6, x:x + 30] = 112
+    g[20:26, 10:16] = 230
+    surf = np.concatenate([g, np.full((h // 2, w), 128, np.uint8)])
+    kw = dict(scale_factor=1.0, canny_threshold_low=20, canny_threshold_high=100, hough_threshold=60,
+              angle_filter_min=-100.0, angle_filter_max=100.0)
+    ro, rg = oracle.roll_correction(oracle.roll_params(**kw)), gpu.roll_correction(gpu.roll_params(**kw))
+    d_in, d_out = DevBuf.from_array(gpu, surf), DevBuf(gpu, surf.nbytes * 6)
+    for i in range(6):
+        rg.correct_nv12_dev(d_in.ptr, w, h, w, d_out.ptr + i * surf.nbytes, w)
+    rg.sync()
+    got = d_out.download((6,) + surf.shape, np.uint8)
+    for i in range(6):
+        assert np.array_equal(got[i], ro.correct_nv12(surf, w, h)), i
+    assert ro.state() == rg.state() and ro.state()[2] > 4

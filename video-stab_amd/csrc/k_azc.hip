@@ -18,6 +18,10 @@
 #include <vector>
 
 #include "azc_contour.h"
+#include <condition_variable>
+#include <deque>
+#include <thread>
+
 #include "vs_common.h"
 
 namespace vsd {
@@ -165,6 +169,32 @@ struct vs_azc {
     size_t io_bytes = 0;
     CropScratch scratch;
     int32_t info[8] = {0};
+    // ---- asynchronous NV12 path (vs_azc_apply_nv12_dev) ----
+    // The mask kernels of a frame are queued by the call; the contour logic - host work in the reference as well
+    // (AutoZoomCrop.cpp:141-147 downloads the mask for cv::findContours) - runs on worker threads, NW frames at a time (frames do
+    // not depend on each other), and the worker then queues the crop-and-scale of both planes.  NS frames in flight.
+    static constexpr int NS = 8, NW = 4, NRES = 1024;
+    struct Slot {
+        uint8_t* d_mask = nullptr;
+        uint8_t* h_mask = nullptr;
+        u64* d_tbits = nullptr;
+        hipEvent_t ev = nullptr;
+        int mw = 0, mh = 0;
+        bool busy = false;
+        long ticket = 0;
+        const uint8_t* src = nullptr;
+        uint8_t* dst = nullptr;
+        int w = 0, h = 0;
+        size_t pitch = 0, uv = 0, opitch = 0, ouv = 0;
+    } slot[NS];
+    struct Result { long ticket = -1; int out_w = 0, out_h = 0, rc = 0; int32_t info[8] = {0}; } results[NRES];
+    hipStream_t st_out = nullptr;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<int> jobs;
+    bool quit = false;
+    long issued = 0, completed = 0;
 };
 
 #define A_HIP(a, expr)                                                             \
@@ -219,6 +249,18 @@ int vs_azc_create(int device, vs_azc** out) {
 void vs_azc_destroy(vs_azc* a) {
     if (!a) return;
     (void)hipSetDevice(a->device);
+    if (!a->workers.empty()) {
+        { std::lock_guard<std::mutex> g(a->mu); a->quit = true; }
+        a->cv_job.notify_all();
+        for (auto& t : a->workers) t.join();
+    }
+    if (a->st_out) { (void)hipStreamSynchronize(a->st_out); (void)hipStreamDestroy(a->st_out); }
+    for (auto& q : a->slot) {
+        if (q.d_mask) (void)hipFree(q.d_mask);
+        if (q.h_mask) (void)hipHostFree(q.h_mask);
+        if (q.d_tbits) (void)hipFree(q.d_tbits);
+        if (q.ev) (void)hipEventDestroy(q.ev);
+    }
     if (a->st) (void)hipStreamSynchronize(a->st);
     if (a->d_mask) (void)hipFree(a->d_mask);
     if (a->h_mask) (void)hipHostFree(a->h_mask);
@@ -240,6 +282,12 @@ int vs_azc_get_info(const vs_azc* a, int32_t* info8) {
 int vs_azc_sync(vs_azc* a) {
     if (!a) return VS_ERR_INVALID_ARG;
     A_HIP(a, hipSetDevice(a->device));
+    if (!a->workers.empty()) {          // asynchronous NV12 frames: their host parts first, then what the workers queued
+        std::unique_lock<std::mutex> lk(a->mu);
+        a->cv_done.wait(lk, [&] { return a->completed == a->issued; });
+        lk.unlock();
+        A_HIP(a, hipStreamSynchronize(a->st_out));
+    }
     A_HIP(a, hipStreamSynchronize(a->st));
     return VS_OK;
 }
@@ -328,6 +376,135 @@ int vs_azc_apply(vs_azc* a, const uint8_t* data, int w, int h, size_t stride, in
     A_HIP(a, hipStreamSynchronize(a->st));
     *out_w = ow; *out_h = oh;
     return VS_OK;
+}
+
+// ---- NV12, asynchronous ----------------------------------------------------------------------------------------------------
+// One frame's host part, on a worker thread: wait for its mask, contour logic, queue crop-and-scale (or the copy of the
+// fall-back paths) of both planes on st_out.  The content mask is taken from the luma plane (gray > 1, :121-127 on a picture
+// that is gray already); the crop rectangle applies to the luma plane as it is and, halved, to the half-size chroma plane;
+// each plane is scaled to its share of 640 x 360 by the reference's scale matrix (:261-270).
+static void azc_worker(vs_azc* a) {
+    (void)hipSetDevice(a->device);
+    CropScratch scratch;
+    for (;;) {
+        int si;
+        {
+            std::unique_lock<std::mutex> lk(a->mu);
+            a->cv_job.wait(lk, [&] { return a->quit || !a->jobs.empty(); });
+            if (a->jobs.empty()) return;
+            si = a->jobs.front();
+            a->jobs.pop_front();
+        }
+        vs_azc::Slot& q = a->slot[si];
+        vs_azc::Result res;
+        res.ticket = q.ticket;
+        int rc = VS_OK;
+        if (hipEventSynchronize(q.ev) != hipSuccess) rc = VS_ERR_HIP;
+        if (rc == VS_OK) {
+            BitFrame bf;
+            bf.w = q.w; bf.h = q.h; bf.pitch = BitFrame::pitch_for(q.w); bf.F = (const uint64_t*)q.h_mask;
+            crop_from_mask(bf, scratch, res.info, nullptr);                                                // :146-228
+            if (!res.info[7]) {                                                                            // :149-152, :238-249
+                res.out_w = q.w; res.out_h = q.h;
+                if (hipMemcpy2DAsync(q.dst, q.opitch, q.src, q.pitch, (size_t)q.w, q.h, hipMemcpyDeviceToDevice, a->st_out) != hipSuccess ||
+                    hipMemcpy2DAsync(q.dst + q.ouv, q.opitch, q.src + q.uv, q.pitch, (size_t)q.w, q.h / 2, hipMemcpyDeviceToDevice, a->st_out) != hipSuccess)
+                    rc = VS_ERR_HIP;
+            } else {
+                res.out_w = 640; res.out_h = 360;
+                const int cx = res.info[2], cy = res.info[3], cw = res.info[4], ch = res.info[5];
+                const int ux = cx / 2, uy = cy / 2, uw = std::max(1, cw / 2), uh = std::max(1, ch / 2);
+                const float My[6] = {(float)(640.0 / cw), 0.f, 0.f, 0.f, (float)(360.0 / ch), 0.f};
+                const float Mu[6] = {(float)(320.0 / uw), 0.f, 0.f, 0.f, (float)(180.0 / uh), 0.f};
+                double Iy[6], Iu[6];
+                warp_invert(My, Iy);
+                warp_invert(Mu, Iu);
+                rc = launch_warp_affine_inv(q.src + (size_t)cy * q.pitch + cx, q.pitch, cw, ch, q.dst, q.opitch, 640, 360, 1, Iy, VS_BORDER_BLACK, a->st_out);
+                if (rc == VS_OK)
+                    rc = launch_warp_affine_inv(q.src + q.uv + (size_t)uy * q.pitch + (size_t)ux * 2, q.pitch, uw, uh, q.dst + q.ouv, q.opitch, 320, 180, 2, Iu,
+                                                VS_BORDER_BLACK, a->st_out);
+            }
+        }
+        res.rc = rc;
+        {
+            std::lock_guard<std::mutex> g(a->mu);
+            a->results[res.ticket % vs_azc::NRES] = res;
+            q.busy = false;
+            a->completed++;
+        }
+        a->cv_done.notify_all();
+    }
+}
+
+// autoZoomCrop for an NV12 surface in HBM, ASYNCHRONOUS.  d_out receives the result - 640 x 360 (luma rows of out_pitch bytes,
+// the 320 x 180 interleaved chroma plane out_uv_offset bytes behind) or, on the reference's fall-back paths, the unchanged
+// w x h surface - so out_pitch >= max(w, 640) and out_uv_offset >= max(h, 360) * out_pitch.  The call returns at once with a
+// ticket; vs_azc_result(ticket) tells what came out (it waits for that frame's host part), the pixels are complete after
+// vs_azc_sync.  Surface and result buffer must stay untouched until then; at most 8 frames are in flight (the call waits
+// for the oldest), results of the last 1024 tickets are kept.
+int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset, void* d_out, size_t out_pitch,
+                          size_t out_uv_offset, int64_t* ticket) {
+    if (!a || !d_surface || !d_out || w < 2 || h < 2 || (w & 1) || (h & 1) || pitch < (size_t)w || out_pitch < (size_t)std::max(w, 640) ||
+        out_uv_offset < (size_t)std::max(h, 360) * out_pitch)
+        return VS_ERR_INVALID_ARG;
+    if (w > 65535 || h > 32767) { a->err = "auto zoom/crop: image too large"; set_last_error(a->err); return VS_ERR_INVALID_ARG; }
+    if (uv_offset == 0) uv_offset = (size_t)h * pitch;
+    A_HIP(a, hipSetDevice(a->device));
+    if (a->workers.empty()) {
+        A_HIP(a, hipStreamCreateWithFlags(&a->st_out, hipStreamNonBlocking));
+        try {
+            for (int i = 0; i < vs_azc::NW; i++) a->workers.emplace_back(azc_worker, a);
+        } catch (...) {
+            a->err = "auto zoom/crop: cannot start worker threads"; set_last_error(a->err);
+            return VS_ERR_HIP;
+        }
+    }
+    vs_azc::Slot& q = a->slot[a->issued % vs_azc::NS];
+    {
+        std::unique_lock<std::mutex> lk(a->mu);
+        a->cv_done.wait(lk, [&] { return !q.busy; });
+    }
+    const size_t mb = BitFrame::words_for(w, h) * 8;
+    if (q.mw != w || q.mh != h) {
+        if (q.d_mask) (void)hipFree(q.d_mask);
+        if (q.h_mask) (void)hipHostFree(q.h_mask);
+        if (q.d_tbits) (void)hipFree(q.d_tbits);
+        q.d_mask = q.h_mask = nullptr; q.d_tbits = nullptr; q.mw = q.mh = 0;
+        A_HIP(a, hipMalloc((void**)&q.d_mask, mb));
+        A_HIP(a, hipMalloc((void**)&q.d_tbits, (size_t)((w + 63) / 64) * h * 8));
+        A_HIP(a, hipHostMalloc((void**)&q.h_mask, mb, hipHostMallocDefault));
+        A_HIP(a, hipMemsetAsync(q.d_mask, 0, mb, a->st));          // the frame of the BitFrame; the kernel rewrites the inside
+        if (!q.ev) A_HIP(a, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+        q.mw = w; q.mh = h;
+    }
+    q.src = (const uint8_t*)d_surface; q.dst = (uint8_t*)d_out; q.w = w; q.h = h;
+    q.pitch = pitch; q.uv = uv_offset; q.opitch = out_pitch; q.ouv = out_uv_offset;
+    A_TRY(a, launch_content_bits(q.src, pitch, w, h, 1, q.d_tbits, (u64*)q.d_mask, BitFrame::pitch_for(w), 1, a->st));      // :111-139 on the luma plane
+    A_HIP(a, hipMemcpyAsync(q.h_mask, q.d_mask, mb, hipMemcpyDeviceToHost, a->st));                                          // :142-143
+    A_HIP(a, hipEventRecord(q.ev, a->st));
+    {
+        std::lock_guard<std::mutex> g(a->mu);
+        q.busy = true;
+        q.ticket = a->issued;
+        a->jobs.push_back((int)(a->issued % vs_azc::NS));
+        if (ticket) *ticket = a->issued;
+        a->issued++;
+    }
+    a->cv_job.notify_one();
+    return VS_OK;
+}
+
+// What ticket's frame became: waits for its host part (not for the pixels: vs_azc_sync).
+int vs_azc_result(vs_azc* a, int64_t ticket, int* out_w, int* out_h, int32_t* info8) {
+    if (!a || ticket < 0) return VS_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lk(a->mu);
+    if (ticket >= a->issued || ticket + vs_azc::NRES <= a->issued) { a->err = "auto zoom/crop: no such ticket (results of the last 1024 frames are kept)"; set_last_error(a->err); return VS_ERR_INVALID_ARG; }
+    a->cv_done.wait(lk, [&] { return a->results[ticket % vs_azc::NRES].ticket == ticket; });
+    const vs_azc::Result& r = a->results[ticket % vs_azc::NRES];
+    if (out_w) *out_w = r.out_w;
+    if (out_h) *out_h = r.out_h;
+    if (info8) memcpy(info8, r.info, sizeof r.info);
+    if (r.rc != VS_OK) { a->err = "auto zoom/crop: a worker's launch failed"; set_last_error(a->err); }
+    return r.rc;
 }
 
 }  // extern "C"

@@ -565,6 +565,24 @@ struct vs_roll {
     double smoothed = 0.0;       // sSmoothedAngle (RollCorrection.cpp:14)
     double last_detected = 0.0;
     int last_lines = 0, last_used = 0;
+    // asynchronous NV12 path (vs_roll_correct_nv12_dev): the line search of a frame does not depend on the frames before it -
+    // only the smoothed angle does, a three-flop recurrence on the host.  RS frames are in flight, each on a worker stream with
+    // a work area of its own; call k first closes frame k - RS (its 24-byte result has long arrived: EMA, clamp, decay, rotation
+    // matrix, the rotation of both planes queued on `st`), then queues the analysis of frame k.  No wait for the device in the
+    // steady state unless the caller is RS frames ahead of it.
+    static constexpr int RS = 4;
+    struct Slot {
+        RollWork wk;
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        int32_t* h_res = nullptr;        // page-locked: counters[16], hysteresis flags[16], pad, RollResult at byte 256
+        const uint8_t* src = nullptr;
+        uint8_t* dst = nullptr;
+        int w = 0, h = 0;
+        size_t pitch = 0, uv = 0, opitch = 0, ouv = 0;
+    } slot[RS];
+    long nv_in = 0, nv_done = 0;          // frames queued / closed
+    long slow_frames = 0;                 // frames whose edge set was still growing after the first group of passes
 };
 
 namespace {
@@ -657,6 +675,12 @@ int vs_roll_create(const vs_roll_params_c* params, int device, vs_roll** out) {
 void vs_roll_destroy(vs_roll* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
+    for (auto& q : r->slot) {
+        if (q.st) { (void)hipStreamSynchronize(q.st); (void)hipStreamDestroy(q.st); }
+        if (q.ev) (void)hipEventDestroy(q.ev);
+        if (q.h_res) (void)hipHostFree(q.h_res);
+        roll_work_free(q.wk);
+    }
     if (r->st) (void)hipStreamSynchronize(r->st);
     roll_work_free(r->wk);
     if (r->d_in) (void)hipFree(r->d_in);
@@ -692,6 +716,25 @@ int vs_roll_get_state(const vs_roll* r, double* smoothed_deg, double* detected_d
 #define R_TRY(r, expr)                                                             \
     do { int _s = (expr); if (_s != VS_OK) { (r)->err = get_last_error(); return _s; } } while (0)
 
+// The angle recurrence of RollCorrection.cpp:76-77, :106-135 on a frame's line statistics.
+static void roll_update(vs_roll* r, const RollResult& res) {
+    const vs_roll_params_c& p = r->p;
+    r->last_lines = res.n_lines; r->last_used = res.count; r->last_detected = 0.0;
+    if (res.n_lines == 0 || res.count == 0) {
+        r->smoothed *= p.angle_decay;                                                             // :76-77,:122-123
+    } else {
+        const double detected = res.sum_deg / res.count;                                          // :125-135
+        r->last_detected = detected;
+        double na = p.angle_smoothing_alpha * detected + (1.0 - p.angle_smoothing_alpha) * r->smoothed;
+        double diff = na - r->smoothed;
+        if (std::fabs(diff) > p.max_angle_change_deg && p.max_angle_change_deg > 0.0) {
+            diff = (diff > 0) ? p.max_angle_change_deg : -p.max_angle_change_deg;
+            na = r->smoothed + diff;
+        }
+        r->smoothed = na;
+    }
+}
+
 // autoCorrectRoll on device buffers (BGR8 in, BGR8 out, same size)
 int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t stride, void* d_out, size_t out_stride) {
     if (!r || !d_data || !d_out || w <= 0 || h <= 0 || stride < (size_t)w * 3 || out_stride < (size_t)w * 3) return VS_ERR_INVALID_ARG;
@@ -717,20 +760,7 @@ int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t str
         R_HIP(r, hipMemcpyAsync(&res, k.res, sizeof res, hipMemcpyDeviceToHost, r->st));
         R_HIP(r, hipStreamSynchronize(r->st));
     }
-    r->last_lines = res.n_lines; r->last_used = res.count; r->last_detected = 0.0;
-    if (res.n_lines == 0 || res.count == 0) {
-        r->smoothed *= p.angle_decay;                                                             // :76-77,:122-123
-    } else {
-        const double detected = res.sum_deg / res.count;                                          // :125-135
-        r->last_detected = detected;
-        double na = p.angle_smoothing_alpha * detected + (1.0 - p.angle_smoothing_alpha) * r->smoothed;
-        double diff = na - r->smoothed;
-        if (std::fabs(diff) > p.max_angle_change_deg && p.max_angle_change_deg > 0.0) {
-            diff = (diff > 0) ? p.max_angle_change_deg : -p.max_angle_change_deg;
-            na = r->smoothed + diff;
-        }
-        r->smoothed = na;
-    }
+    roll_update(r, res);
     // cv::getRotationMatrix2D(center, angle, 1.0) (:141-144)
     const float cx = w / 2.0f, cy = h / 2.0f;
     const double a = r->smoothed * 3.1415926535897932384626433832795 / 180;
@@ -739,9 +769,77 @@ int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t str
     return vs_op_warp_affine_ex(d_data, stride, w, h, d_out, out_stride, w, h, 3, M, VS_BORDER_REPLICATE, r->st);   // :146-149
 }
 
+// Closes the oldest frame in flight: its result is on the host (or arrives now), the angle advances, the rotation is queued.
+static int roll_close_oldest(vs_roll* r) {
+    vs_roll::Slot& q = r->slot[r->nv_done % vs_roll::RS];
+    const vs_roll_params_c& p = r->p;
+    R_HIP(r, hipEventSynchronize(q.ev));
+    RollResult res;
+    memcpy(&res, reinterpret_cast<const uint8_t*>(q.h_res) + 256, sizeof res);
+    if (q.h_res[16 + 3]) {          // the edge set was still growing after four passes: finish it and redo the line search
+        r->slow_frames++;
+        R_TRY(r, hyst_finish(q.wk, q.st));
+        R_TRY(r, run_hough(q.wk, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));
+        R_HIP(r, hipMemcpyAsync(&res, q.wk.res, sizeof res, hipMemcpyDeviceToHost, q.st));
+        R_HIP(r, hipStreamSynchronize(q.st));
+    }
+    roll_update(r, res);
+    // cv::getRotationMatrix2D(center, angle, 1.0) (:141-144); the interleaved chroma plane is the half-size picture: the same
+    // rotation with the translation halved
+    const float cx = q.w / 2.0f, cy = q.h / 2.0f;
+    const double a = r->smoothed * 3.1415926535897932384626433832795 / 180;
+    const double alpha = std::cos(a), beta = std::sin(a);
+    const double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
+    const double Mc[6] = {M[0], M[1], M[2] * 0.5, M[3], M[4], M[5] * 0.5};
+    // the rotations run on `st`, behind the frame's analysis (which read the same surface)
+    int rc = vs_op_warp_affine_ex(q.src, q.pitch, q.w, q.h, q.dst, q.opitch, q.w, q.h, 1, M, VS_BORDER_REPLICATE, r->st);          // :146-149
+    if (rc == VS_OK)
+        rc = vs_op_warp_affine_ex(q.src + q.uv, q.pitch, q.w / 2, q.h / 2, q.dst + q.ouv, q.opitch, q.w / 2, q.h / 2, 2, Mc, VS_BORDER_REPLICATE, r->st);
+    r->nv_done++;
+    if (rc != VS_OK) { r->err = get_last_error(); return rc; }
+    return VS_OK;
+}
+
+// autoCorrectRoll for an NV12 surface in HBM (luma plane at d_surface, interleaved chroma plane uv_offset bytes behind it; the
+// same for the result), ASYNCHRONOUS: the line search runs on the luma plane (resize x scale_factor -> Canny -> HoughLines; a
+// gray picture needs no cvtColor), the rotation is applied to both planes.  The call returns at once; the result of call k is
+// queued by call k + 4 (or vs_roll_sync) and complete after vs_roll_sync.  The surface and the result buffer of a call must
+// stay untouched until then.
+int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset, void* d_out, size_t out_pitch,
+                             size_t out_uv_offset) {
+    if (!r || !d_surface || !d_out || w < 2 || h < 2 || (w & 1) || (h & 1) || pitch < (size_t)w || out_pitch < (size_t)w) return VS_ERR_INVALID_ARG;
+    if (uv_offset == 0) uv_offset = (size_t)h * pitch;
+    if (out_uv_offset == 0) out_uv_offset = (size_t)h * out_pitch;
+    R_HIP(r, hipSetDevice(r->device));
+    const vs_roll_params_c& p = r->p;
+    if (r->first) { r->first = false; r->smoothed = 0.0; }                                       // :24-27
+    if (r->nv_in - r->nv_done >= vs_roll::RS) R_TRY(r, roll_close_oldest(r));
+    vs_roll::Slot& q = r->slot[r->nv_in % vs_roll::RS];
+    if (!q.st) {
+        R_HIP(r, hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
+        R_HIP(r, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+        R_HIP(r, hipHostMalloc((void**)&q.h_res, 320, hipHostMallocDefault));
+    }
+    int sw = (int)(w * p.scale_factor), sh = (int)(h * p.scale_factor);                         // :35-38
+    if (!(sw > 0 && sh > 0)) { sw = w; sh = h; }                                                 // :40-45
+    R_TRY(r, roll_work_alloc(q.wk, sw, sh, p.hough_rho, p.hough_theta, q.st));
+    RollWork& k = q.wk;
+    q.src = (const uint8_t*)d_surface; q.dst = (uint8_t*)d_out; q.w = w; q.h = h;
+    q.pitch = pitch; q.uv = uv_offset; q.opitch = out_pitch; q.ouv = out_uv_offset;
+    R_TRY(r, launch_resize_gray(q.src, pitch, w, h, VS_FMT_GRAY8, k.gray, sw, sw, sh, q.st));                                   // :41
+    R_TRY(r, run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true));   // :54-61
+    R_TRY(r, run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));                       // :66-73, :106-119
+    // counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics: one copy
+    R_HIP(r, hipMemcpyAsync(q.h_res, k.counters, 256 + sizeof(RollResult), hipMemcpyDeviceToHost, q.st));
+    R_HIP(r, hipEventRecord(q.ev, q.st));
+    r->nv_in++;
+    return VS_OK;
+}
+
 int vs_roll_sync(vs_roll* r) {
     if (!r) return VS_ERR_INVALID_ARG;
     R_HIP(r, hipSetDevice(r->device));
+    while (r->nv_done < r->nv_in) R_TRY(r, roll_close_oldest(r));      // (asynchronous NV12 calls still open)
     R_HIP(r, hipStreamSynchronize(r->st));
     return VS_OK;
 }

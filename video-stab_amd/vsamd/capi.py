@@ -255,6 +255,9 @@ class VsLib:
         L.vs_roll_last_error.restype = C.c_char_p
         L.vs_roll_correct.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
         L.vs_roll_correct_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
+        L.vs_roll_correct_nv12_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t]
+        L.vs_azc_apply_nv12_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_int64)]
+        L.vs_azc_result.argtypes = [vp, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), i32p]
         L.vs_roll_sync.argtypes = [vp]
         L.vs_roll_get_state.argtypes = [vp, f64p, f64p, i32p, i32p]
         L.vs_op_canny.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.c_size_t, vp]
@@ -579,6 +582,18 @@ class AutoZoomCrop:
         shape = (oh.value, ow.value) if cn == 1 else (oh.value, ow.value, 3)
         return buf[:oh.value * ow.value * cn].reshape(shape).copy()
 
+    def apply_nv12_dev(self, d_in, w, h, pitch, d_out, out_pitch, out_uv_offset, uv_offset=0):
+        """Asynchronous (vs_azc_apply_nv12_dev): returns the ticket; result(ticket) tells what came out, sync() completes the pixels."""
+        t = C.c_int64(-1)
+        self._check(self.lib.vs_azc_apply_nv12_dev(self.h, d_in, w, h, pitch, uv_offset, d_out, out_pitch, out_uv_offset, C.byref(t)))
+        return t.value
+
+    def result(self, ticket):
+        ow, oh = C.c_int(), C.c_int()
+        info = np.zeros(8, np.int32)
+        self._check(self.lib.vs_azc_result(self.h, ticket, C.byref(ow), C.byref(oh), _p(info, i32p)))
+        return ow.value, oh.value, info
+
     def apply_dev(self, d_in, w, h, stride, cn, d_out, out_stride):
         ow, oh = C.c_int(), C.c_int()
         self._check(self.lib.vs_azc_apply_dev(self.h, d_in, w, h, stride, cn, d_out, out_stride,
@@ -795,6 +810,10 @@ class RollCorrection:
 
     def correct_dev(self, d_in, w, h, stride, d_out, out_stride):
         self._check(self.lib.vs_roll_correct_dev(self.h, d_in, w, h, stride, d_out, out_stride))
+
+    def correct_nv12_dev(self, d_in, w, h, pitch, d_out, out_pitch, uv_offset=0, out_uv_offset=0):
+        """Asynchronous (vs_roll_correct_nv12_dev): the result is complete after sync()."""
+        self._check(self.lib.vs_roll_correct_nv12_dev(self.h, d_in, w, h, pitch, uv_offset, d_out, out_pitch, out_uv_offset))
 
     def sync(self):
         self._check(self.lib.vs_roll_sync(self.h))
