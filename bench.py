@@ -427,7 +427,7 @@ def config2(vs, comm, device, args, full=True):
     regions = int(os.environ.get("VS_BENCH_4K_REGIONS", str(args.regions)))
     fb = W * H * 3 // 2
     elapsed, roof, _, _ = run_stream_workload(comm, ss, steps, 4, regions, int(os.environ.get("VS_BENCH_4K_WARM", "40")),
-                                              False, 2.0 * fb, "warp_plane_kernel<1> + <2> (Y and interleaved UV plane)")
+                                              False, 2.0 * fb, "warp_nv12_kernel (luma and interleaved chroma tiles of 32 surfaces in one launch)")
     med = statistics.median(elapsed)
     tables_pass(ss, roof, steps)
     traffic_from_counters(vs, roof, "configs2")
@@ -437,35 +437,66 @@ def config2(vs, comm, device, args, full=True):
     ss.close()
     if not full:
         return out
-    # (b) the reference's order of operators on a 4K BGR frame: roll correction -> stabilize -> auto zoom/crop (each
-    # call finished before the next: the reference's loop is synchronous, examples/roll-correction-file.cpp:58-70)
-    NB = 8
-    bclip = synth.make_clip_dev(vs, synth.SEED_CONFIG3, W, H, NB)
-    fb = W * H * 3
-    d_r, d_s, d_z = capi.DevBuf(vs, fb), capi.DevBuf(vs, fb), capi.DevBuf(vs, fb)   # (the zoom stage returns the frame as it is when it finds no crop)
+    # (b) configs[2] as ONE chain on the decoder surfaces: roll correction -> stabilize -> auto zoom/crop (the reference's order
+    # of operators, examples/vs.cpp:553-562), each stage through its asynchronous device entry point, chunks of 64 surfaces:
+    # while the roll stage works on chunk c, the stabilizer takes chunk c-1 and the zoom stage the stabilized surfaces of chunk
+    # c-2; one host wait per stage and chunk.
+    out["chain_nv12"] = config2_chain(vs, device, p, W, H)
+    return out
+
+
+def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
+    CH = 64
+    NF = int(os.environ.get("VS_BENCH_4K_CLIP", "64"))
+    clip = synth.make_clip_dev(vs, synth.SEED_CONFIG3, W, H, NF, nv12=True)
+    sb = W * H * 3 // 2
+    R_RING, S_RING, Z_RING = 4, 3, 2        # chunks a roll result / a stabilized surface / a zoom result stays untouched
+    d_roll = [capi.DevBuf(vs, sb * CH) for _ in range(R_RING)]
+    d_stab = [capi.DevBuf(vs, sb * CH) for _ in range(S_RING)]
+    d_zoom = [capi.DevBuf(vs, sb * CH) for _ in range(Z_RING)]      # (room for the fall-back: the unchanged 4K surface)
     rc, az = vs.roll_correction(), vs.auto_zoom_crop()
     st = vs.stabilizer(p, device=device)
+    st.set_batch(CH)
+    st.set_zero_copy(True)
+    produced = {}                      # chunk -> stabilized surfaces it yielded
+    n_in = 0
+    tickets = []
 
-    def one(i):
-        rc.correct_dev(bclip.ptr + (i % NB) * fb, W, H, W * 3, d_r.ptr, W * 3)
+    def step(c):
+        nonlocal n_in
+        for i in range(CH):                                                    # roll: chunk c
+            rc.correct_nv12_dev(clip.ptr + ((c * CH + i) % NF) * sb, W, H, W, d_roll[c % R_RING].ptr + i * sb, W)
+        if c >= 1:                                                             # stabilize: chunk c-1 (its rotations are complete)
+            k = 0
+            for i in range(CH):
+                k += st.push_dev(d_roll[(c - 1) % R_RING].ptr + i * sb, W, H, W, capi.FMT_NV12, d_stab[(c - 1) % S_RING].ptr + k * sb, W)
+            produced[c - 1] = k
+        if c >= 2:                                                             # zoom/crop: what chunk c-2 yielded (complete)
+            for j in range(produced[c - 2]):
+                tickets.append(az.apply_nv12_dev(d_stab[(c - 2) % S_RING].ptr + j * sb, W, H, W, d_zoom[c % Z_RING].ptr + j * sb, W, W * H))
         rc.sync()
-        k = st.push_dev(d_r.ptr, W, H, W * 3, capi.FMT_BGR8, d_s.ptr, W * 3)
         st.sync()
-        if k:
-            az.apply_dev(d_s.ptr, W, H, W * 3, 3, d_z.ptr, W * 3)
-            az.sync()
-        return k
-    for i in range(40):
-        one(i)
+        az.sync()
+    for c in range(chunks_warm):
+        step(c)
+    n0 = len(tickets)
     t0 = time.perf_counter()
-    n = sum(one(i) for i in range(40, 140))
+    for c in range(chunks_warm, chunks_warm + chunks_timed):
+        step(c)
     dt = time.perf_counter() - t0
-    out["roll_stabilize_zoomcrop_bgr"] = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n, 1) * 1e3, 3),
-                                          "what": "autoCorrectRoll -> stabilize -> autoZoomCrop per 4K BGR frame, one frame at a time"}
+    n = len(tickets) - n0
+    ow, oh, info = az.result(tickets[-1])
+    res = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n, 1) * 1e3, 4), "frames": n,
+           "last_result": [ow, oh], "last_crop": [int(v) for v in info[2:6]],
+           "what": "vs_roll_correct_nv12_dev -> vs_stab_push_dev (batch 64, zero-copy) -> vs_azc_apply_nv12_dev on 3840x2160 NV12 surfaces "
+                   "resident in HBM, chunks of 64, the three stages overlapped on the device, one host wait per stage and chunk; every "
+                   "surface goes through all three stages (640x360 NV12 out)"}
     st.close()
-    for b in (bclip, d_r, d_s, d_z):
+    rc.close()
+    az.close()
+    for b in [clip] + d_roll + d_stab + d_zoom:
         b.free()
-    return out
+    return res
 
 
 def main():
@@ -516,7 +547,7 @@ def main():
     vs.check(vs.lib.vs_dev_set_device(local_rank))
 
     if args.workload == "configs2":
-        out = config2(vs, comm, local_rank, args, full=False)
+        out = config2(vs, comm, local_rank, args, full=os.environ.get("VS_BENCH_CHAIN") == "1")   # (VS_BENCH_CHAIN=1: and the chain)
         if rank == 0:
             print(json.dumps(out), flush=True)
         comm.close()
