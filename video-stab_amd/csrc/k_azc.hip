@@ -172,8 +172,8 @@ struct vs_azc {
     // ---- asynchronous NV12 path (vs_azc_apply_nv12_dev) ----
     // The mask kernels of a frame are queued by the call; the contour logic - host work in the reference as well
     // (AutoZoomCrop.cpp:141-147 downloads the mask for cv::findContours) - runs on worker threads, NW frames at a time (frames do
-    // not depend on each other), and the worker then queues the crop-and-scale of both planes.  NS frames in flight.
-    static constexpr int NS = 8, NW = 4, NRES = 1024;
+    // not depend on each other; 0.3 ms per 4K frame and thread: four threads were the limit of the stage at 12.8 k frames/s), and the worker then queues the crop-and-scale of both planes.  NS frames in flight.
+    static constexpr int NS = 16, NW = 8, NRES = 1024;
     struct Slot {
         uint8_t* d_mask = nullptr;
         uint8_t* h_mask = nullptr;
@@ -439,7 +439,7 @@ static void azc_worker(vs_azc* a) {
 // the 320 x 180 interleaved chroma plane out_uv_offset bytes behind) or, on the reference's fall-back paths, the unchanged
 // w x h surface - so out_pitch >= max(w, 640) and out_uv_offset >= max(h, 360) * out_pitch.  The call returns at once with a
 // ticket; vs_azc_result(ticket) tells what came out (it waits for that frame's host part), the pixels are complete after
-// vs_azc_sync.  Surface and result buffer must stay untouched until then; at most 8 frames are in flight (the call waits
+// vs_azc_sync.  Surface and result buffer must stay untouched until then; at most 16 frames are in flight (the call waits
 // for the oldest), results of the last 1024 tickets are kept.
 int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset, void* d_out, size_t out_pitch,
                           size_t out_uv_offset, int64_t* ticket) {

@@ -289,11 +289,12 @@ __device__ __forceinline__ void select_corners(const SelArgs& a) {
 
     // The greedy pass below walks the candidates from the strongest on and stops at max_corners accepted ones: how deep it gets
     // depends on the picture, and sorting ALL candidates first made the launch twice as long on pictures with twice the local
-    // maxima (58 -> 198 us per batch, round 3).  The list is therefore consumed in chunks of growing size - the strongest 1024
-    // (or a few more) first, then 4096 at a time - each chunk = every key in [lo, upper), chosen by a radix search on the key
+    // maxima (58 -> 198 us per batch, round 3).  The list is therefore consumed in chunks of growing size - the strongest 448
+    // (or a few more) first, then 1792, then 4096 at a time - each chunk = every key in [lo, upper), chosen by a radix search on the key
     // bytes (one pass over the candidates per byte, usually three), sorted, and walked; the walk ends where the serial loop
     // would (list and order are unchanged: a chunk boundary is a position in the sorted order, nothing else).
-    int want = 768;              // (a chunk of up to 1024 keys is sorted with four keys per thread)
+    int want = 448;              // (a chunk of up to 512 keys is sorted with two keys per thread; 200 corners at minDistance 15
+                                 //  are typically reached 320 - 350 candidates deep on the bench clips)
     while (true) {
         // ---- choose the next chunk: at least `want` (at most SORT_CAP) of the largest keys below s_upper
         const unsigned long long upper = s_upper;
@@ -478,7 +479,7 @@ __device__ __forceinline__ void select_corners(const SelArgs& a) {
         }
         __syncthreads();
         if (s_done) break;
-        want = SORT_CAP / 2;
+        want = want < 1792 ? 1792 : SORT_CAP / 2;
     }
     __syncthreads();
     if (tid == 0) {

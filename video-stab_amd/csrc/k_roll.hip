@@ -576,11 +576,22 @@ struct vs_roll {
         hipStream_t st = nullptr;
         hipEvent_t ev = nullptr;
         int32_t* h_res = nullptr;        // page-locked: counters[16], hysteresis flags[16], pad, RollResult at byte 256
+        // the frame's line search as ONE graph launch: its thirteen launches and two copies cost the host ~100 us per frame when
+        // queued one by one (the runtime's launch path, not the device), which made the stage host-bound at 9 k frames/s.  The
+        // graph is captured once per slot and geometry; the one thing that changes from frame to frame - where the surface lies
+        // - travels through a 16-byte (source, destination) pair the graph's first node copies to the device.
+        hipGraphExec_t gexec = nullptr;
+        ImgPair* h_pair = nullptr;       // page-locked
+        ImgPair* d_pair = nullptr;
+        int g_w = 0, g_h = 0;
+        size_t g_pitch = 0;
+        long g_gen = -1;                 // parameter generation the graph was captured with
         const uint8_t* src = nullptr;
         uint8_t* dst = nullptr;
         int w = 0, h = 0;
         size_t pitch = 0, uv = 0, opitch = 0, ouv = 0;
     } slot[RS];
+    long param_gen = 0;                   // advanced by vs_roll_set_params: the thresholds are baked into the slots' graphs
     long nv_in = 0, nv_done = 0;          // frames queued / closed
     long slow_frames = 0;                 // frames whose edge set was still growing after the first group of passes
 };
@@ -679,6 +690,9 @@ void vs_roll_destroy(vs_roll* r) {
         if (q.st) { (void)hipStreamSynchronize(q.st); (void)hipStreamDestroy(q.st); }
         if (q.ev) (void)hipEventDestroy(q.ev);
         if (q.h_res) (void)hipHostFree(q.h_res);
+        if (q.gexec) (void)hipGraphExecDestroy(q.gexec);
+        if (q.h_pair) (void)hipHostFree(q.h_pair);
+        if (q.d_pair) (void)hipFree(q.d_pair);
         roll_work_free(q.wk);
     }
     if (r->st) (void)hipStreamSynchronize(r->st);
@@ -696,6 +710,7 @@ int vs_roll_set_params(vs_roll* r, const vs_roll_params_c* params) {
     if (!r || !params || params->struct_size != (int32_t)sizeof(vs_roll_params_c)) return VS_ERR_INVALID_ARG;
     if (params->canny_aperture != 3) { r->err = "roll: only cannyAperture 3 is supported"; set_last_error(r->err); return VS_ERR_UNSUPPORTED; }
     r->p = *params;
+    r->param_gen++;
     return VS_OK;
 }
 
@@ -826,11 +841,35 @@ int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, si
     RollWork& k = q.wk;
     q.src = (const uint8_t*)d_surface; q.dst = (uint8_t*)d_out; q.w = w; q.h = h;
     q.pitch = pitch; q.uv = uv_offset; q.opitch = out_pitch; q.ouv = out_uv_offset;
-    R_TRY(r, launch_resize_gray(q.src, pitch, w, h, VS_FMT_GRAY8, k.gray, sw, sw, sh, q.st));                                   // :41
-    R_TRY(r, run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true));   // :54-61
-    R_TRY(r, run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));                       // :66-73, :106-119
-    // counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics: one copy
-    R_HIP(r, hipMemcpyAsync(q.h_res, k.counters, 256 + sizeof(RollResult), hipMemcpyDeviceToHost, q.st));
+    if (!q.h_pair) {
+        R_HIP(r, hipHostMalloc((void**)&q.h_pair, sizeof(ImgPair), hipHostMallocDefault));
+        R_HIP(r, hipMalloc((void**)&q.d_pair, sizeof(ImgPair)));
+    }
+    if (!q.gexec || q.g_w != w || q.g_h != h || q.g_pitch != pitch || q.g_gen != r->param_gen) {
+        if (q.gexec) { (void)hipGraphExecDestroy(q.gexec); q.gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        R_HIP(r, hipStreamSynchronize(q.st));
+        R_HIP(r, hipStreamBeginCapture(q.st, hipStreamCaptureModeThreadLocal));
+        int rc = VS_OK;
+        hipError_t e = hipMemcpyAsync(q.d_pair, q.h_pair, sizeof(ImgPair), hipMemcpyHostToDevice, q.st);
+        if (e == hipSuccess) {
+            rc = launch_resize_gray_batch(q.d_pair, 1, pitch, w, h, VS_FMT_GRAY8, sw, sw, sh, 0, q.st);                                      // :41
+            if (rc == VS_OK) rc = run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true);   // :54-61
+            if (rc == VS_OK) rc = run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st);                  // :66-73, :106-119
+            // counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics: one copy
+            if (rc == VS_OK) e = hipMemcpyAsync(q.h_res, k.counters, 256 + sizeof(RollResult), hipMemcpyDeviceToHost, q.st);
+        }
+        const hipError_t e2 = hipStreamEndCapture(q.st, &graph);
+        if (rc != VS_OK) { if (graph) (void)hipGraphDestroy(graph); r->err = get_last_error(); return rc; }
+        R_HIP(r, e);
+        R_HIP(r, e2);
+        const hipError_t e3 = hipGraphInstantiate(&q.gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        R_HIP(r, e3);
+        q.g_w = w; q.g_h = h; q.g_pitch = pitch; q.g_gen = r->param_gen;
+    }
+    q.h_pair->src = q.src; q.h_pair->dst = k.gray;
+    R_HIP(r, hipGraphLaunch(q.gexec, q.st));
     R_HIP(r, hipEventRecord(q.ev, q.st));
     r->nv_in++;
     return VS_OK;
