@@ -26,6 +26,10 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "vs_common.h"
@@ -566,33 +570,28 @@ struct vs_roll {
     double last_detected = 0.0;
     int last_lines = 0, last_used = 0;
     // asynchronous NV12 path (vs_roll_correct_nv12_dev): the line search of a frame does not depend on the frames before it -
-    // only the smoothed angle does, a three-flop recurrence on the host.  RS frames are in flight, each on a worker stream with
-    // a work area of its own; call k first closes frame k - RS (its 24-byte result has long arrived: EMA, clamp, decay, rotation
-    // matrix, the rotation of both planes queued on `st`), then queues the analysis of frame k.  No wait for the device in the
-    // steady state unless the caller is RS frames ahead of it.
-    static constexpr int RS = 4;
+    // only the smoothed angle does, a three-flop recurrence on the host.  A frame's search is fifteen small launches, and queued
+    // from the caller's thread they cost ~100 us of the runtime's launch path per frame (9 k frames/s, whether one by one or as a
+    // captured graph - the runtime replays a graph node by node).  RS worker threads, each with a stream and a work area of its
+    // own, take the frames in turn: a worker queues its frame's search, waits for the 24-byte result, and then - in frame order -
+    // advances the angle (EMA, clamp, decay) and queues the rotation of both planes on `st`.  The caller's thread only hands
+    // over the job.
+    static constexpr int RS = 4, QMAX = 32;
+    struct Job { const uint8_t* src; uint8_t* dst; int w, h; size_t pitch, uv, opitch, ouv; long seq; };
     struct Slot {
         RollWork wk;
         hipStream_t st = nullptr;
         hipEvent_t ev = nullptr;
         int32_t* h_res = nullptr;        // page-locked: counters[16], hysteresis flags[16], pad, RollResult at byte 256
-        // the frame's line search as ONE graph launch: its thirteen launches and two copies cost the host ~100 us per frame when
-        // queued one by one (the runtime's launch path, not the device), which made the stage host-bound at 9 k frames/s.  The
-        // graph is captured once per slot and geometry; the one thing that changes from frame to frame - where the surface lies
-        // - travels through a 16-byte (source, destination) pair the graph's first node copies to the device.
-        hipGraphExec_t gexec = nullptr;
-        ImgPair* h_pair = nullptr;       // page-locked
-        ImgPair* d_pair = nullptr;
-        int g_w = 0, g_h = 0;
-        size_t g_pitch = 0;
-        long g_gen = -1;                 // parameter generation the graph was captured with
-        const uint8_t* src = nullptr;
-        uint8_t* dst = nullptr;
-        int w = 0, h = 0;
-        size_t pitch = 0, uv = 0, opitch = 0, ouv = 0;
+        std::deque<Job> jobs;
     } slot[RS];
-    long param_gen = 0;                   // advanced by vs_roll_set_params: the thresholds are baked into the slots' graphs
-    long nv_in = 0, nv_done = 0;          // frames queued / closed
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    bool quit = false;
+    int worker_rc = VS_OK;
+    std::string worker_err;
+    long nv_in = 0, nv_done = 0;          // frames handed over / closed (angle advanced, rotation queued)
     long slow_frames = 0;                 // frames whose edge set was still growing after the first group of passes
 };
 
@@ -686,13 +685,15 @@ int vs_roll_create(const vs_roll_params_c* params, int device, vs_roll** out) {
 void vs_roll_destroy(vs_roll* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
+    if (!r->workers.empty()) {
+        { std::lock_guard<std::mutex> g(r->mu); r->quit = true; }
+        r->cv_job.notify_all();
+        for (auto& t : r->workers) t.join();
+    }
     for (auto& q : r->slot) {
         if (q.st) { (void)hipStreamSynchronize(q.st); (void)hipStreamDestroy(q.st); }
         if (q.ev) (void)hipEventDestroy(q.ev);
         if (q.h_res) (void)hipHostFree(q.h_res);
-        if (q.gexec) (void)hipGraphExecDestroy(q.gexec);
-        if (q.h_pair) (void)hipHostFree(q.h_pair);
-        if (q.d_pair) (void)hipFree(q.d_pair);
         roll_work_free(q.wk);
     }
     if (r->st) (void)hipStreamSynchronize(r->st);
@@ -709,8 +710,8 @@ const char* vs_roll_last_error(const vs_roll* r) { return r ? r->err.c_str() : "
 int vs_roll_set_params(vs_roll* r, const vs_roll_params_c* params) {
     if (!r || !params || params->struct_size != (int32_t)sizeof(vs_roll_params_c)) return VS_ERR_INVALID_ARG;
     if (params->canny_aperture != 3) { r->err = "roll: only cannyAperture 3 is supported"; set_last_error(r->err); return VS_ERR_UNSUPPORTED; }
+    if (r->nv_in != r->nv_done) { const int rc = vs_roll_sync(r); if (rc != VS_OK) return rc; }      // (frames in flight keep the parameters they were given)
     r->p = *params;
-    r->param_gen++;
     return VS_OK;
 }
 
@@ -754,6 +755,7 @@ static void roll_update(vs_roll* r, const RollResult& res) {
 int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t stride, void* d_out, size_t out_stride) {
     if (!r || !d_data || !d_out || w <= 0 || h <= 0 || stride < (size_t)w * 3 || out_stride < (size_t)w * 3) return VS_ERR_INVALID_ARG;
     R_HIP(r, hipSetDevice(r->device));
+    if (r->nv_in != r->nv_done) R_TRY(r, vs_roll_sync(r));         // (asynchronous NV12 frames first: one angle, one order)
     const vs_roll_params_c& p = r->p;
     if (r->first) { r->first = false; r->smoothed = 0.0; }                                       // :24-27
     int sw = (int)(w * p.scale_factor), sh = (int)(h * p.scale_factor);                         // :35-38
@@ -784,101 +786,122 @@ int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t str
     return vs_op_warp_affine_ex(d_data, stride, w, h, d_out, out_stride, w, h, 3, M, VS_BORDER_REPLICATE, r->st);   // :146-149
 }
 
-// Closes the oldest frame in flight: its result is on the host (or arrives now), the angle advances, the rotation is queued.
-static int roll_close_oldest(vs_roll* r) {
-    vs_roll::Slot& q = r->slot[r->nv_done % vs_roll::RS];
+// One worker of the asynchronous NV12 path: the frames seq = wi, wi + RS, ... in turn.
+static int roll_worker_frame(vs_roll* r, vs_roll::Slot& q, const vs_roll::Job& j) {
     const vs_roll_params_c& p = r->p;
-    R_HIP(r, hipEventSynchronize(q.ev));
+    if (!q.st) {
+        R_HIP(r, hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
+        R_HIP(r, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+        R_HIP(r, hipHostMalloc((void**)&q.h_res, 320, hipHostMallocDefault));
+    }
+    int sw = (int)(j.w * p.scale_factor), sh = (int)(j.h * p.scale_factor);                     // :35-38
+    if (!(sw > 0 && sh > 0)) { sw = j.w; sh = j.h; }                                             // :40-45
+    VS_TRY(roll_work_alloc(q.wk, sw, sh, p.hough_rho, p.hough_theta, q.st));
+    RollWork& k = q.wk;
+    VS_TRY(launch_resize_gray(j.src, j.pitch, j.w, j.h, VS_FMT_GRAY8, k.gray, sw, sw, sh, q.st));                               // :41
+    VS_TRY(run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true));     // :54-61
+    VS_TRY(run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));                         // :66-73, :106-119
+    // counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics: one copy
+    VS_HIP_TRY(hipMemcpyAsync(q.h_res, k.counters, 256 + sizeof(RollResult), hipMemcpyDeviceToHost, q.st));
+    VS_HIP_TRY(hipEventRecord(q.ev, q.st));
+    VS_HIP_TRY(hipEventSynchronize(q.ev));
     RollResult res;
     memcpy(&res, reinterpret_cast<const uint8_t*>(q.h_res) + 256, sizeof res);
+    bool slow = false;
     if (q.h_res[16 + 3]) {          // the edge set was still growing after four passes: finish it and redo the line search
-        r->slow_frames++;
-        R_TRY(r, hyst_finish(q.wk, q.st));
-        R_TRY(r, run_hough(q.wk, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));
-        R_HIP(r, hipMemcpyAsync(&res, q.wk.res, sizeof res, hipMemcpyDeviceToHost, q.st));
-        R_HIP(r, hipStreamSynchronize(q.st));
+        slow = true;
+        VS_TRY(hyst_finish(k, q.st));
+        VS_TRY(run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));
+        VS_HIP_TRY(hipMemcpyAsync(&res, k.res, sizeof res, hipMemcpyDeviceToHost, q.st));
+        VS_HIP_TRY(hipStreamSynchronize(q.st));
     }
+    // ---- in frame order: the angle recurrence and the rotation
+    std::unique_lock<std::mutex> lk(r->mu);
+    r->cv_done.wait(lk, [&] { return r->nv_done == j.seq; });
+    if (slow) r->slow_frames++;
     roll_update(r, res);
     // cv::getRotationMatrix2D(center, angle, 1.0) (:141-144); the interleaved chroma plane is the half-size picture: the same
     // rotation with the translation halved
-    const float cx = q.w / 2.0f, cy = q.h / 2.0f;
+    const float cx = j.w / 2.0f, cy = j.h / 2.0f;
     const double a = r->smoothed * 3.1415926535897932384626433832795 / 180;
     const double alpha = std::cos(a), beta = std::sin(a);
     const double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
     const double Mc[6] = {M[0], M[1], M[2] * 0.5, M[3], M[4], M[5] * 0.5};
-    // the rotations run on `st`, behind the frame's analysis (which read the same surface)
-    int rc = vs_op_warp_affine_ex(q.src, q.pitch, q.w, q.h, q.dst, q.opitch, q.w, q.h, 1, M, VS_BORDER_REPLICATE, r->st);          // :146-149
+    int rc = vs_op_warp_affine_ex(j.src, j.pitch, j.w, j.h, j.dst, j.opitch, j.w, j.h, 1, M, VS_BORDER_REPLICATE, r->st);          // :146-149
     if (rc == VS_OK)
-        rc = vs_op_warp_affine_ex(q.src + q.uv, q.pitch, q.w / 2, q.h / 2, q.dst + q.ouv, q.opitch, q.w / 2, q.h / 2, 2, Mc, VS_BORDER_REPLICATE, r->st);
-    r->nv_done++;
-    if (rc != VS_OK) { r->err = get_last_error(); return rc; }
-    return VS_OK;
+        rc = vs_op_warp_affine_ex(j.src + j.uv, j.pitch, j.w / 2, j.h / 2, j.dst + j.ouv, j.opitch, j.w / 2, j.h / 2, 2, Mc, VS_BORDER_REPLICATE, r->st);
+    return rc;          // (the caller advances nv_done under the same lock)
+}
+
+static void roll_worker(vs_roll* r, int wi) {
+    (void)hipSetDevice(r->device);
+    vs_roll::Slot& q = r->slot[wi];
+    for (;;) {
+        vs_roll::Job j;
+        {
+            std::unique_lock<std::mutex> lk(r->mu);
+            r->cv_job.wait(lk, [&] { return r->quit || !q.jobs.empty(); });
+            if (q.jobs.empty()) return;
+            j = q.jobs.front();
+            q.jobs.pop_front();
+        }
+        int rc = roll_worker_frame(r, q, j);
+        {
+            std::unique_lock<std::mutex> lk(r->mu, std::defer_lock);
+            if (!lk.owns_lock()) lk.lock();
+            // (a frame that failed before its ordered part still has to let the next one pass)
+            r->cv_done.wait(lk, [&] { return r->nv_done == j.seq; });
+            if (rc != VS_OK && r->worker_rc == VS_OK) { r->worker_rc = rc; r->worker_err = get_last_error(); }
+            r->nv_done++;
+        }
+        r->cv_done.notify_all();
+    }
 }
 
 // autoCorrectRoll for an NV12 surface in HBM (luma plane at d_surface, interleaved chroma plane uv_offset bytes behind it; the
 // same for the result), ASYNCHRONOUS: the line search runs on the luma plane (resize x scale_factor -> Canny -> HoughLines; a
-// gray picture needs no cvtColor), the rotation is applied to both planes.  The call returns at once; the result of call k is
-// queued by call k + 4 (or vs_roll_sync) and complete after vs_roll_sync.  The surface and the result buffer of a call must
-// stay untouched until then.
+// gray picture needs no cvtColor), the rotation is applied to both planes.  The call hands the frame to the object's worker
+// threads and returns; results are complete after vs_roll_sync.  The surface and the result buffer of a call must stay
+// untouched until then.
 int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset, void* d_out, size_t out_pitch,
                              size_t out_uv_offset) {
     if (!r || !d_surface || !d_out || w < 2 || h < 2 || (w & 1) || (h & 1) || pitch < (size_t)w || out_pitch < (size_t)w) return VS_ERR_INVALID_ARG;
     if (uv_offset == 0) uv_offset = (size_t)h * pitch;
     if (out_uv_offset == 0) out_uv_offset = (size_t)h * out_pitch;
     R_HIP(r, hipSetDevice(r->device));
-    const vs_roll_params_c& p = r->p;
-    if (r->first) { r->first = false; r->smoothed = 0.0; }                                       // :24-27
-    if (r->nv_in - r->nv_done >= vs_roll::RS) R_TRY(r, roll_close_oldest(r));
-    vs_roll::Slot& q = r->slot[r->nv_in % vs_roll::RS];
-    if (!q.st) {
-        R_HIP(r, hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
-        R_HIP(r, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
-        R_HIP(r, hipHostMalloc((void**)&q.h_res, 320, hipHostMallocDefault));
-    }
-    int sw = (int)(w * p.scale_factor), sh = (int)(h * p.scale_factor);                         // :35-38
-    if (!(sw > 0 && sh > 0)) { sw = w; sh = h; }                                                 // :40-45
-    R_TRY(r, roll_work_alloc(q.wk, sw, sh, p.hough_rho, p.hough_theta, q.st));
-    RollWork& k = q.wk;
-    q.src = (const uint8_t*)d_surface; q.dst = (uint8_t*)d_out; q.w = w; q.h = h;
-    q.pitch = pitch; q.uv = uv_offset; q.opitch = out_pitch; q.ouv = out_uv_offset;
-    if (!q.h_pair) {
-        R_HIP(r, hipHostMalloc((void**)&q.h_pair, sizeof(ImgPair), hipHostMallocDefault));
-        R_HIP(r, hipMalloc((void**)&q.d_pair, sizeof(ImgPair)));
-    }
-    if (!q.gexec || q.g_w != w || q.g_h != h || q.g_pitch != pitch || q.g_gen != r->param_gen) {
-        if (q.gexec) { (void)hipGraphExecDestroy(q.gexec); q.gexec = nullptr; }
-        hipGraph_t graph = nullptr;
-        R_HIP(r, hipStreamSynchronize(q.st));
-        R_HIP(r, hipStreamBeginCapture(q.st, hipStreamCaptureModeThreadLocal));
-        int rc = VS_OK;
-        hipError_t e = hipMemcpyAsync(q.d_pair, q.h_pair, sizeof(ImgPair), hipMemcpyHostToDevice, q.st);
-        if (e == hipSuccess) {
-            rc = launch_resize_gray_batch(q.d_pair, 1, pitch, w, h, VS_FMT_GRAY8, sw, sw, sh, 0, q.st);                                      // :41
-            if (rc == VS_OK) rc = run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true);   // :54-61
-            if (rc == VS_OK) rc = run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st);                  // :66-73, :106-119
-            // counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics: one copy
-            if (rc == VS_OK) e = hipMemcpyAsync(q.h_res, k.counters, 256 + sizeof(RollResult), hipMemcpyDeviceToHost, q.st);
+    if (r->workers.empty()) {
+        try {
+            for (int i = 0; i < vs_roll::RS; i++) r->workers.emplace_back(roll_worker, r, i);
+        } catch (...) {
+            r->err = "roll: cannot start worker threads"; set_last_error(r->err);
+            return VS_ERR_HIP;
         }
-        const hipError_t e2 = hipStreamEndCapture(q.st, &graph);
-        if (rc != VS_OK) { if (graph) (void)hipGraphDestroy(graph); r->err = get_last_error(); return rc; }
-        R_HIP(r, e);
-        R_HIP(r, e2);
-        const hipError_t e3 = hipGraphInstantiate(&q.gexec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        R_HIP(r, e3);
-        q.g_w = w; q.g_h = h; q.g_pitch = pitch; q.g_gen = r->param_gen;
     }
-    q.h_pair->src = q.src; q.h_pair->dst = k.gray;
-    R_HIP(r, hipGraphLaunch(q.gexec, q.st));
-    R_HIP(r, hipEventRecord(q.ev, q.st));
-    r->nv_in++;
+    {
+        std::unique_lock<std::mutex> lk(r->mu);
+        if (r->first) { r->first = false; r->smoothed = 0.0; }                                   // :24-27
+        r->cv_done.wait(lk, [&] { return r->nv_in - r->nv_done < vs_roll::QMAX; });
+        vs_roll::Job j{(const uint8_t*)d_surface, (uint8_t*)d_out, w, h, pitch, uv_offset, out_pitch, out_uv_offset, r->nv_in};
+        r->slot[r->nv_in % vs_roll::RS].jobs.push_back(j);
+        r->nv_in++;
+    }
+    r->cv_job.notify_all();
     return VS_OK;
 }
 
 int vs_roll_sync(vs_roll* r) {
     if (!r) return VS_ERR_INVALID_ARG;
     R_HIP(r, hipSetDevice(r->device));
-    while (r->nv_done < r->nv_in) R_TRY(r, roll_close_oldest(r));      // (asynchronous NV12 calls still open)
+    if (!r->workers.empty()) {          // asynchronous NV12 frames: until the last one is closed
+        std::unique_lock<std::mutex> lk(r->mu);
+        r->cv_done.wait(lk, [&] { return r->nv_done == r->nv_in; });
+        if (r->worker_rc != VS_OK) {
+            const int rc = r->worker_rc;
+            r->err = r->worker_err; set_last_error(r->err);
+            r->worker_rc = VS_OK;
+            return rc;
+        }
+    }
     R_HIP(r, hipStreamSynchronize(r->st));
     return VS_OK;
 }
