@@ -459,7 +459,7 @@ int vs_roll_sync(vs_roll* r);
  * RollCorrection.cpp:35-119) runs on the luma plane (a gray picture: no cvtColor), the rotation about the picture centre
  * (:141-149, BORDER_REPLICATE) is applied to the luma plane and, with the translation halved, to the half-size interleaved
  * chroma plane.  uv_offset / out_uv_offset: where the chroma plane starts (0 = h * pitch).  The call hands the frame to the
- * object's four worker threads and returns (it waits only when 32 frames are pending): a worker queues the frame's line search
+ * object's eight worker threads and returns (it waits only when 64 frames are pending): a worker queues the frame's line search
  * on its own stream, and when the 24-byte result has arrived the smoothed angle advances - in call order, on the host - and
  * the rotation is queued.  Results are complete after vs_roll_sync; surfaces and result buffers must stay untouched until
  * then.  vs_roll_get_state (after vs_roll_sync) reports the last frame. */

@@ -1,4 +1,4 @@
-"""Turns the rocprofv3 passes of scratch/profile_r03.sh into the files kept under profiles/.
+"""Turns the rocprofv3 passes of scratch/profile_r03.sh (rounds 3 and 4: `profile_r03.sh r04_<x>`) into the files kept under profiles/.
 
 usage: python profiles/summarize_r03.py <tag> <dir with c1_stats, c1_fetch, c1_write, c1_sqa, c1_sqb, c2_...>
 
@@ -92,8 +92,9 @@ for wl, wname in NAMES.items():
             "# FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE to be doubled on gfx950 for 16-byte-per-lane reads); SQ_* summed over the 8 XCDs\n"
             + "\n".join(lines) + "\n")
     # warp traffic: full launches only (those that write the most)
-    warp_k = ["warp_tab_kernel"] if wl == "c1" else ["warp_plane_kernel<1>", "warp_plane_kernel<2>"]
     fpass, wpass = passes["fetch"], passes["write"]
+    # (round 4: luma and chroma tiles of the NV12 surfaces in one launch, warp_nv12_kernel; before: one launch per plane)
+    warp_k = ["warp_tab_kernel"] if wl == "c1" else (["warp_nv12_kernel"] if "warp_nv12_kernel" in fpass else ["warp_plane_kernel<1>", "warp_plane_kernel<2>"])
     if all(k in fpass and k in wpass for k in warp_k):
         rd = wr = 0.0
         nl = 0

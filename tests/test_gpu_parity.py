@@ -156,6 +156,25 @@ def test_warp_full_hd_properties(gpu, oracle):
     assert np.array_equal(gpu.warp_affine(img, M), oracle.warp_affine(img, M, threads=8))
 
 
+def test_warp_table_scratch_grows_between_launches_on_one_stream(gpu, oracle):
+    """The standalone operator keeps ONE grow-only block of coordinate tables per stream (k_warp.hip op_tabs): a 32-frame launch,
+    then a launch with larger frames (the block is replaced behind a stream sync), then the small geometry again - every frame
+    equal to the oracle's, i.e. no launch ever read tables of another geometry or of a freed block.  (Round 2 saw zeroed table
+    records in in-flight builds that took this scratch from the stream-ordered pool; the cause could not be settled from what
+    was kept - DESIGN section 8 - and this is the regression test for the path as it is built now.)"""
+    rng = np.random.default_rng(940)
+
+    def mats(n):
+        a = rng.normal(0, 0.004, n)
+        return np.array([[np.cos(t), -np.sin(t), dx, np.sin(t), np.cos(t), dy] for t, dx, dy in zip(a, rng.normal(0, 4, n), rng.normal(0, 4, n))], np.float32)
+    for (h, w, n) in ((120, 200, 32), (270, 482, 32), (120, 200, 7), (300, 644, 33)):
+        imgs = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        Ms = mats(n)
+        out = gpu.warp_affine(imgs, Ms)
+        for i in range(n):
+            assert np.array_equal(out[i], oracle.warp_affine(imgs[i], Ms[i])), (h, w, i)
+
+
 def test_warp_nv12(gpu, oracle, clip_small):
     nv = synth.bgr_to_nv12(clip_small[0])
     M = [0.99998, -0.006, 2.5, 0.006, 0.99998, -3.0]

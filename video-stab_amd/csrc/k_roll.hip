@@ -576,7 +576,7 @@ struct vs_roll {
     // own, take the frames in turn: a worker queues its frame's search, waits for the 24-byte result, and then - in frame order -
     // advances the angle (EMA, clamp, decay) and queues the rotation of both planes on `st`.  The caller's thread only hands
     // over the job.
-    static constexpr int RS = 4, QMAX = 32;
+    static constexpr int RS = 8, QMAX = 64;
     struct Job { const uint8_t* src; uint8_t* dst; int w, h; size_t pitch, uv, opitch, ouv; long seq; };
     struct Slot {
         RollWork wk;
