@@ -458,11 +458,12 @@ int vs_roll_sync(vs_roll* r);
  * path; defined as the BGR operator's geometry applied per plane: the line search (resize x scale_factor, Canny, HoughLines,
  * RollCorrection.cpp:35-119) runs on the luma plane (a gray picture: no cvtColor), the rotation about the picture centre
  * (:141-149, BORDER_REPLICATE) is applied to the luma plane and, with the translation halved, to the half-size interleaved
- * chroma plane.  uv_offset / out_uv_offset: where the chroma plane starts (0 = h * pitch).  The call hands the frame to the
- * object's eight worker threads and returns (it waits only when 64 frames are pending): a worker queues the frame's line search
- * on its own stream, and when the 24-byte result has arrived the smoothed angle advances - in call order, on the host - and
- * the rotation is queued.  Results are complete after vs_roll_sync; surfaces and result buffers must stay untouched until
- * then.  vs_roll_get_state (after vs_roll_sync) reports the last frame. */
+ * chroma plane.  uv_offset / out_uv_offset: where the chroma plane starts (0 = h * pitch).  The call hands the frame over and
+ * returns (it waits only when 128 frames are pending): eight consecutive frames form a batch whose line searches a worker
+ * thread queues as ONE launch per stage on its own stream; when the batch's results (24 bytes per frame) have arrived the
+ * smoothed angle advances - in call order, on the host - and the rotations are queued.  Results are complete after
+ * vs_roll_sync (which closes an incomplete batch); surfaces and result buffers must stay untouched until then.
+ * vs_roll_get_state (after vs_roll_sync) reports the last frame. */
 int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset,
                              void* d_out, size_t out_pitch, size_t out_uv_offset);
 /* smoothed angle (sSmoothedAngle), the angle detected on the last frame, lines found / used */

@@ -30,6 +30,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "vs_common.h"
@@ -42,10 +43,17 @@ int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh,
 namespace {
 
 constexpr int NT = 256;
+// Several frames per launch (the asynchronous NV12 path analyses eight frames with one launch per stage): blockIdx.z selects the
+// frame, whose buffers lie `fb` bytes behind those of frame 0 (one work area per frame, laid out alike).  fb = 0: one frame.
+template <typename T> __device__ __forceinline__ T* frame_ptr(T* p, size_t fb) {
+    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.z * fb);
+}
+
 constexpr int HOUGH_CAP = 8192;      // peaks kept for the sort (cv::HoughLines has no cap)
 
 __global__ __launch_bounds__(NT) void sobel_kernel(const uint8_t* __restrict__ g, size_t stride, int w, int h,
-                                                   short2* __restrict__ dxy, int* __restrict__ mag, int mw) {
+                                                   short2* __restrict__ dxy, int* __restrict__ mag, int mw, size_t fb) {
+    g = frame_ptr(g, fb); dxy = frame_ptr(dxy, fb); mag = frame_ptr(mag, fb);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w || y >= h) return;
     const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
@@ -66,7 +74,8 @@ typedef unsigned long long u64;
 
 __global__ __launch_bounds__(NT) void canny_nms_kernel(const short2* __restrict__ dxy, const int* __restrict__ mag,
                                                        int w, int h, int mw, int low, int high, u64* __restrict__ E,
-                                                       u64* __restrict__ C, int wpr) {
+                                                       u64* __restrict__ C, int wpr, size_t fb) {
+    dxy = frame_ptr(dxy, fb); mag = frame_ptr(mag, fb); E = frame_ptr(E, fb); C = frame_ptr(C, fb);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     int out = 1;
     if (x < w) {
@@ -147,7 +156,9 @@ __device__ __forceinline__ u64 fill_col(u64 g, u64 c, int lane) {
 // unique, so concurrent bands can only help each other; passes repeat until one changes nothing.
 __global__ __launch_bounds__(64 * HB_WORDS) void canny_hyst_band_kernel(u64* __restrict__ E, const u64* __restrict__ C,
                                                                         int wpr, int h, int* __restrict__ changed,
-                                                                        const int* __restrict__ before) {
+                                                                        const int* __restrict__ before, size_t fb) {
+    E = frame_ptr(E, fb); C = frame_ptr(C, fb); changed = frame_ptr(changed, fb);
+    if (before) before = frame_ptr(before, fb);
     if (before && *before == 0) return;      // the pass before this one changed nothing: neither will this one
     __shared__ uint8_t s_lo[HB_WORDS][64], s_hi[HB_WORDS][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
@@ -240,7 +251,8 @@ __global__ __launch_bounds__(NT) void edge_list_kernel(const uint8_t* __restrict
 // The same list straight from the Canny bit plane E (the roll stage never needs the edge map as bytes): a lane
 // takes one word of 64 pixels.
 __global__ __launch_bounds__(NT) void edge_list_bits_kernel(const u64* __restrict__ E, int wpr, int h,
-                                                            int* __restrict__ list, int* __restrict__ counters) {
+                                                            int* __restrict__ list, int* __restrict__ counters, size_t fb) {
+    E = frame_ptr(E, fb); list = frame_ptr(list, fb); counters = frame_ptr(counters, fb);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     u64 m = idx < wpr * h ? E[idx] : 0ull;
     const int mine = __popcll(m);
@@ -268,8 +280,9 @@ __global__ __launch_bounds__(NT) void edge_list_bits_kernel(const u64* __restric
 __global__ __launch_bounds__(1024) void hough_accum_lds_kernel(const int* __restrict__ list, const int* __restrict__ counters,
                                                                const float* __restrict__ tabSin,
                                                                const float* __restrict__ tabCos, int numrho,
-                                                               int* __restrict__ accum) {
+                                                               int* __restrict__ accum, size_t fb) {
     extern __shared__ int s_row[];
+    list = frame_ptr(list, fb); counters = frame_ptr(counters, fb); accum = frame_ptr(accum, fb);
     const int n = blockIdx.x, n_edges = counters[1];
     for (int r = threadIdx.x; r < numrho; r += blockDim.x) s_row[r] = 0;
     __syncthreads();
@@ -290,7 +303,8 @@ __global__ __launch_bounds__(1024) void hough_accum_lds_kernel(const int* __rest
 __global__ __launch_bounds__(NT) void hough_accum_kernel(const int* __restrict__ list, const int* __restrict__ counters,
                                                          const float* __restrict__ tabSin,
                                                          const float* __restrict__ tabCos, int numangle, int numrho,
-                                                         int* __restrict__ accum) {
+                                                         int* __restrict__ accum, size_t fb) {
+    list = frame_ptr(list, fb); counters = frame_ptr(counters, fb); accum = frame_ptr(accum, fb);
     const int n_edges = counters[1];
     const long long total = (long long)n_edges * numangle;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -305,7 +319,8 @@ __global__ __launch_bounds__(NT) void hough_accum_kernel(const int* __restrict__
 
 __global__ __launch_bounds__(NT) void hough_peaks_kernel(const int* __restrict__ accum, int numangle, int numrho,
                                                          int threshold, unsigned long long* __restrict__ keys,
-                                                         int* __restrict__ counters) {
+                                                         int* __restrict__ counters, size_t fb) {
+    accum = frame_ptr(accum, fb); keys = frame_ptr(keys, fb); counters = frame_ptr(counters, fb);
     const int r = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
     if (r >= numrho || n >= numangle) return;
     const int base = (n + 1) * (numrho + 2) + r + 1;
@@ -331,8 +346,9 @@ __global__ __launch_bounds__(1024) void hough_select_kernel(unsigned long long* 
                                                             const int* __restrict__ counters, int numrho, float rho,
                                                             float theta, double amin, double amax,
                                                             float* __restrict__ lines_out, int max_out,
-                                                            RollResult* __restrict__ res) {
+                                                            RollResult* __restrict__ res, size_t fb) {
     __shared__ unsigned long long sk[HOUGH_CAP];
+    keys = frame_ptr(keys, fb); counters = frame_ptr(counters, fb); lines_out = frame_ptr(lines_out, fb); res = frame_ptr(res, fb);
     const int tid = threadIdx.x;
     int n = counters[2];
     n = n < HOUGH_CAP ? n : HOUGH_CAP;
@@ -417,15 +433,28 @@ struct RollWork {
     int* hflags = nullptr;               // hysteresis pass flags (16 words after the counters)
     RollResult* res = nullptr;
     size_t accum_bytes = 0;
+    int frames = 1;                      // work areas in this allocation, laid out alike, fb bytes apart (the pointers: frame 0)
+    size_t fb = 0;
 };
+
+// Frame f of a work area for several frames, as a work area of its own (it does not own the memory).
+static RollWork frame_view(const RollWork& k, int f) {
+    RollWork v = k;
+    const size_t o = (size_t)f * k.fb;
+    auto adv = [&](auto*& p) { p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<uint8_t*>(p) + o); };
+    adv(v.gray); adv(v.edges); adv(v.dxy); adv(v.mag); adv(v.E); adv(v.C); adv(v.queue); adv(v.list); adv(v.accum);
+    adv(v.tabSin); adv(v.tabCos); adv(v.keys); adv(v.lines); adv(v.counters); adv(v.hflags); adv(v.res);
+    v.base = nullptr; v.frames = 1; v.fb = 0;
+    return v;
+}
 
 static void roll_work_free(RollWork& k) {
     if (k.base) (void)hipFree(k.base);
     k = RollWork();
 }
 
-static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hipStream_t st) {
-    if (k.base && k.w == w && k.h == h && k.rho == rho && k.theta == theta) return VS_OK;
+static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hipStream_t st, int frames = 1) {
+    if (k.base && k.w == w && k.h == h && k.rho == rho && k.theta == theta && k.frames == frames) return VS_OK;
     roll_work_free(k);
     if (!(rho > 0) || !(theta > 0)) { set_last_error("hough: rho and theta must be positive"); return VS_ERR_INVALID_ARG; }
     // the accumulator has (pi / theta) x (2 (w + h) / rho) cells: bounded before the int casts of hough_geom can overflow
@@ -444,8 +473,9 @@ static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hi
     const size_t o_queue = take(npx * 4 + 64), o_list = take(npx * 4 + 64), o_accum = take(k.accum_bytes);
     const size_t o_sin = take((size_t)k.geom.numangle * 4), o_cos = take((size_t)k.geom.numangle * 4);
     const size_t o_keys = take((size_t)HOUGH_CAP * 8), o_lines = take((size_t)HOUGH_CAP * 8), o_cnt = take(128), o_res = take(64);
-    VS_HIP_TRY(hipMalloc((void**)&k.base, off));
-    VS_HIP_TRY(hipMemsetAsync(k.base, 0, off, st));
+    VS_HIP_TRY(hipMalloc((void**)&k.base, off * frames));
+    VS_HIP_TRY(hipMemsetAsync(k.base, 0, off * frames, st));
+    k.frames = frames; k.fb = frames > 1 ? off : 0;
     uint8_t* b = k.base;
     k.gray = b + o_gray; k.edges = b + o_edges; k.dxy = (short2*)(b + o_dxy); k.mag = (int*)(b + o_mag);
     k.E = (unsigned long long*)(b + o_E); k.C = (unsigned long long*)(b + o_C); k.queue = (int*)(b + o_queue); k.list = (int*)(b + o_list); k.accum = (int*)(b + o_accum);
@@ -460,8 +490,10 @@ static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hi
         ts[n] = (float)(std::sin((double)ang) * irho);
         tc[n] = (float)(std::cos((double)ang) * irho);
     }
-    VS_HIP_TRY(hipMemcpyAsync(k.tabSin, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, st));
-    VS_HIP_TRY(hipMemcpyAsync(k.tabCos, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, st));
+    for (int f = 0; f < frames; f++) {       // (every frame's area carries its own copy of the tables: one layout)
+        VS_HIP_TRY(hipMemcpyAsync((uint8_t*)k.tabSin + (size_t)f * k.fb, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, st));
+        VS_HIP_TRY(hipMemcpyAsync((uint8_t*)k.tabCos + (size_t)f * k.fb, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, st));
+    }
     VS_HIP_TRY(hipStreamSynchronize(st));
     return VS_OK;
 }
@@ -470,11 +502,12 @@ static int roll_work_alloc(RollWork& k, int w, int h, float rho, float theta, hi
 // one returns at once when the pass before it changed nothing.
 static int hyst_group(RollWork& k, int group, hipStream_t st) {
     const int nwv = k.wpr < HB_WORDS ? k.wpr : HB_WORDS;
-    dim3 hg((k.wpr + nwv - 1) / nwv, (k.h + HB_ROWS - 1) / HB_ROWS);
-    VS_HIP_TRY(hipMemsetAsync(k.hflags, 0, 64, st));
+    dim3 hg((k.wpr + nwv - 1) / nwv, (k.h + HB_ROWS - 1) / HB_ROWS, k.frames);
+    if (k.frames > 1) VS_HIP_TRY(hipMemset2DAsync(k.hflags, k.fb, 0, 64, k.frames, st));
+    else VS_HIP_TRY(hipMemsetAsync(k.hflags, 0, 64, st));
     for (int p = 0; p < group; p++)
         hipLaunchKernelGGL(canny_hyst_band_kernel, hg, dim3(64 * nwv), 0, st, k.E, k.C, k.wpr, k.h, k.hflags + p,
-                           p ? k.hflags + p - 1 : (int*)nullptr);
+                           p ? k.hflags + p - 1 : (int*)nullptr, k.fb);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -508,9 +541,10 @@ static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double l
     if (low_t > high_t) std::swap(low_t, high_t);
     const int low = (int)std::floor(low_t), high = (int)std::floor(high_t);
     const int w = k.w, h = k.h;
-    dim3 grid((w + NT - 1) / NT, h);
-    hipLaunchKernelGGL(sobel_kernel, grid, dim3(NT), 0, st, d_gray, stride, w, h, k.dxy, k.mag, k.mw);
-    hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.E, k.C, k.wpr);
+    // (several frames: d_gray is frame 0's analysis image inside the work area, the others lie k.fb apart like everything else)
+    dim3 grid((w + NT - 1) / NT, h, k.frames);
+    hipLaunchKernelGGL(sobel_kernel, grid, dim3(NT), 0, st, d_gray, stride, w, h, k.dxy, k.mag, k.mw, k.fb);
+    hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.E, k.C, k.wpr, k.fb);
     VS_HIP_TRY(hipGetLastError());
     VS_TRY(hyst_group(k, 4, st));
     if (!unchecked) {
@@ -527,27 +561,29 @@ static int run_hough(RollWork& k, const uint8_t* d_edges, size_t estride, int th
                      hipStream_t st) {
     const int w = k.w, h = k.h;
     if (w > 65535 || h > 32767) { set_last_error("hough: image too large"); return VS_ERR_INVALID_ARG; }
-    VS_HIP_TRY(hipMemsetAsync(k.counters + 1, 0, 60, st));
+    if (k.frames > 1) VS_HIP_TRY(hipMemset2DAsync(k.counters + 1, k.fb, 0, 60, k.frames, st));
+    else VS_HIP_TRY(hipMemsetAsync(k.counters + 1, 0, 60, st));
     if (d_edges) {
         dim3 lgrid((w + NT * EL_PX - 1) / (NT * EL_PX), h);
         hipLaunchKernelGGL(edge_list_kernel, lgrid, dim3(NT), 0, st, d_edges, estride, w, h, k.list, k.counters);
     } else {        // the edge set of the last run_canny on this work area, as it stands in k.E
-        hipLaunchKernelGGL(edge_list_bits_kernel, dim3((k.wpr * h + NT - 1) / NT), dim3(NT), 0, st, k.E, k.wpr, h, k.list,
-                           k.counters);
+        hipLaunchKernelGGL(edge_list_bits_kernel, dim3((k.wpr * h + NT - 1) / NT, 1, k.frames), dim3(NT), 0, st, k.E, k.wpr, h, k.list,
+                           k.counters, k.fb);
     }
     const size_t row_bytes = (size_t)k.geom.numrho * 4;
     if (row_bytes <= 60 * 1024) {
-        hipLaunchKernelGGL(hough_accum_lds_kernel, dim3(k.geom.numangle), dim3(1024), row_bytes, st, k.list, k.counters,
-                           k.tabSin, k.tabCos, k.geom.numrho, k.accum);
+        hipLaunchKernelGGL(hough_accum_lds_kernel, dim3(k.geom.numangle, 1, k.frames), dim3(1024), row_bytes, st, k.list, k.counters,
+                           k.tabSin, k.tabCos, k.geom.numrho, k.accum, k.fb);
     } else {
-        VS_HIP_TRY(hipMemsetAsync(k.accum, 0, k.accum_bytes, st));
-        hipLaunchKernelGGL(hough_accum_kernel, dim3(2048), dim3(NT), 0, st, k.list, k.counters, k.tabSin, k.tabCos,
-                           k.geom.numangle, k.geom.numrho, k.accum);
+        if (k.frames > 1) VS_HIP_TRY(hipMemset2DAsync(k.accum, k.fb, 0, k.accum_bytes, k.frames, st));
+        else VS_HIP_TRY(hipMemsetAsync(k.accum, 0, k.accum_bytes, st));
+        hipLaunchKernelGGL(hough_accum_kernel, dim3(2048, 1, k.frames), dim3(NT), 0, st, k.list, k.counters, k.tabSin, k.tabCos,
+                           k.geom.numangle, k.geom.numrho, k.accum, k.fb);
     }
-    dim3 g2((k.geom.numrho + NT - 1) / NT, k.geom.numangle);
-    hipLaunchKernelGGL(hough_peaks_kernel, g2, dim3(NT), 0, st, k.accum, k.geom.numangle, k.geom.numrho, threshold, k.keys, k.counters);
-    hipLaunchKernelGGL(hough_select_kernel, dim3(1), dim3(1024), 0, st, k.keys, k.counters, k.geom.numrho, k.rho, k.theta,
-                       amin, amax, k.lines, HOUGH_CAP, k.res);
+    dim3 g2((k.geom.numrho + NT - 1) / NT, k.geom.numangle, k.frames);
+    hipLaunchKernelGGL(hough_peaks_kernel, g2, dim3(NT), 0, st, k.accum, k.geom.numangle, k.geom.numrho, threshold, k.keys, k.counters, k.fb);
+    hipLaunchKernelGGL(hough_select_kernel, dim3(1, 1, k.frames), dim3(1024), 0, st, k.keys, k.counters, k.geom.numrho, k.rho, k.theta,
+                       amin, amax, k.lines, HOUGH_CAP, k.res, k.fb);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -570,21 +606,26 @@ struct vs_roll {
     double last_detected = 0.0;
     int last_lines = 0, last_used = 0;
     // asynchronous NV12 path (vs_roll_correct_nv12_dev): the line search of a frame does not depend on the frames before it -
-    // only the smoothed angle does, a three-flop recurrence on the host.  A frame's search is fifteen small launches, and queued
-    // from the caller's thread they cost ~100 us of the runtime's launch path per frame (9 k frames/s, whether one by one or as a
-    // captured graph - the runtime replays a graph node by node).  RS worker threads, each with a stream and a work area of its
-    // own, take the frames in turn: a worker queues its frame's search, waits for the 24-byte result, and then - in frame order -
-    // advances the angle (EMA, clamp, decay) and queues the rotation of both planes on `st`.  The caller's thread only hands
-    // over the job.
-    static constexpr int RS = 8, QMAX = 64;
+    // only the smoothed angle does, a three-flop recurrence on the host.  A frame's search is fifteen small launches: queued one
+    // by one from the caller's thread they cost ~100 us of the runtime's launch path per frame (9 k frames/s; the same as a
+    // captured graph, which the runtime replays node by node), and from eight threads, a frame each, still 80 us (12.5 k).  So the
+    // searches of RB consecutive frames go through ONE launch per stage (blockIdx.z = frame, a work area per frame), queued by
+    // one of NWK worker threads on its own stream; when the batch's results (24 bytes per frame) have arrived the worker - in
+    // frame order - advances the angle (EMA, clamp, decay) and queues each frame's rotation (both planes) on `st`.  The caller's
+    // thread only hands the frames over.
+    static constexpr int NWK = 3, RB = 8, QMAX = 128;
     struct Job { const uint8_t* src; uint8_t* dst; int w, h; size_t pitch, uv, opitch, ouv; long seq; };
     struct Slot {
-        RollWork wk;
+        RollWork wk;                     // RB frames
         hipStream_t st = nullptr;
         hipEvent_t ev = nullptr;
-        int32_t* h_res = nullptr;        // page-locked: counters[16], hysteresis flags[16], pad, RollResult at byte 256
-        std::deque<Job> jobs;
-    } slot[RS];
+        int32_t* h_res = nullptr;        // page-locked, per frame 320 bytes: counters[16], hysteresis flags[16], pad, RollResult at byte 256
+        ImgPair* h_pairs = nullptr;      // page-locked: (surface, analysis image) of the batch's frames
+        ImgPair* d_pairs = nullptr;
+        std::deque<std::vector<Job>> batches;
+    } slot[NWK];
+    std::vector<Job> pending;            // handed over, not yet a batch
+    long nbatches = 0;
     std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
@@ -694,6 +735,8 @@ void vs_roll_destroy(vs_roll* r) {
         if (q.st) { (void)hipStreamSynchronize(q.st); (void)hipStreamDestroy(q.st); }
         if (q.ev) (void)hipEventDestroy(q.ev);
         if (q.h_res) (void)hipHostFree(q.h_res);
+        if (q.h_pairs) (void)hipHostFree(q.h_pairs);
+        if (q.d_pairs) (void)hipFree(q.d_pairs);
         roll_work_free(q.wk);
     }
     if (r->st) (void)hipStreamSynchronize(r->st);
@@ -786,83 +829,106 @@ int vs_roll_correct_dev(vs_roll* r, const void* d_data, int w, int h, size_t str
     return vs_op_warp_affine_ex(d_data, stride, w, h, d_out, out_stride, w, h, 3, M, VS_BORDER_REPLICATE, r->st);   // :146-149
 }
 
-// One worker of the asynchronous NV12 path: the frames seq = wi, wi + RS, ... in turn.
-static int roll_worker_frame(vs_roll* r, vs_roll::Slot& q, const vs_roll::Job& j) {
+// One batch of the asynchronous NV12 path: the line searches of its frames as one launch per stage, then - in frame order - the
+// angle recurrence and the rotations.  Returns with r->mu held by `lk` when the ordered part was reached.
+static int roll_worker_batch(vs_roll* r, vs_roll::Slot& q, const std::vector<vs_roll::Job>& jobs, std::unique_lock<std::mutex>& lk) {
     const vs_roll_params_c& p = r->p;
+    const int n = (int)jobs.size();
+    const vs_roll::Job& j0 = jobs[0];
     if (!q.st) {
         R_HIP(r, hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
         R_HIP(r, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
-        R_HIP(r, hipHostMalloc((void**)&q.h_res, 320, hipHostMallocDefault));
+        R_HIP(r, hipHostMalloc((void**)&q.h_res, 320 * vs_roll::RB, hipHostMallocDefault));
+        R_HIP(r, hipHostMalloc((void**)&q.h_pairs, sizeof(ImgPair) * vs_roll::RB, hipHostMallocDefault));
+        R_HIP(r, hipMalloc((void**)&q.d_pairs, sizeof(ImgPair) * vs_roll::RB));
     }
-    int sw = (int)(j.w * p.scale_factor), sh = (int)(j.h * p.scale_factor);                     // :35-38
-    if (!(sw > 0 && sh > 0)) { sw = j.w; sh = j.h; }                                             // :40-45
-    VS_TRY(roll_work_alloc(q.wk, sw, sh, p.hough_rho, p.hough_theta, q.st));
-    RollWork& k = q.wk;
-    VS_TRY(launch_resize_gray(j.src, j.pitch, j.w, j.h, VS_FMT_GRAY8, k.gray, sw, sw, sh, q.st));                               // :41
-    VS_TRY(run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true));     // :54-61
-    VS_TRY(run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));                         // :66-73, :106-119
-    // counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics: one copy
-    VS_HIP_TRY(hipMemcpyAsync(q.h_res, k.counters, 256 + sizeof(RollResult), hipMemcpyDeviceToHost, q.st));
+    int sw = (int)(j0.w * p.scale_factor), sh = (int)(j0.h * p.scale_factor);                   // :35-38
+    if (!(sw > 0 && sh > 0)) { sw = j0.w; sh = j0.h; }                                           // :40-45
+    VS_TRY(roll_work_alloc(q.wk, sw, sh, p.hough_rho, p.hough_theta, q.st, vs_roll::RB));
+    RollWork k = q.wk;               // the first n work areas
+    k.base = nullptr; k.frames = n;
+    for (int f = 0; f < n; f++) { q.h_pairs[f].src = jobs[f].src; q.h_pairs[f].dst = k.gray + (size_t)f * k.fb; }
+    VS_HIP_TRY(hipMemcpyAsync(q.d_pairs, q.h_pairs, sizeof(ImgPair) * n, hipMemcpyHostToDevice, q.st));
+    VS_TRY(launch_resize_gray_batch(q.d_pairs, n, j0.pitch, j0.w, j0.h, VS_FMT_GRAY8, sw, sw, sh, 0, q.st));                     // :41
+    VS_TRY(run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true));      // :54-61
+    VS_TRY(run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));                          // :66-73, :106-119
+    // per frame: counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics
+    VS_HIP_TRY(hipMemcpy2DAsync(q.h_res, 320, k.counters, k.fb, 256 + sizeof(RollResult), n, hipMemcpyDeviceToHost, q.st));
     VS_HIP_TRY(hipEventRecord(q.ev, q.st));
     VS_HIP_TRY(hipEventSynchronize(q.ev));
-    RollResult res;
-    memcpy(&res, reinterpret_cast<const uint8_t*>(q.h_res) + 256, sizeof res);
-    bool slow = false;
-    if (q.h_res[16 + 3]) {          // the edge set was still growing after four passes: finish it and redo the line search
-        slow = true;
-        VS_TRY(hyst_finish(k, q.st));
-        VS_TRY(run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));
-        VS_HIP_TRY(hipMemcpyAsync(&res, k.res, sizeof res, hipMemcpyDeviceToHost, q.st));
-        VS_HIP_TRY(hipStreamSynchronize(q.st));
+    std::vector<RollResult> res((size_t)n);
+    std::vector<char> slow((size_t)n, 0);
+    for (int f = 0; f < n; f++) {
+        const uint8_t* h = reinterpret_cast<const uint8_t*>(q.h_res) + (size_t)320 * f;
+        memcpy(&res[f], h + 256, sizeof(RollResult));
+        if (reinterpret_cast<const int32_t*>(h)[16 + 3]) {      // the edge set was still growing after four passes: finish it, search again
+            slow[f] = 1;
+            RollWork v = frame_view(q.wk, f);
+            VS_TRY(hyst_finish(v, q.st));
+            VS_TRY(run_hough(v, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));
+            VS_HIP_TRY(hipMemcpyAsync(&res[f], v.res, sizeof(RollResult), hipMemcpyDeviceToHost, q.st));
+            VS_HIP_TRY(hipStreamSynchronize(q.st));
+        }
     }
-    // ---- in frame order: the angle recurrence and the rotation
-    std::unique_lock<std::mutex> lk(r->mu);
-    r->cv_done.wait(lk, [&] { return r->nv_done == j.seq; });
-    if (slow) r->slow_frames++;
-    roll_update(r, res);
-    // cv::getRotationMatrix2D(center, angle, 1.0) (:141-144); the interleaved chroma plane is the half-size picture: the same
-    // rotation with the translation halved
-    const float cx = j.w / 2.0f, cy = j.h / 2.0f;
-    const double a = r->smoothed * 3.1415926535897932384626433832795 / 180;
-    const double alpha = std::cos(a), beta = std::sin(a);
-    const double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
-    const double Mc[6] = {M[0], M[1], M[2] * 0.5, M[3], M[4], M[5] * 0.5};
-    int rc = vs_op_warp_affine_ex(j.src, j.pitch, j.w, j.h, j.dst, j.opitch, j.w, j.h, 1, M, VS_BORDER_REPLICATE, r->st);          // :146-149
-    if (rc == VS_OK)
-        rc = vs_op_warp_affine_ex(j.src + j.uv, j.pitch, j.w / 2, j.h / 2, j.dst + j.ouv, j.opitch, j.w / 2, j.h / 2, 2, Mc, VS_BORDER_REPLICATE, r->st);
-    return rc;          // (the caller advances nv_done under the same lock)
+    // ---- in frame order: the angle recurrence and the rotations
+    lk.lock();
+    r->cv_done.wait(lk, [&] { return r->nv_done == j0.seq; });
+    for (int f = 0; f < n; f++) {
+        const vs_roll::Job& j = jobs[f];
+        if (slow[f]) r->slow_frames++;
+        roll_update(r, res[f]);
+        // cv::getRotationMatrix2D(center, angle, 1.0) (:141-144); the interleaved chroma plane is the half-size picture: the same
+        // rotation with the translation halved
+        const float cx = j.w / 2.0f, cy = j.h / 2.0f;
+        const double a = r->smoothed * 3.1415926535897932384626433832795 / 180;
+        const double alpha = std::cos(a), beta = std::sin(a);
+        const double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
+        const double Mc[6] = {M[0], M[1], M[2] * 0.5, M[3], M[4], M[5] * 0.5};
+        VS_TRY(vs_op_warp_affine_ex(j.src, j.pitch, j.w, j.h, j.dst, j.opitch, j.w, j.h, 1, M, VS_BORDER_REPLICATE, r->st));          // :146-149
+        VS_TRY(vs_op_warp_affine_ex(j.src + j.uv, j.pitch, j.w / 2, j.h / 2, j.dst + j.ouv, j.opitch, j.w / 2, j.h / 2, 2, Mc, VS_BORDER_REPLICATE, r->st));
+    }
+    return VS_OK;
 }
 
 static void roll_worker(vs_roll* r, int wi) {
     (void)hipSetDevice(r->device);
     vs_roll::Slot& q = r->slot[wi];
     for (;;) {
-        vs_roll::Job j;
+        std::vector<vs_roll::Job> jobs;
         {
             std::unique_lock<std::mutex> lk(r->mu);
-            r->cv_job.wait(lk, [&] { return r->quit || !q.jobs.empty(); });
-            if (q.jobs.empty()) return;
-            j = q.jobs.front();
-            q.jobs.pop_front();
+            r->cv_job.wait(lk, [&] { return r->quit || !q.batches.empty(); });
+            if (q.batches.empty()) return;
+            jobs.swap(q.batches.front());
+            q.batches.pop_front();
         }
-        int rc = roll_worker_frame(r, q, j);
-        {
-            std::unique_lock<std::mutex> lk(r->mu, std::defer_lock);
-            if (!lk.owns_lock()) lk.lock();
-            // (a frame that failed before its ordered part still has to let the next one pass)
-            r->cv_done.wait(lk, [&] { return r->nv_done == j.seq; });
-            if (rc != VS_OK && r->worker_rc == VS_OK) { r->worker_rc = rc; r->worker_err = get_last_error(); }
-            r->nv_done++;
+        std::unique_lock<std::mutex> lk(r->mu, std::defer_lock);
+        const int rc = roll_worker_batch(r, q, jobs, lk);
+        if (!lk.owns_lock()) {           // (a batch that failed before its ordered part still has to let the next one pass)
+            lk.lock();
+            r->cv_done.wait(lk, [&] { return r->nv_done == jobs[0].seq; });
         }
+        if (rc != VS_OK && r->worker_rc == VS_OK) { r->worker_rc = rc; r->worker_err = get_last_error(); }
+        r->nv_done += (long)jobs.size();
+        lk.unlock();
         r->cv_done.notify_all();
     }
 }
 
+// (r->mu held) what has been handed over becomes a batch of the next worker
+static void roll_flush_pending(vs_roll* r) {
+    if (r->pending.empty()) return;
+    r->slot[r->nbatches % vs_roll::NWK].batches.emplace_back();
+    r->slot[r->nbatches % vs_roll::NWK].batches.back().swap(r->pending);
+    r->nbatches++;
+}
+
 // autoCorrectRoll for an NV12 surface in HBM (luma plane at d_surface, interleaved chroma plane uv_offset bytes behind it; the
 // same for the result), ASYNCHRONOUS: the line search runs on the luma plane (resize x scale_factor -> Canny -> HoughLines; a
-// gray picture needs no cvtColor), the rotation is applied to both planes.  The call hands the frame to the object's worker
-// threads and returns; results are complete after vs_roll_sync.  The surface and the result buffer of a call must stay
-// untouched until then.
+// gray picture needs no cvtColor), the rotation is applied to both planes.  The call hands the frame over and returns; eight
+// consecutive frames of one geometry form a batch that a worker thread analyses with one launch per stage.  Results are complete
+// after vs_roll_sync (which also closes an incomplete batch).  The surface and the result buffer of a call must stay untouched
+// until then.
 int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset, void* d_out, size_t out_pitch,
                              size_t out_uv_offset) {
     if (!r || !d_surface || !d_out || w < 2 || h < 2 || (w & 1) || (h & 1) || pitch < (size_t)w || out_pitch < (size_t)w) return VS_ERR_INVALID_ARG;
@@ -871,7 +937,7 @@ int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, si
     R_HIP(r, hipSetDevice(r->device));
     if (r->workers.empty()) {
         try {
-            for (int i = 0; i < vs_roll::RS; i++) r->workers.emplace_back(roll_worker, r, i);
+            for (int i = 0; i < vs_roll::NWK; i++) r->workers.emplace_back(roll_worker, r, i);
         } catch (...) {
             r->err = "roll: cannot start worker threads"; set_last_error(r->err);
             return VS_ERR_HIP;
@@ -881,9 +947,10 @@ int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, si
         std::unique_lock<std::mutex> lk(r->mu);
         if (r->first) { r->first = false; r->smoothed = 0.0; }                                   // :24-27
         r->cv_done.wait(lk, [&] { return r->nv_in - r->nv_done < vs_roll::QMAX; });
-        vs_roll::Job j{(const uint8_t*)d_surface, (uint8_t*)d_out, w, h, pitch, uv_offset, out_pitch, out_uv_offset, r->nv_in};
-        r->slot[r->nv_in % vs_roll::RS].jobs.push_back(j);
+        if (!r->pending.empty() && (r->pending[0].w != w || r->pending[0].h != h || r->pending[0].pitch != pitch)) roll_flush_pending(r);
+        r->pending.push_back(vs_roll::Job{(const uint8_t*)d_surface, (uint8_t*)d_out, w, h, pitch, uv_offset, out_pitch, out_uv_offset, r->nv_in});
         r->nv_in++;
+        if ((int)r->pending.size() >= vs_roll::RB) roll_flush_pending(r);
     }
     r->cv_job.notify_all();
     return VS_OK;
@@ -894,6 +961,8 @@ int vs_roll_sync(vs_roll* r) {
     R_HIP(r, hipSetDevice(r->device));
     if (!r->workers.empty()) {          // asynchronous NV12 frames: until the last one is closed
         std::unique_lock<std::mutex> lk(r->mu);
+        roll_flush_pending(r);
+        r->cv_job.notify_all();
         r->cv_done.wait(lk, [&] { return r->nv_done == r->nv_in; });
         if (r->worker_rc != VS_OK) {
             const int rc = r->worker_rc;
