@@ -39,6 +39,8 @@ namespace vsd {
 
 int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst, size_t dstride,
                            int dw, int dh, int cn, const double* h_Minv, int border, hipStream_t st);
+int launch_warp_affine_list_inv(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh, size_t dstride, int dw, int dh,
+                                int cn, const double* h_Minv, int border, hipStream_t st);
 
 namespace {
 
@@ -688,20 +690,22 @@ int vs_op_hough_lines(const void* d_edges, size_t stride, int w, int h, float rh
     return VS_OK;
 }
 
+// cv::warpAffine: the forward matrix (double) is inverted in double
+static void invert_forward(const double* M, double* Mi) {
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    Mi[0] = A11; Mi[1] = M[1] * -D; Mi[3] = M[3] * -D; Mi[4] = A22;
+    Mi[2] = -Mi[0] * M[2] - Mi[1] * M[5];
+    Mi[5] = -Mi[3] * M[2] - Mi[4] * M[5];
+}
+
 int vs_op_warp_affine_ex(const void* d_src, size_t src_stride, int sw, int sh, void* d_dst, size_t dst_stride, int dw,
                          int dh, int cn, const double* M, int border, void* stream) {
     VS_TRY(ensure_device());
     if (!M) return VS_ERR_INVALID_ARG;
-    // cv::warpAffine: the forward matrix is inverted in double
     double Mi[6];
-    {
-        double D = M[0] * M[4] - M[1] * M[3];
-        D = D != 0 ? 1. / D : 0;
-        const double A11 = M[4] * D, A22 = M[0] * D;
-        Mi[0] = A11; Mi[1] = M[1] * -D; Mi[3] = M[3] * -D; Mi[4] = A22;
-        Mi[2] = -Mi[0] * M[2] - Mi[1] * M[5];
-        Mi[5] = -Mi[3] * M[2] - Mi[4] * M[5];
-    }
+    invert_forward(M, Mi);
     return launch_warp_affine_inv((const uint8_t*)d_src, src_stride, sw, sh, (uint8_t*)d_dst, dst_stride, dw, dh, cn, Mi,
                                   border, (hipStream_t)stream);
 }
@@ -873,6 +877,10 @@ static int roll_worker_batch(vs_roll* r, vs_roll::Slot& q, const std::vector<vs_
     // ---- in frame order: the angle recurrence and the rotations
     lk.lock();
     r->cv_done.wait(lk, [&] { return r->nv_done == j0.seq; });
+    double Iy[vs_roll::RB * 6], Iu[vs_roll::RB * 6];
+    const uint8_t *ys[vs_roll::RB], *us[vs_roll::RB];
+    uint8_t *yd[vs_roll::RB], *ud[vs_roll::RB];
+    bool one_launch = true;
     for (int f = 0; f < n; f++) {
         const vs_roll::Job& j = jobs[f];
         if (slow[f]) r->slow_frames++;
@@ -884,8 +892,21 @@ static int roll_worker_batch(vs_roll* r, vs_roll::Slot& q, const std::vector<vs_
         const double alpha = std::cos(a), beta = std::sin(a);
         const double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
         const double Mc[6] = {M[0], M[1], M[2] * 0.5, M[3], M[4], M[5] * 0.5};
-        VS_TRY(vs_op_warp_affine_ex(j.src, j.pitch, j.w, j.h, j.dst, j.opitch, j.w, j.h, 1, M, VS_BORDER_REPLICATE, r->st));          // :146-149
-        VS_TRY(vs_op_warp_affine_ex(j.src + j.uv, j.pitch, j.w / 2, j.h / 2, j.dst + j.ouv, j.opitch, j.w / 2, j.h / 2, 2, Mc, VS_BORDER_REPLICATE, r->st));
+        invert_forward(M, Iy + 6 * f);
+        invert_forward(Mc, Iu + 6 * f);
+        ys[f] = j.src; us[f] = j.src + j.uv; yd[f] = j.dst; ud[f] = j.dst + j.ouv;
+        one_launch &= j.opitch == j0.opitch;
+    }
+    // the rotations of the batch (:146-149): one launch per plane when the results share a pitch (the surfaces do), else frame by frame
+    if (one_launch) {
+        VS_TRY(launch_warp_affine_list_inv(ys, yd, n, j0.pitch, j0.w, j0.h, j0.opitch, j0.w, j0.h, 1, Iy, VS_BORDER_REPLICATE, r->st));
+        VS_TRY(launch_warp_affine_list_inv(us, ud, n, j0.pitch, j0.w / 2, j0.h / 2, j0.opitch, j0.w / 2, j0.h / 2, 2, Iu, VS_BORDER_REPLICATE, r->st));
+    } else {
+        for (int f = 0; f < n; f++) {
+            const vs_roll::Job& j = jobs[f];
+            VS_TRY(launch_warp_affine_inv(ys[f], j.pitch, j.w, j.h, yd[f], j.opitch, j.w, j.h, 1, Iy + 6 * f, VS_BORDER_REPLICATE, r->st));
+            VS_TRY(launch_warp_affine_inv(us[f], j.pitch, j.w / 2, j.h / 2, ud[f], j.opitch, j.w / 2, j.h / 2, 2, Iu + 6 * f, VS_BORDER_REPLICATE, r->st));
+        }
     }
     return VS_OK;
 }

@@ -1381,6 +1381,37 @@ int launch_warp_nv12_hostM(const uint8_t* d_src, size_t sstride, size_t sframe, 
     return VS_OK;
 }
 
+// Frames given one by one, inverse maps given on the host in double (6 per frame), selectable border: the rotations of a batch
+// of roll-corrected frames (cv::warpAffine(..., BORDER_REPLICATE), RollCorrection.cpp:146-149) as ONE launch per plane.  Four
+// frames and more take the coordinate tables (scratch of the stream, op_tabs).
+int launch_warp_affine_list_inv(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh, size_t dstride, int dw, int dh,
+                                int cn, const double* h_Minv, int border, hipStream_t st) {
+    if (n < 1 || n > MAXB || !srcs || !dsts || bad_args(srcs[0], dsts[0], h_Minv, sstride, sw, sh, dstride, dw, dh, cn, n) ||
+        (border != VS_BORDER_BLACK && border != VS_BORDER_REPLICATE)) {
+        set_last_error("warp_affine_list_inv: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
+    WarpArgs a;
+    fill_common(a, srcs[0], sstride, 0, sw, sh, dsts[0], dstride, 0, dw, dh, cn);
+    const int galign = cn == 2 ? 8 : 4;
+    for (int i = 0; i < MAXB; i++) {
+        a.srcs[i] = srcs[i < n ? i : 0]; a.dsts[i] = dsts[i < n ? i : 0];
+        if (!a.srcs[i] || !a.dsts[i]) { set_last_error("warp_affine_list_inv: null frame"); return VS_ERR_INVALID_ARG; }
+        if ((uintptr_t)a.srcs[i] % galign) a.c.src_aligned = 0;
+        if ((uintptr_t)a.dsts[i] % galign) a.c.dst_aligned = 0;
+    }
+    a.use_list = 1;
+    a.Minv_dev = nullptr;
+    a.c.border = border;
+    for (int i = 0; i < MAXB * 6; i++) a.Minv_val[i] = i < 6 * n ? h_Minv[i] : 0.;
+    int32_t* d_tabs = nullptr;
+    if (n >= 4) VS_TRY(op_tabs(st, warp_tabs_ints(dw, dh, n) * sizeof(int32_t), &d_tabs));
+    dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, n);
+    launch_cn(a, grid, cn, d_tabs, st);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
 // One frame, inverse map given on the host in double, selectable border: used by the
 // roll-correction rotate (cv::warpAffine(..., BORDER_REPLICATE)) and AutoZoomCrop's scale.
 int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh, uint8_t* d_dst, size_t dstride,
