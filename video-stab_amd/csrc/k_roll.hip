@@ -539,7 +539,7 @@ static int canny_emit(RollWork& k, uint8_t* d_edges, size_t estride, hipStream_t
 }
 
 static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double low_t, double high_t, uint8_t* d_edges,
-                     size_t estride, hipStream_t st, bool unchecked = false) {
+                     size_t estride, hipStream_t st, bool unchecked = false, int first_group = 4) {
     if (low_t > high_t) std::swap(low_t, high_t);
     const int low = (int)std::floor(low_t), high = (int)std::floor(high_t);
     const int w = k.w, h = k.h;
@@ -548,10 +548,10 @@ static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double l
     hipLaunchKernelGGL(sobel_kernel, grid, dim3(NT), 0, st, d_gray, stride, w, h, k.dxy, k.mag, k.mw, k.fb);
     hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.E, k.C, k.wpr, k.fb);
     VS_HIP_TRY(hipGetLastError());
-    VS_TRY(hyst_group(k, 4, st));
+    VS_TRY(hyst_group(k, first_group, st));
     if (!unchecked) {
         int32_t flag = 0;
-        VS_HIP_TRY(hipMemcpyAsync(&flag, k.hflags + 3, 4, hipMemcpyDeviceToHost, st));
+        VS_HIP_TRY(hipMemcpyAsync(&flag, k.hflags + first_group - 1, 4, hipMemcpyDeviceToHost, st));
         VS_HIP_TRY(hipStreamSynchronize(st));
         if (flag) VS_TRY(hyst_finish(k, st));
     }
@@ -854,7 +854,10 @@ static int roll_worker_batch(vs_roll* r, vs_roll::Slot& q, const std::vector<vs_
     for (int f = 0; f < n; f++) { q.h_pairs[f].src = jobs[f].src; q.h_pairs[f].dst = k.gray + (size_t)f * k.fb; }
     VS_HIP_TRY(hipMemcpyAsync(q.d_pairs, q.h_pairs, sizeof(ImgPair) * n, hipMemcpyHostToDevice, q.st));
     VS_TRY(launch_resize_gray_batch(q.d_pairs, n, j0.pitch, j0.w, j0.h, VS_FMT_GRAY8, sw, sw, sh, 0, q.st));                     // :41
-    VS_TRY(run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true));      // :54-61
+    // (twelve hysteresis passes per batch - a pass whose predecessor changed nothing for its frame returns at once: with four, 40 % of
+    // the bench clip's frames had to finish their growth one by one behind the batch, 30 us per frame)
+    constexpr int PASSES = 12;
+    VS_TRY(run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true, PASSES));   // :54-61
     VS_TRY(run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));                          // :66-73, :106-119
     // per frame: counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics
     VS_HIP_TRY(hipMemcpy2DAsync(q.h_res, 320, k.counters, k.fb, 256 + sizeof(RollResult), n, hipMemcpyDeviceToHost, q.st));
@@ -865,7 +868,7 @@ static int roll_worker_batch(vs_roll* r, vs_roll::Slot& q, const std::vector<vs_
     for (int f = 0; f < n; f++) {
         const uint8_t* h = reinterpret_cast<const uint8_t*>(q.h_res) + (size_t)320 * f;
         memcpy(&res[f], h + 256, sizeof(RollResult));
-        if (reinterpret_cast<const int32_t*>(h)[16 + 3]) {      // the edge set was still growing after four passes: finish it, search again
+        if (reinterpret_cast<const int32_t*>(h)[16 + PASSES - 1]) {      // the edge set was still growing after the last pass: finish it, search again
             slow[f] = 1;
             RollWork v = frame_view(q.wk, f);
             VS_TRY(hyst_finish(v, q.st));
