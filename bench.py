@@ -446,7 +446,7 @@ def config2(vs, comm, device, args, full=True):
 
 
 def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
-    CH = 64
+    CH = int(os.environ.get("VS_BENCH_CHAIN_CHUNK", "64"))
     NF = int(os.environ.get("VS_BENCH_4K_CLIP", "64"))
     clip = synth.make_clip_dev(vs, synth.SEED_CONFIG3, W, H, NF, nv12=True)
     sb = W * H * 3 // 2
@@ -462,6 +462,16 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
     tickets = []
 
     import threading
+    busy = {"roll": 0.0, "stab": 0.0, "zoom": 0.0}       # host time of a stage's thread (its calls and its wait), timed chunks only
+    timing = [False]
+
+    def timed(name, f):
+        def g(c):
+            t = time.perf_counter()
+            f(c)
+            if timing[0]:
+                busy[name] += time.perf_counter() - t
+        return g
 
     def roll_stage(c):
         for i in range(CH):                                                    # roll: chunk c
@@ -487,7 +497,7 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
     def step(c):
         # one host thread per stage (a stage's calls queue a dozen launches per surface: three stages from one thread cost the sum
         # of their host times, 0.21 ms per surface); the three join at the end of the chunk
-        ths = [threading.Thread(target=f, args=(c,)) for f in (roll_stage, stab_stage, zoom_stage)]
+        ths = [threading.Thread(target=timed(n, f), args=(c,)) for n, f in (("roll", roll_stage), ("stab", stab_stage), ("zoom", zoom_stage))]
         for t in ths:
             t.start()
         for t in ths:
@@ -495,6 +505,7 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
     for c in range(chunks_warm):
         step(c)
     n0 = len(tickets)
+    timing[0] = True
     t0 = time.perf_counter()
     for c in range(chunks_warm, chunks_warm + chunks_timed):
         step(c)
@@ -502,7 +513,8 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
     n = len(tickets) - n0
     ow, oh, info = az.result(tickets[-1])
     res = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n, 1) * 1e3, 4), "frames": n,
-           "last_result": [ow, oh], "last_crop": [int(v) for v in info[2:6]],
+           "last_result": [ow, oh], "last_crop": [int(v) for v in info[2:6]], "chunk": CH,
+           "stage_thread_ms_per_chunk": {k: round(v / chunks_timed * 1e3, 3) for k, v in busy.items()},
            "what": "vs_roll_correct_nv12_dev -> vs_stab_push_dev (batch 64, zero-copy) -> vs_azc_apply_nv12_dev on 3840x2160 NV12 surfaces "
                    "resident in HBM, chunks of 64, one host thread per stage, the three stages overlapped on the device, one host wait per stage and chunk; every "
                    "surface goes through all three stages (640x360 NV12 out)"}
