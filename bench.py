@@ -456,7 +456,7 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
     d_zoom = [capi.DevBuf(vs, sb * CH) for _ in range(Z_RING)]      # (room for the fall-back: the unchanged 4K surface)
     rc, az = vs.roll_correction(), vs.auto_zoom_crop()
     st = vs.stabilizer(p, device=device)
-    st.set_batch(CH)
+    st.set_batch(min(CH, 64))
     st.set_zero_copy(True)
     produced = {}                      # chunk -> stabilized surfaces it yielded
     tickets = []

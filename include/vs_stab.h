@@ -507,8 +507,8 @@ int vs_azc_sync(vs_azc* a);
  * unchanged w x h surface: out_pitch >= max(w, 640), out_uv_offset >= max(h, 360) * out_pitch.  The call queues the mask
  * kernels and returns a ticket; the contour logic runs on the object's worker threads (it is host work in the reference too,
  * :141-147), which then queue the crop-and-scale.  vs_azc_result(ticket) waits for that frame's host part and tells what
- * came out; the pixels are complete after vs_azc_sync.  At most 16 frames in flight (eight worker threads), results of the last
- * 1024 tickets kept. */
+ * came out; the pixels are complete after vs_azc_sync.  At most 32 frames in flight, eight worker threads (environment
+ * VS_AZC_WORKERS: 1 .. 16), results of the last 1024 tickets kept. */
 int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset,
                           void* d_out, size_t out_pitch, size_t out_uv_offset, int64_t* ticket);
 int vs_azc_result(vs_azc* a, int64_t ticket, int* out_w, int* out_h, int32_t* info8);

@@ -173,7 +173,8 @@ struct vs_azc {
     // The mask kernels of a frame are queued by the call; the contour logic - host work in the reference as well
     // (AutoZoomCrop.cpp:141-147 downloads the mask for cv::findContours) - runs on worker threads, NW frames at a time (frames do
     // not depend on each other; 0.3 ms per 4K frame and thread: four threads were the limit of the stage at 12.8 k frames/s), and the worker then queues the crop-and-scale of both planes.  NS frames in flight.
-    static constexpr int NS = 16, NW = 8, NRES = 1024;
+    static constexpr int NS = 32, NRES = 1024;    // NS: slots = frames in flight
+    int nw = 8;                          // worker threads (VS_AZC_WORKERS, 1 .. 16)
     struct Slot {
         uint8_t* d_mask = nullptr;
         uint8_t* h_mask = nullptr;
@@ -452,7 +453,8 @@ int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t
     if (a->workers.empty()) {
         A_HIP(a, hipStreamCreateWithFlags(&a->st_out, hipStreamNonBlocking));
         try {
-            for (int i = 0; i < vs_azc::NW; i++) a->workers.emplace_back(azc_worker, a);
+            if (const char* e = std::getenv("VS_AZC_WORKERS")) a->nw = std::max(1, std::min(std::atoi(e), 16));
+            for (int i = 0; i < a->nw; i++) a->workers.emplace_back(azc_worker, a);
         } catch (...) {
             a->err = "auto zoom/crop: cannot start worker threads"; set_last_error(a->err);
             return VS_ERR_HIP;
