@@ -41,6 +41,8 @@ int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh,
                            int dw, int dh, int cn, const double* h_Minv, int border, hipStream_t st);
 int launch_warp_affine_list_inv(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh, size_t dstride, int dw, int dh,
                                 int cn, const double* h_Minv, int border, hipStream_t st);
+int launch_warp_nv12_list_inv(const uint8_t* const* ys, uint8_t* const* yd, int n, size_t sstride, size_t dstride, int w, int h, size_t src_uv,
+                              size_t dst_uv, const double* h_MinvY, const double* h_MinvUV, int border, hipStream_t st);
 
 namespace {
 
@@ -898,12 +900,12 @@ static int roll_worker_batch(vs_roll* r, vs_roll::Slot& q, const std::vector<vs_
         invert_forward(M, Iy + 6 * f);
         invert_forward(Mc, Iu + 6 * f);
         ys[f] = j.src; us[f] = j.src + j.uv; yd[f] = j.dst; ud[f] = j.dst + j.ouv;
-        one_launch &= j.opitch == j0.opitch;
+        one_launch &= j.opitch == j0.opitch && j.uv == j0.uv && j.ouv == j0.ouv;
     }
-    // the rotations of the batch (:146-149): one launch per plane when the results share a pitch (the surfaces do), else frame by frame
+    // the rotations of the batch (:146-149): luma and chroma tiles of all its surfaces in ONE grid (warp_nv12_kernel with the
+    // BORDER_REPLICATE staging) when the results share one layout (the surfaces do), else frame by frame
     if (one_launch) {
-        VS_TRY(launch_warp_affine_list_inv(ys, yd, n, j0.pitch, j0.w, j0.h, j0.opitch, j0.w, j0.h, 1, Iy, VS_BORDER_REPLICATE, r->st));
-        VS_TRY(launch_warp_affine_list_inv(us, ud, n, j0.pitch, j0.w / 2, j0.h / 2, j0.opitch, j0.w / 2, j0.h / 2, 2, Iu, VS_BORDER_REPLICATE, r->st));
+        VS_TRY(launch_warp_nv12_list_inv(ys, yd, n, j0.pitch, j0.opitch, j0.w, j0.h, j0.uv, j0.ouv, Iy, Iu, VS_BORDER_REPLICATE, r->st));
     } else {
         for (int f = 0; f < n; f++) {
             const vs_roll::Job& j = jobs[f];

@@ -815,6 +815,23 @@ __device__ __forceinline__ uint4 load_chunk_straddling(const uint8_t* rowp, int 
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// The same chunk under BORDER_REPLICATE (remapBilinear's clip()): a byte outside the row is the byte of the same channel of the
+// row's first / last pixel.  (Chunks of tiles at the picture's edge only.)
+template <int CN>
+__device__ __forceinline__ uint4 load_chunk_replicate(const uint8_t* rowp, int xb, int sw) {
+    uint32_t wq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int xx = xb + 4 * q + k;
+            const int px = min(max(CN == 1 ? xx : xx >> 1, 0), sw - 1);
+            wq[q] |= (uint32_t)rowp[CN == 1 ? px : 2 * px + (xx & 1)] << (8 * k);
+        }
+    }
+    return make_uint4(wq[0], wq[1], wq[2], wq[3]);
+}
+
 template <int CN> struct PlaneCfg {
     static constexpr int THP = 64 / CN;                  // rows of a tile
     static constexpr int DB = 136 * CN + 8 * CN;         // staged bytes of a row (136 pixels + slack for the 8-byte tap read)
@@ -941,7 +958,9 @@ __device__ __attribute__((noinline)) void plane_direct_tile(WarpCore c, const ui
 
 // One tile of a plane: tile (tx, ty) of the frame whose plane table starts at Ts (column records) / Tg (the per-column and
 // per-row terms).  tile / lut / s_row: the workgroup's LDS.
-template <int CN>
+// BORDER: what the staged box holds where it leaves the picture - zeros (cv::warpAffine BORDER_CONSTANT: the stabilizer's warp) or the
+// nearest picture pixel (BORDER_REPLICATE: the roll stage's rotation); a launch whose border is the other one takes the direct path.
+template <int CN, int BORDER = VS_BORDER_BLACK>
 __device__ __forceinline__ void plane_tile(const WarpCore& c, const __attribute__((address_space(4))) int32_t* Ts, gtab_t Tg, int tab_row, int tx, int tyl,
                                            uint8_t* tile, uint8_t* lut, int2* s_row, int tid) {
     typedef PlaneCfg<CN> P;
@@ -986,7 +1005,7 @@ __device__ __forceinline__ void plane_tile(const WarpCore& c, const __attribute_
         bx0a = bx0 & ~3;
         bw = bx1 - bx0a + 1;
         bh = by1 - by0 + 1;
-        fit = !saturated && bw <= 136 && bh <= P::ROWS && c.border == VS_BORDER_BLACK;
+        fit = !saturated && bw <= 136 && bh <= P::ROWS && c.border == BORDER;
     }
     if (fit) {
         // ---- staging: chunks of 16 bytes, (row, chunk) = (i / CPR, i % CPR); all loads of a lane first, then its stores
@@ -1002,7 +1021,11 @@ __device__ __forceinline__ void plane_tile(const WarpCore& c, const __attribute_
                 const int r = i / P::CPR, ch = i - r * P::CPR;
                 const int y = by0 + r;
                 const long long xb = (long long)bx0a * CN + 16 * ch;          // byte column of the chunk in the source row
-                if ((unsigned)y < (unsigned)c.sh) {
+                if (BORDER == VS_BORDER_REPLICATE) {
+                    const uint8_t* row = src + (size_t)min(max(y, 0), c.sh - 1) * c.sstride;
+                    if (xb >= 0 && xb + 16 <= rowbytes && c.src_aligned) d[k] = *reinterpret_cast<const uint4*>(row + xb);
+                    else d[k] = load_chunk_replicate<CN>(row, (int)max(min(xb, (long long)rowbytes + 64), -64ll), c.sw);
+                } else if ((unsigned)y < (unsigned)c.sh) {
                     const uint8_t* row = src + (size_t)y * c.sstride;
                     if (xb >= 0 && xb + 16 <= rowbytes && c.src_aligned) {
                         d[k] = *reinterpret_cast<const uint4*>(row + xb);       // 4-byte aligned: bx0a is a multiple of 4 pixels
@@ -1076,6 +1099,7 @@ __global__ __launch_bounds__(NT, 8) void warp_plane_kernel(gtab_t tabs, int tab_
 // c-th contiguous eighth).  A frame's tables lie in one block (warp_tab.h): luma table, then chroma table, `tab_stride` ints from
 // frame to frame.  The chroma plane's geometry is the luma plane's halved (surfaces share one pitch); flags as in the plane
 // kernels plus the frame count in bits 16...  mtpf = ceil(2^32 / tiles per frame), mgx1 / mgx2 likewise for the tile columns.
+template <int BORDER>
 __global__ __launch_bounds__(NT, 8) void warp_nv12_kernel(gtab_t tabs, int tab_stride, uint32_t sstride, uint32_t dstride, uint32_t swh, uint32_t dwh,
                                                        uint32_t flags, uint32_t mtpf, uint32_t mgx1, uint32_t mgx2) {
     typedef PlaneCfg<1> P1;
@@ -1105,7 +1129,7 @@ __global__ __launch_bounds__(NT, 8) void warp_nv12_kernel(gtab_t tabs, int tab_s
     if (t < n1) {
         const TabLayout L = tab_layout(c.dw, c.dh);
         const uint32_t row = gx1 == 1 ? t : __umulhi(t, mgx1);
-        plane_tile<1>(c, (cptr)(const int32_t*)T, T + L.ad, L.row, (int)(t - row * gx1), (int)row, tile, lut, s_row, threadIdx.x);
+        plane_tile<1, BORDER>(c, (cptr)(const int32_t*)T, T + L.ad, L.row, (int)(t - row * gx1), (int)row, tile, lut, s_row, threadIdx.x);
     } else {
         t -= n1;
         T += tab_layout(c.dw, c.dh).stride;
@@ -1113,7 +1137,7 @@ __global__ __launch_bounds__(NT, 8) void warp_nv12_kernel(gtab_t tabs, int tab_s
         c.src_aligned = (flags >> 5) & 1u; c.dst_aligned = (flags >> 6) & 1u;
         const TabLayout L = tab_layout(c.dw, c.dh);
         const uint32_t row = gx2 == 1 ? t : __umulhi(t, mgx2);
-        plane_tile<2>(c, (cptr)(const int32_t*)T, T + L.ad, L.row, (int)(t - row * gx2), (int)row, tile, lut, s_row, threadIdx.x);
+        plane_tile<2, BORDER>(c, (cptr)(const int32_t*)T, T + L.ad, L.row, (int)(t - row * gx2), (int)row, tile, lut, s_row, threadIdx.x);
     }
 }
 
@@ -1270,8 +1294,11 @@ int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, in
 // or launch_warp_affine_list(.., VS_WARP_TABLES_ONLY, nv12_tab_ints) per plane).  Returns VS_ERR_UNSUPPORTED when the geometry
 // is outside what the kernel packs (the caller then launches the planes one by one).
 int launch_warp_nv12_list(const uint8_t* const* ys, uint8_t* const* yd, int n, size_t sstride, size_t dstride, int w, int h, size_t src_uv,
-                          size_t dst_uv, const int32_t* d_tabs, hipStream_t st) {
-    if (!ys || !yd || !d_tabs || n < 1 || w < 2 || h < 2 || (w & 1) || (h & 1)) { set_last_error("warp_nv12_list: invalid argument"); return VS_ERR_INVALID_ARG; }
+                          size_t dst_uv, const int32_t* d_tabs, hipStream_t st, int border) {
+    if (!ys || !yd || !d_tabs || n < 1 || w < 2 || h < 2 || (w & 1) || (h & 1) || (border != VS_BORDER_BLACK && border != VS_BORDER_REPLICATE)) {
+        set_last_error("warp_nv12_list: invalid argument");
+        return VS_ERR_INVALID_ARG;
+    }
     typedef PlaneCfg<1> P1;
     typedef PlaneCfg<2> P2;
     const unsigned long long gx1 = (w + TW - 1) / TW, gy1 = (h + P1::THP - 1) / P1::THP, gx2 = (w / 2 + TW - 1) / TW, gy2 = (h / 2 + P2::THP - 1) / P2::THP;
@@ -1290,11 +1317,15 @@ int launch_warp_nv12_list(const uint8_t* const* ys, uint8_t* const* yd, int n, s
         if ((uintptr_t)ys[i] % 8) al &= ~4u;
         if ((uintptr_t)yd[i] % 8) al &= ~8u;
     }
-    const uint32_t flags = (al & 1u) | (al & 2u) | (uint32_t)VS_BORDER_BLACK << 2 | ((al >> 2) & 1u) << 5 | ((al >> 3) & 1u) << 6 | 0x100u | (uint32_t)n << 16;
+    const uint32_t flags = (al & 1u) | (al & 2u) | (uint32_t)border << 2 | ((al >> 2) & 1u) << 5 | ((al >> 3) & 1u) << 6 | 0x100u | (uint32_t)n << 16;
     const uint32_t mtpf = (uint32_t)((0x100000000ull + tpf - 1) / tpf), mgx1 = (uint32_t)((0x100000000ull + gx1 - 1) / gx1),
                    mgx2 = (uint32_t)((0x100000000ull + gx2 - 1) / gx2);
-    hipLaunchKernelGGL(warp_nv12_kernel, dim3((unsigned)total), dim3(NT), 0, st, (gtab_t)d_tabs, nv12_tab_ints(w, h), (uint32_t)sstride, (uint32_t)dstride,
-                       (uint32_t)w | (uint32_t)h << 16, (uint32_t)w | (uint32_t)h << 16, flags, mtpf, mgx1, mgx2);
+    if (border == VS_BORDER_REPLICATE)
+        hipLaunchKernelGGL(warp_nv12_kernel<VS_BORDER_REPLICATE>, dim3((unsigned)total), dim3(NT), 0, st, (gtab_t)d_tabs, nv12_tab_ints(w, h), (uint32_t)sstride,
+                           (uint32_t)dstride, (uint32_t)w | (uint32_t)h << 16, (uint32_t)w | (uint32_t)h << 16, flags, mtpf, mgx1, mgx2);
+    else
+        hipLaunchKernelGGL(warp_nv12_kernel<VS_BORDER_BLACK>, dim3((unsigned)total), dim3(NT), 0, st, (gtab_t)d_tabs, nv12_tab_ints(w, h), (uint32_t)sstride,
+                           (uint32_t)dstride, (uint32_t)w | (uint32_t)h << 16, (uint32_t)w | (uint32_t)h << 16, flags, mtpf, mgx1, mgx2);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -1408,6 +1439,47 @@ int launch_warp_affine_list_inv(const uint8_t* const* srcs, uint8_t* const* dsts
     if (n >= 4) VS_TRY(op_tabs(st, warp_tabs_ints(dw, dh, n) * sizeof(int32_t), &d_tabs));
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, n);
     launch_cn(a, grid, cn, d_tabs, st);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// NV12 surfaces given one by one, inverse maps of both planes given on the host (6 doubles per frame and plane), selectable
+// border: four and more surfaces build their table blocks with a launch per plane and are warped in ONE grid (the rotations of a
+// batch of roll-corrected surfaces); fewer go plane by plane.
+int launch_warp_nv12_list_inv(const uint8_t* const* ys, uint8_t* const* yd, int n, size_t sstride, size_t dstride, int w, int h, size_t src_uv,
+                              size_t dst_uv, const double* h_MinvY, const double* h_MinvUV, int border, hipStream_t st) {
+    if (n < 1 || n > MAXB || !ys || !yd || !h_MinvY || !h_MinvUV) { set_last_error("warp_nv12_list_inv: invalid argument"); return VS_ERR_INVALID_ARG; }
+    const uint8_t* us[MAXB];
+    uint8_t* ud[MAXB];
+    for (int i = 0; i < n; i++) {
+        if (!ys[i] || !yd[i]) { set_last_error("warp_nv12_list_inv: null frame"); return VS_ERR_INVALID_ARG; }
+        us[i] = ys[i] + src_uv; ud[i] = yd[i] + dst_uv;
+    }
+    int one = VS_ERR_UNSUPPORTED;
+    if (n >= 4) {
+        const int block = nv12_tab_ints(w, h), sy = tab_layout(w, h).stride;
+        int32_t* d_tabs = nullptr;
+        VS_TRY(op_tabs(st, (size_t)block * n * sizeof(int32_t), &d_tabs));
+        for (int plane = 0; plane < 2; plane++) {
+            WarpArgs a;
+            const int pw = plane ? w / 2 : w, ph = plane ? h / 2 : h;
+            fill_common(a, plane ? us[0] : ys[0], sstride, 0, pw, ph, plane ? ud[0] : yd[0], dstride, 0, pw, ph, plane ? 2 : 1);
+            for (int i = 0; i < MAXB; i++) { a.srcs[i] = plane ? us[i < n ? i : 0] : ys[i < n ? i : 0]; a.dsts[i] = plane ? ud[i < n ? i : 0] : yd[i < n ? i : 0]; }
+            a.use_list = 1;
+            a.Minv_dev = nullptr;
+            a.c.border = border;
+            const double* Mi = plane ? h_MinvUV : h_MinvY;
+            for (int i = 0; i < MAXB * 6; i++) a.Minv_val[i] = i < 6 * n ? Mi[i] : 0.;
+            dim3 grid((pw + TW - 1) / TW, (ph + TH - 1) / TH, n);
+            launch_cn(a, grid, plane ? 2 : 1, d_tabs + (plane ? sy : 0), st, VS_WARP_TABLES_ONLY, block);
+        }
+        one = launch_warp_nv12_list(ys, yd, n, sstride, dstride, w, h, src_uv, dst_uv, d_tabs, st, border);
+        if (one != VS_OK && one != VS_ERR_UNSUPPORTED) return one;
+    }
+    if (one == VS_ERR_UNSUPPORTED) {
+        VS_TRY(launch_warp_affine_list_inv(ys, yd, n, sstride, w, h, dstride, w, h, 1, h_MinvY, border, st));
+        VS_TRY(launch_warp_affine_list_inv(us, ud, n, sstride, w / 2, h / 2, dstride, w / 2, h / 2, 2, h_MinvUV, border, st));
+    }
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

@@ -100,7 +100,7 @@ int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, in
                             hipStream_t st, int what = VS_WARP_ALL, int tab_stride = 0);
 // NV12: both planes of n surfaces in one launch, from table blocks (warp_tab.h) that have been built
 int launch_warp_nv12_list(const uint8_t* const* ys, uint8_t* const* yd, int n, size_t sstride, size_t dstride, int w, int h, size_t src_uv,
-                          size_t dst_uv, const int32_t* d_tabs, hipStream_t st);
+                          size_t dst_uv, const int32_t* d_tabs, hipStream_t st, int border = VS_BORDER_BLACK);
 int launch_resize_gray(const uint8_t* d_src, size_t sstride, int sw, int sh, int fmt,
                        uint8_t* d_dst, size_t dstride, int dw, int dh, hipStream_t st);
 // Batched forms (batch mode): the images of `items` frames in one launch; d_pairs = device table of
