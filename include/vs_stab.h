@@ -504,11 +504,12 @@ int vs_azc_sync(vs_azc* a);
  * plane, gray > 1; the crop rectangle as it is for the luma plane and halved (x/2, y/2, max(1, w/2), max(1, h/2)) for the
  * half-size interleaved chroma plane; each plane scaled to its share of 640 x 360 by the reference's scale matrix,
  * AutoZoomCrop.cpp:246-270).  d_out receives 640 x 360 (chroma 320 x 180 at out_uv_offset) or, on the fall-back paths, the
- * unchanged w x h surface: out_pitch >= max(w, 640), out_uv_offset >= max(h, 360) * out_pitch.  The call queues the mask
- * kernels and returns a ticket; the contour logic runs on the object's worker threads (it is host work in the reference too,
- * :141-147), which then queue the crop-and-scale.  vs_azc_result(ticket) waits for that frame's host part and tells what
- * came out; the pixels are complete after vs_azc_sync.  At most 32 frames in flight, eight worker threads (environment
- * VS_AZC_WORKERS: 1 .. 16), results of the last 1024 tickets kept. */
+ * unchanged w x h surface: out_pitch >= max(w, 640), out_uv_offset >= max(h, 360) * out_pitch.  The call hands the frame over
+ * and returns a ticket; eight consecutive frames of one geometry form a batch whose mask kernels are one launch each and
+ * whose bit masks reach the host with one copy; the contour logic runs on the object's worker threads (it is host work in the
+ * reference too, :141-147), a frame each, which then queue the crop-and-scale.  vs_azc_result(ticket) waits for that
+ * frame's host part and tells what came out, vs_azc_sync completes the pixels (both close an incomplete batch).  Four
+ * batches in flight, eight worker threads (environment VS_AZC_WORKERS: 1 .. 16), results of the last 1024 tickets kept. */
 int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset,
                           void* d_out, size_t out_pitch, size_t out_uv_offset, int64_t* ticket);
 int vs_azc_result(vs_azc* a, int64_t ticket, int* out_w, int* out_h, int32_t* info8);

@@ -94,7 +94,8 @@ for wl, wname in NAMES.items():
     # warp traffic: full launches only (those that write the most)
     fpass, wpass = passes["fetch"], passes["write"]
     # (round 4: luma and chroma tiles of the NV12 surfaces in one launch, warp_nv12_kernel; before: one launch per plane)
-    warp_k = ["warp_tab_kernel"] if wl == "c1" else (["warp_nv12_kernel"] if "warp_nv12_kernel" in fpass else ["warp_plane_kernel<1>", "warp_plane_kernel<2>"])
+    nv12_k = [k for k in fpass if k.startswith("warp_nv12_kernel<0")]       # (the BORDER_CONSTANT instance: the stabilizer's warp)
+    warp_k = ["warp_tab_kernel"] if wl == "c1" else (nv12_k if nv12_k else ["warp_plane_kernel<1>", "warp_plane_kernel<2>"])
     if all(k in fpass and k in wpass for k in warp_k):
         rd = wr = 0.0
         nl = 0

@@ -44,9 +44,12 @@ __device__ __forceinline__ unsigned content_bgr(uint32_t b, uint32_t g, uint32_t
 // A lane takes 4 pixels (12 bytes, three dword loads when the rows allow), a workgroup 1024 pixels of one row;
 // the 4-bit results go through LDS and 16 lanes pack them into the 16 words.
 template <int CN>
+// (several pictures per launch: blockIdx.z selects the picture - its source from `srcs`, its bit plane tfb words behind T)
 __global__ __launch_bounds__(256) void threshold_bits_kernel(const uint8_t* __restrict__ src, size_t stride, int w,
-                                                             int aligned, u64* __restrict__ T, int wpr) {
+                                                             int aligned, u64* __restrict__ T, int wpr,
+                                                             const uint8_t* const* __restrict__ srcs, size_t tfb) {
     __shared__ __attribute__((aligned(16))) uint8_t nib[256];
+    if (srcs) { src = srcs[blockIdx.z]; T += (size_t)blockIdx.z * tfb; }
     const int tid = threadIdx.x, x = (blockIdx.x * 256 + tid) * 4, y = blockIdx.y;
     const uint8_t* row = src + (size_t)y * stride;
     unsigned n = 0;
@@ -100,7 +103,8 @@ __device__ __forceinline__ u64 row_from(u64 v, int d, int lane) {     // value o
 // image, erosion ones (cv::morphologyEx border value).  The result goes out as a zero-framed BitFrame (host
 // side below) or, for vs_op_content_mask, as a plain bit plane that expand_bits_kernel turns into bytes.
 __global__ __launch_bounds__(64) void close5_bits_kernel(const u64* __restrict__ T, int wpr, int w, int h,
-                                                         u64* __restrict__ out, int opitch, int oframe) {
+                                                         u64* __restrict__ out, int opitch, int oframe, size_t tfb, size_t ofb) {
+    T += (size_t)blockIdx.z * tfb; out += (size_t)blockIdx.z * ofb;      // (words between the pictures of a launch)
     const int lane = threadIdx.x, k = blockIdx.x, y = blockIdx.y * MC_ROWS - 4 + lane;
     const bool row_in = y >= 0 && y < h;
     auto word_in = [&](int kk) { return kk >= 0 && kk < wpr; };
@@ -136,17 +140,21 @@ __global__ __launch_bounds__(256) void expand_bits_kernel(const u64* __restrict_
 
 // d_T: scratch of ceil(w/64)*h words.  The closed mask goes to d_out with row pitch opitch words, shifted by
 // oframe rows and words (1 for a BitFrame whose frame is already zero, 0 for a plain bit plane).
+// d_srcs (optional): a device table of `frames` source pointers, one geometry and pitch; the pictures' bit planes / results lie
+// tfb / ofb words apart.
 int launch_content_bits(const uint8_t* d_src, size_t stride, int w, int h, int cn, u64* d_T, u64* d_out, int opitch,
-                        int oframe, hipStream_t st) {
-    if (!d_src || !d_T || !d_out || w <= 0 || h <= 0 || (cn != 1 && cn != 3)) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
+                        int oframe, hipStream_t st, const uint8_t* const* d_srcs = nullptr, int frames = 1, size_t tfb = 0, size_t ofb = 0,
+                        int srcs_aligned = 0) {
+    if ((!d_src && !d_srcs) || !d_T || !d_out || w <= 0 || h <= 0 || (cn != 1 && cn != 3) || frames < 1) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
     if (h > 65535) { set_last_error("content_mask: image too tall"); return VS_ERR_INVALID_ARG; }
     const int wpr = (w + 63) / 64;
-    const int aligned = (((uintptr_t)d_src | stride) & 3) == 0;
-    dim3 g1((w + 1023) / 1024, h);
-    if (cn == 3) hipLaunchKernelGGL(threshold_bits_kernel<3>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr);
-    else hipLaunchKernelGGL(threshold_bits_kernel<1>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr);
-    dim3 g2(wpr, (h + MC_ROWS - 1) / MC_ROWS);
-    hipLaunchKernelGGL(close5_bits_kernel, g2, dim3(64), 0, st, d_T, wpr, w, h, d_out, opitch, oframe);
+    // (a table of sources: srcs_aligned = every one of them is 4-byte aligned)
+    const int aligned = d_srcs ? (srcs_aligned && (stride & 3) == 0) : ((((uintptr_t)d_src | stride) & 3) == 0);
+    dim3 g1((w + 1023) / 1024, h, frames);
+    if (cn == 3) hipLaunchKernelGGL(threshold_bits_kernel<3>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr, d_srcs, tfb);
+    else hipLaunchKernelGGL(threshold_bits_kernel<1>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr, d_srcs, tfb);
+    dim3 g2(wpr, (h + MC_ROWS - 1) / MC_ROWS, frames);
+    hipLaunchKernelGGL(close5_bits_kernel, g2, dim3(64), 0, st, d_T, wpr, w, h, d_out, opitch, oframe, tfb, ofb);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }
@@ -170,30 +178,33 @@ struct vs_azc {
     CropScratch scratch;
     int32_t info[8] = {0};
     // ---- asynchronous NV12 path (vs_azc_apply_nv12_dev) ----
-    // The mask kernels of a frame are queued by the call; the contour logic - host work in the reference as well
-    // (AutoZoomCrop.cpp:141-147 downloads the mask for cv::findContours) - runs on worker threads, NW frames at a time (frames do
-    // not depend on each other; 0.3 ms per 4K frame and thread: four threads were the limit of the stage at 12.8 k frames/s), and the worker then queues the crop-and-scale of both planes.  NS frames in flight.
-    static constexpr int NS = 32, NRES = 1024;    // NS: slots = frames in flight
+    // Eight consecutive frames form a batch: their mask kernels are ONE launch each (blockIdx.z = frame) and their bit masks come
+    // to page-locked memory with one copy (a launch costs the host 6 - 7 us on this runtime: per frame they were half of the
+    // chain's host time).  The contour logic - host work in the reference as well (AutoZoomCrop.cpp:141-147 downloads the mask for
+    // cv::findContours) - runs on worker threads, a frame each (frames do not depend on each other; 0.3 ms per 4K frame and
+    // thread), and the worker then queues the crop-and-scale of both planes.  NBS batches in flight.
+    static constexpr int ZB = 8, NBS = 4, NRES = 1024;
     int nw = 8;                          // worker threads (VS_AZC_WORKERS, 1 .. 16)
-    struct Slot {
-        uint8_t* d_mask = nullptr;
-        uint8_t* h_mask = nullptr;
-        u64* d_tbits = nullptr;
+    struct Frame { const uint8_t* src; uint8_t* dst; int w, h; size_t pitch, uv, opitch, ouv; long ticket; };
+    struct BatchSlot {
+        uint8_t* d_masks = nullptr;      // ZB BitFrames
+        uint8_t* h_masks = nullptr;      // page-locked
+        u64* d_tbits = nullptr;          // ZB thresholded bit planes, before the closing
+        const uint8_t** h_srcs = nullptr;    // page-locked table of the batch's luma planes
+        const uint8_t** d_srcs = nullptr;
         hipEvent_t ev = nullptr;
         int mw = 0, mh = 0;
-        bool busy = false;
-        long ticket = 0;
-        const uint8_t* src = nullptr;
-        uint8_t* dst = nullptr;
-        int w = 0, h = 0;
-        size_t pitch = 0, uv = 0, opitch = 0, ouv = 0;
-    } slot[NS];
+        int n = 0, left = 0;             // frames of the batch / of them not yet through their host part
+        Frame fr[ZB];
+    } bslot[NBS];
     struct Result { long ticket = -1; int out_w = 0, out_h = 0, rc = 0; int32_t info[8] = {0}; } results[NRES];
+    std::vector<Frame> pending;          // handed over, not yet a batch
+    long nbatches = 0;
     hipStream_t st_out = nullptr;
     std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
-    std::deque<int> jobs;
+    std::deque<std::pair<int, int>> jobs;    // (batch slot, frame of the batch)
     bool quit = false;
     long issued = 0, completed = 0;
 };
@@ -256,10 +267,12 @@ void vs_azc_destroy(vs_azc* a) {
         for (auto& t : a->workers) t.join();
     }
     if (a->st_out) { (void)hipStreamSynchronize(a->st_out); (void)hipStreamDestroy(a->st_out); }
-    for (auto& q : a->slot) {
-        if (q.d_mask) (void)hipFree(q.d_mask);
-        if (q.h_mask) (void)hipHostFree(q.h_mask);
+    for (auto& q : a->bslot) {
+        if (q.d_masks) (void)hipFree(q.d_masks);
+        if (q.h_masks) (void)hipHostFree(q.h_masks);
         if (q.d_tbits) (void)hipFree(q.d_tbits);
+        if (q.h_srcs) (void)hipHostFree((void*)q.h_srcs);
+        if (q.d_srcs) (void)hipFree((void*)q.d_srcs);
         if (q.ev) (void)hipEventDestroy(q.ev);
     }
     if (a->st) (void)hipStreamSynchronize(a->st);
@@ -280,11 +293,15 @@ int vs_azc_get_info(const vs_azc* a, int32_t* info8) {
     return VS_OK;
 }
 
+static int azc_flush_pending(vs_azc* a, std::unique_lock<std::mutex>& lk);
+
 int vs_azc_sync(vs_azc* a) {
     if (!a) return VS_ERR_INVALID_ARG;
     A_HIP(a, hipSetDevice(a->device));
     if (!a->workers.empty()) {          // asynchronous NV12 frames: their host parts first, then what the workers queued
         std::unique_lock<std::mutex> lk(a->mu);
+        const int frc = azc_flush_pending(a, lk);
+        if (frc != VS_OK) return frc;
         a->cv_done.wait(lk, [&] { return a->completed == a->issued; });
         lk.unlock();
         A_HIP(a, hipStreamSynchronize(a->st_out));
@@ -388,22 +405,24 @@ static void azc_worker(vs_azc* a) {
     (void)hipSetDevice(a->device);
     CropScratch scratch;
     for (;;) {
-        int si;
+        std::pair<int, int> job;
         {
             std::unique_lock<std::mutex> lk(a->mu);
             a->cv_job.wait(lk, [&] { return a->quit || !a->jobs.empty(); });
             if (a->jobs.empty()) return;
-            si = a->jobs.front();
+            job = a->jobs.front();
             a->jobs.pop_front();
         }
-        vs_azc::Slot& q = a->slot[si];
+        vs_azc::BatchSlot& b = a->bslot[job.first];
+        const vs_azc::Frame q = b.fr[job.second];
         vs_azc::Result res;
         res.ticket = q.ticket;
         int rc = VS_OK;
-        if (hipEventSynchronize(q.ev) != hipSuccess) rc = VS_ERR_HIP;
+        if (hipEventSynchronize(b.ev) != hipSuccess) rc = VS_ERR_HIP;
         if (rc == VS_OK) {
             BitFrame bf;
-            bf.w = q.w; bf.h = q.h; bf.pitch = BitFrame::pitch_for(q.w); bf.F = (const uint64_t*)q.h_mask;
+            bf.w = q.w; bf.h = q.h; bf.pitch = BitFrame::pitch_for(q.w);
+            bf.F = (const uint64_t*)(b.h_masks + (size_t)job.second * BitFrame::words_for(q.w, q.h) * 8);
             crop_from_mask(bf, scratch, res.info, nullptr);                                                // :146-228
             if (!res.info[7]) {                                                                            // :149-152, :238-249
                 res.out_w = q.w; res.out_h = q.h;
@@ -429,19 +448,62 @@ static void azc_worker(vs_azc* a) {
         {
             std::lock_guard<std::mutex> g(a->mu);
             a->results[res.ticket % vs_azc::NRES] = res;
-            q.busy = false;
+            b.left--;
             a->completed++;
         }
         a->cv_done.notify_all();
     }
 }
 
+// (a->mu held through lk) what has been handed over becomes a batch: mask kernels, one copy, a job per frame
+static int azc_flush_pending(vs_azc* a, std::unique_lock<std::mutex>& lk) {
+    if (a->pending.empty()) return VS_OK;
+    vs_azc::BatchSlot& b = a->bslot[a->nbatches % vs_azc::NBS];
+    a->cv_done.wait(lk, [&] { return b.left == 0; });
+    const int n = (int)a->pending.size();
+    const int w = a->pending[0].w, h = a->pending[0].h;
+    const size_t mb = BitFrame::words_for(w, h) * 8, tw = (size_t)((w + 63) / 64) * h;
+    if (b.mw != w || b.mh != h) {
+        if (b.d_masks) (void)hipFree(b.d_masks);
+        if (b.h_masks) (void)hipHostFree(b.h_masks);
+        if (b.d_tbits) (void)hipFree(b.d_tbits);
+        b.d_masks = b.h_masks = nullptr; b.d_tbits = nullptr; b.mw = b.mh = 0;
+        A_HIP(a, hipMalloc((void**)&b.d_masks, mb * vs_azc::ZB));
+        A_HIP(a, hipMalloc((void**)&b.d_tbits, tw * 8 * vs_azc::ZB));
+        A_HIP(a, hipHostMalloc((void**)&b.h_masks, mb * vs_azc::ZB, hipHostMallocDefault));
+        A_HIP(a, hipMemsetAsync(b.d_masks, 0, mb * vs_azc::ZB, a->st));          // the frames of the BitFrames; the kernel rewrites the insides
+        if (!b.ev) {
+            A_HIP(a, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+            A_HIP(a, hipHostMalloc((void**)&b.h_srcs, sizeof(void*) * vs_azc::ZB, hipHostMallocDefault));
+            A_HIP(a, hipMalloc((void**)&b.d_srcs, sizeof(void*) * vs_azc::ZB));
+        }
+        b.mw = w; b.mh = h;
+    }
+    int aligned = 1;
+    for (int i = 0; i < n; i++) {
+        b.fr[i] = a->pending[i];
+        b.h_srcs[i] = a->pending[i].src;
+        if ((uintptr_t)a->pending[i].src & 3) aligned = 0;
+    }
+    A_HIP(a, hipMemcpyAsync((void*)b.d_srcs, (const void*)b.h_srcs, sizeof(void*) * n, hipMemcpyHostToDevice, a->st));
+    A_TRY(a, launch_content_bits(nullptr, a->pending[0].pitch, w, h, 1, b.d_tbits, (u64*)b.d_masks, BitFrame::pitch_for(w), 1, a->st, b.d_srcs, n, tw,
+                                 mb / 8, aligned));                                                                              // :111-139 on the luma planes
+    A_HIP(a, hipMemcpyAsync(b.h_masks, b.d_masks, mb * n, hipMemcpyDeviceToHost, a->st));                                          // :142-143
+    A_HIP(a, hipEventRecord(b.ev, a->st));
+    b.n = n; b.left = n;
+    for (int i = 0; i < n; i++) a->jobs.emplace_back((int)(a->nbatches % vs_azc::NBS), i);
+    a->nbatches++;
+    a->pending.clear();
+    a->cv_job.notify_all();
+    return VS_OK;
+}
+
 // autoZoomCrop for an NV12 surface in HBM, ASYNCHRONOUS.  d_out receives the result - 640 x 360 (luma rows of out_pitch bytes,
 // the 320 x 180 interleaved chroma plane out_uv_offset bytes behind) or, on the reference's fall-back paths, the unchanged
 // w x h surface - so out_pitch >= max(w, 640) and out_uv_offset >= max(h, 360) * out_pitch.  The call returns at once with a
-// ticket; vs_azc_result(ticket) tells what came out (it waits for that frame's host part), the pixels are complete after
-// vs_azc_sync.  Surface and result buffer must stay untouched until then; at most 16 frames are in flight (the call waits
-// for the oldest), results of the last 1024 tickets are kept.
+// ticket; eight consecutive frames of one geometry form a batch (vs_azc_sync and vs_azc_result close an incomplete one).
+// vs_azc_result(ticket) tells what came out (it waits for that frame's host part), the pixels are complete after vs_azc_sync.
+// Surface and result buffer must stay untouched until then; results of the last 1024 tickets are kept.
 int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset, void* d_out, size_t out_pitch,
                           size_t out_uv_offset, int64_t* ticket) {
     if (!a || !d_surface || !d_out || w < 2 || h < 2 || (w & 1) || (h & 1) || pitch < (size_t)w || out_pitch < (size_t)std::max(w, 640) ||
@@ -460,38 +522,15 @@ int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t
             return VS_ERR_HIP;
         }
     }
-    vs_azc::Slot& q = a->slot[a->issued % vs_azc::NS];
-    {
-        std::unique_lock<std::mutex> lk(a->mu);
-        a->cv_done.wait(lk, [&] { return !q.busy; });
+    std::unique_lock<std::mutex> lk(a->mu);
+    if (!a->pending.empty() && (a->pending[0].w != w || a->pending[0].h != h || a->pending[0].pitch != pitch)) {
+        const int rc = azc_flush_pending(a, lk);
+        if (rc != VS_OK) return rc;
     }
-    const size_t mb = BitFrame::words_for(w, h) * 8;
-    if (q.mw != w || q.mh != h) {
-        if (q.d_mask) (void)hipFree(q.d_mask);
-        if (q.h_mask) (void)hipHostFree(q.h_mask);
-        if (q.d_tbits) (void)hipFree(q.d_tbits);
-        q.d_mask = q.h_mask = nullptr; q.d_tbits = nullptr; q.mw = q.mh = 0;
-        A_HIP(a, hipMalloc((void**)&q.d_mask, mb));
-        A_HIP(a, hipMalloc((void**)&q.d_tbits, (size_t)((w + 63) / 64) * h * 8));
-        A_HIP(a, hipHostMalloc((void**)&q.h_mask, mb, hipHostMallocDefault));
-        A_HIP(a, hipMemsetAsync(q.d_mask, 0, mb, a->st));          // the frame of the BitFrame; the kernel rewrites the inside
-        if (!q.ev) A_HIP(a, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
-        q.mw = w; q.mh = h;
-    }
-    q.src = (const uint8_t*)d_surface; q.dst = (uint8_t*)d_out; q.w = w; q.h = h;
-    q.pitch = pitch; q.uv = uv_offset; q.opitch = out_pitch; q.ouv = out_uv_offset;
-    A_TRY(a, launch_content_bits(q.src, pitch, w, h, 1, q.d_tbits, (u64*)q.d_mask, BitFrame::pitch_for(w), 1, a->st));      // :111-139 on the luma plane
-    A_HIP(a, hipMemcpyAsync(q.h_mask, q.d_mask, mb, hipMemcpyDeviceToHost, a->st));                                          // :142-143
-    A_HIP(a, hipEventRecord(q.ev, a->st));
-    {
-        std::lock_guard<std::mutex> g(a->mu);
-        q.busy = true;
-        q.ticket = a->issued;
-        a->jobs.push_back((int)(a->issued % vs_azc::NS));
-        if (ticket) *ticket = a->issued;
-        a->issued++;
-    }
-    a->cv_job.notify_one();
+    a->pending.push_back(vs_azc::Frame{(const uint8_t*)d_surface, (uint8_t*)d_out, w, h, pitch, uv_offset, out_pitch, out_uv_offset, a->issued});
+    if (ticket) *ticket = a->issued;
+    a->issued++;
+    if ((int)a->pending.size() >= vs_azc::ZB) return azc_flush_pending(a, lk);
     return VS_OK;
 }
 
@@ -500,6 +539,10 @@ int vs_azc_result(vs_azc* a, int64_t ticket, int* out_w, int* out_h, int32_t* in
     if (!a || ticket < 0) return VS_ERR_INVALID_ARG;
     std::unique_lock<std::mutex> lk(a->mu);
     if (ticket >= a->issued || ticket + vs_azc::NRES <= a->issued) { a->err = "auto zoom/crop: no such ticket (results of the last 1024 frames are kept)"; set_last_error(a->err); return VS_ERR_INVALID_ARG; }
+    if (!a->pending.empty() && ticket >= a->pending[0].ticket) {       // (still waiting for its batch to fill)
+        const int frc = azc_flush_pending(a, lk);
+        if (frc != VS_OK) return frc;
+    }
     a->cv_done.wait(lk, [&] { return a->results[ticket % vs_azc::NRES].ticket == ticket; });
     const vs_azc::Result& r = a->results[ticket % vs_azc::NRES];
     if (out_w) *out_w = r.out_w;
