@@ -388,7 +388,12 @@ def cpp_class_rate(device):
         r = subprocess.run([exe, str(device)], capture_output=True, text=True, timeout=300)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode == 0 and line:
-            return json.loads(line[-1])
+            out = json.loads(line[-1])
+            r2 = subprocess.run([exe, str(device), "checker"], capture_output=True, text=True, timeout=300)
+            line2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+            if r2.returncode == 0 and line2:
+                out["busy_picture"] = json.loads(line2[-1])
+            return out
         return {"note": "wrapper_time failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
     except Exception as e:       # noqa: BLE001 - a missing extra must not lose the headline line
         return {"note": "wrapper_time: %r" % (e,)}
@@ -438,7 +443,7 @@ def config2(vs, comm, device, args, full=True):
     if not full:
         return out
     # (b) configs[2] as ONE chain on the decoder surfaces: roll correction -> stabilize -> auto zoom/crop (the reference's order
-    # of operators, examples/vs.cpp:553-562), each stage through its asynchronous device entry point, chunks of 64 surfaces:
+    # of operators, examples/vs.cpp:553-562), each stage through its asynchronous device entry point, chunks of 128 surfaces:
     # while the roll stage works on chunk c, the stabilizer takes chunk c-1 and the zoom stage the stabilized surfaces of chunk
     # c-2; one host wait per stage and chunk.
     out["chain_nv12"] = config2_chain(vs, device, p, W, H)
@@ -446,7 +451,7 @@ def config2(vs, comm, device, args, full=True):
 
 
 def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
-    CH = int(os.environ.get("VS_BENCH_CHAIN_CHUNK", "64"))
+    CH = int(os.environ.get("VS_BENCH_CHAIN_CHUNK", "128"))
     NF = int(os.environ.get("VS_BENCH_4K_CLIP", "64"))
     clip = synth.make_clip_dev(vs, synth.SEED_CONFIG3, W, H, NF, nv12=True)
     sb = W * H * 3 // 2
@@ -516,8 +521,8 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
            "last_result": [ow, oh], "last_crop": [int(v) for v in info[2:6]], "chunk": CH,
            "stage_thread_ms_per_chunk": {k: round(v / chunks_timed * 1e3, 3) for k, v in busy.items()},
            "what": "vs_roll_correct_nv12_dev -> vs_stab_push_dev (batch 64, zero-copy) -> vs_azc_apply_nv12_dev on 3840x2160 NV12 surfaces "
-                   "resident in HBM, chunks of 64, one host thread per stage, the three stages overlapped on the device, one host wait per stage and chunk; every "
-                   "surface goes through all three stages (640x360 NV12 out)"}
+                   "resident in HBM, chunks of %d, one host thread per stage, the three stages overlapped on the device, one host wait per stage and chunk; every "
+                   "surface goes through all three stages (640x360 NV12 out)" % CH}
     st.close()
     rc.close()
     az.close()

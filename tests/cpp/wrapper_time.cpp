@@ -5,6 +5,8 @@
 //   host_pipeline     Parameters::hostPipeline = true
 //   unpinned          Parameters::pinHostFrames = false (plain cv::Mat allocations: round 2's behaviour)
 //   keeps_results     default, but the application keeps every result alive for 8 frames (the ring cannot recycle)
+// wrapper_time <device> checker: the same two calls (default, host_pipeline) on a 24-pixel checkerboard - tens of thousands of corner
+// candidates per analysis image: the detector's worst case (the selection consumes its candidate list in chunks since round 4).
 // Prints one JSON line.  The capture side is three Mats holding consecutive synthetic frames, taken in turn (a decoder's
 // buffer pool); only the stabilize() calls are timed.
 #include <chrono>
@@ -42,6 +44,21 @@ static cv::Mat make_frame(int w, int h, int k) {
     return f;
 }
 
+// A moving checkerboard of 24-pixel squares with a little texture: every square corner is a corner candidate.
+static cv::Mat make_checker(int w, int h, int k) {
+    cv::Mat f(h, w, CV_8UC3);
+    for (int y = 0; y < h; y++) {
+        unsigned char *p = f.ptr(y);
+        for (int x = 0; x < w; x++) {
+            const int u = x + 2 * k, v = y + (k % 3);
+            int c = (((u / 24) + (v / 24)) & 1) ? 200 : 60;
+            c += (int)((((unsigned)u * 73856093u) ^ ((unsigned)v * 19349663u)) >> 7 & 7) - 3;
+            p[3 * x] = (unsigned char)c; p[3 * x + 1] = (unsigned char)(c + 10); p[3 * x + 2] = (unsigned char)(c - 10);
+        }
+    }
+    return f;
+}
+
 static double run(const vs::Stabilizer::Parameters &p, std::vector<cv::Mat> &cap, int warm, int timed, int keep) {
     vs::Stabilizer stab(p);
     std::deque<cv::Mat> kept;
@@ -62,10 +79,20 @@ int main(int argc, char **argv) {
     if (argc > 1) setenv("VS_STAB_DEVICE", argv[1], 1);
     const int W = 1920, H = 1080;
     std::vector<cv::Mat> cap;
-    for (int k = 0; k < 3; k++) cap.push_back(make_frame(W, H, k));
+    const bool checker = argc > 2 && std::string(argv[2]) == "checker";
+    for (int k = 0; k < 3; k++) cap.push_back(checker ? make_checker(W, H, k) : make_frame(W, H, k));
     vs::Stabilizer::Parameters p;                    // the reference's defaults (smoothingRadius 30 ...)
     p.logging = false;
     const int warm = 80, timed = 400;
+    if (checker) {
+        const double sync = run(p, cap, warm, timed, 0);
+        vs::Stabilizer::Parameters q = p;
+        q.hostPipeline = true;
+        const double piped = run(q, cap, warm, timed, 0);
+        std::printf("{\"what\": \"the same calls on a 24-pixel checkerboard (tens of thousands of corner candidates per analysis image)\", "
+                    "\"default_synchronous\": %.1f, \"host_pipeline\": %.1f, \"unit\": \"frames/s\"}\n", sync, piped);
+        return 0;
+    }
     const double sync = run(p, cap, warm, timed, 0);
     vs::Stabilizer::Parameters q = p;
     q.hostPipeline = true;

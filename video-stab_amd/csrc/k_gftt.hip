@@ -289,12 +289,13 @@ __device__ __forceinline__ void select_corners(const SelArgs& a) {
 
     // The greedy pass below walks the candidates from the strongest on and stops at max_corners accepted ones: how deep it gets
     // depends on the picture, and sorting ALL candidates first made the launch twice as long on pictures with twice the local
-    // maxima (58 -> 198 us per batch, round 3).  The list is therefore consumed in chunks of growing size - the strongest 448
-    // (or a few more) first, then 1792, then 4096 at a time - each chunk = every key in [lo, upper), chosen by a radix search on the key
+    // maxima (58 -> 198 us per batch, round 3).  The list is therefore consumed in chunks - the strongest 1400 (or a few more)
+    // first, then 4096 at a time - each chunk = every key in [lo, upper), chosen by a radix search on the key
     // bytes (one pass over the candidates per byte, usually three), sorted, and walked; the walk ends where the serial loop
     // would (list and order are unchanged: a chunk boundary is a position in the sorted order, nothing else).
-    int want = 448;              // (a chunk of up to 512 keys is sorted with two keys per thread; 200 corners at minDistance 15
-                                 //  are typically reached 320 - 350 candidates deep on the bench clips)
+    int want = 1400;             // (up to 2100 candidates are one chunk - sorted with eight keys per thread, as before round 4: the bench
+                                 //  clips hold 750 - 1300 per detection; first chunks of 448 / 768 cost the headline clip a second chunk:
+                                 //  69.8 / 64.2 us per launch against 63.0, gpurun_out/r04_t)
     while (true) {
         // ---- choose the next chunk: at least `want` (at most SORT_CAP) of the largest keys below s_upper
         const unsigned long long upper = s_upper;
@@ -479,7 +480,7 @@ __device__ __forceinline__ void select_corners(const SelArgs& a) {
         }
         __syncthreads();
         if (s_done) break;
-        want = want < 1792 ? 1792 : SORT_CAP / 2;
+        want = SORT_CAP / 2;
     }
     __syncthreads();
     if (tid == 0) {
