@@ -478,25 +478,25 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
                 busy[name] += time.perf_counter() - t
         return g
 
-    def roll_stage(c):
-        for i in range(CH):                                                    # roll: chunk c
-            rc.correct_nv12_dev(clip.ptr + ((c * CH + i) % NF) * sb, W, H, W, d_roll[c % R_RING].ptr + i * sb, W)
+    def roll_stage(c):                                                         # roll: chunk c
+        rc.correct_nv12_dev_n([clip.ptr + ((c * CH + i) % NF) * sb for i in range(CH)], W, H, W,
+                              [d_roll[c % R_RING].ptr + i * sb for i in range(CH)], W)
         rc.sync()
 
     def stab_stage(c):
         if c < 1:
-            return
-        k = 0                                                                  # stabilize: chunk c-1 (its rotations are complete)
-        for i in range(CH):
-            k += st.push_dev(d_roll[(c - 1) % R_RING].ptr + i * sb, W, H, W, capi.FMT_NV12, d_stab[(c - 1) % S_RING].ptr + k * sb, W)
-        produced[c - 1] = k
+            return                                                             # stabilize: chunk c-1 (its rotations are complete)
+        produced[c - 1] = st.push_dev_n([d_roll[(c - 1) % R_RING].ptr + i * sb for i in range(CH)], W, H, W, capi.FMT_NV12,
+                                        [d_stab[(c - 1) % S_RING].ptr + j * sb for j in range(CH)], W)
         st.sync()
 
     def zoom_stage(c):
         if c < 2:
             return
-        for j in range(produced[c - 2]):                                       # zoom/crop: what chunk c-2 yielded (complete)
-            tickets.append(az.apply_nv12_dev(d_stab[(c - 2) % S_RING].ptr + j * sb, W, H, W, d_zoom[c % Z_RING].ptr + j * sb, W, W * H))
+        k = produced[c - 2]                                                    # zoom/crop: what chunk c-2 yielded (complete)
+        if k:
+            tickets.extend(az.apply_nv12_dev_n([d_stab[(c - 2) % S_RING].ptr + j * sb for j in range(k)], W, H, W,
+                                               [d_zoom[c % Z_RING].ptr + j * sb for j in range(k)], W, W * H))
         az.sync()
 
     def step(c):

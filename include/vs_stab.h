@@ -225,6 +225,9 @@ int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced);
  * `produced` is decided on the host from the frame count alone (E0). */
 int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride,
                      int fmt, void* d_out, size_t out_stride, int* produced);
+/* n consecutive pushes of one geometry in one call: the j-th result that becomes due goes to d_outs[j]; *produced = how many did */
+int vs_stab_push_dev_n(vs_stab* s, const void* const* d_frames, int n, int w, int h, size_t stride, int fmt,
+                       void* const* d_outs, size_t out_stride, int* produced);
 int vs_stab_flush_dev(vs_stab* s, void* d_out, size_t out_stride, int* produced);
 int vs_stab_sync(vs_stab* s);
 /* size of the frames stabilize() returns for w x h input (crop/border rules,
@@ -466,6 +469,9 @@ int vs_roll_sync(vs_roll* r);
  * vs_roll_get_state (after vs_roll_sync) reports the last frame. */
 int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset,
                              void* d_out, size_t out_pitch, size_t out_uv_offset);
+/* n surfaces of one layout, in call order (n calls of the above in one) */
+int vs_roll_correct_nv12_dev_n(vs_roll* r, const void* const* d_surfaces, void* const* d_outs, int n, int w, int h,
+                               size_t pitch, size_t uv_offset, size_t out_pitch, size_t out_uv_offset);
 /* smoothed angle (sSmoothedAngle), the angle detected on the last frame, lines found / used */
 int vs_roll_get_state(const vs_roll* r, double* smoothed_deg, double* detected_deg,
                       int* n_lines, int* n_used);
@@ -512,6 +518,8 @@ int vs_azc_sync(vs_azc* a);
  * batches in flight, eight worker threads (environment VS_AZC_WORKERS: 1 .. 16), results of the last 1024 tickets kept. */
 int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset,
                           void* d_out, size_t out_pitch, size_t out_uv_offset, int64_t* ticket);
+int vs_azc_apply_nv12_dev_n(vs_azc* a, const void* const* d_surfaces, void* const* d_outs, int n, int w, int h,
+                            size_t pitch, size_t uv_offset, size_t out_pitch, size_t out_uv_offset, int64_t* tickets);
 int vs_azc_result(vs_azc* a, int64_t ticket, int* out_w, int* out_h, int32_t* info8);
 /* info8 = {n_contours, contour_points, crop_x, crop_y, crop_w, crop_h, iterations, cropped} */
 int vs_azc_get_info(const vs_azc* a, int32_t* info8);

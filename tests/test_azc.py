@@ -336,7 +336,9 @@ def test_auto_zoom_crop_nv12_async_matches_oracle(gpu, oracle):
     d_in = DevBuf.from_array(gpu, np.stack(surfs))
     d_out = DevBuf(gpu, ob * len(surfs))
     az = gpu.auto_zoom_crop()
-    tickets = [az.apply_nv12_dev(d_in.ptr + i * sb, w, h, w, d_out.ptr + i * ob, op, op * oh_max) for i in range(len(surfs))]
+    # (the first five one by one, the rest through the array form: one trip through the binding)
+    tickets = [az.apply_nv12_dev(d_in.ptr + i * sb, w, h, w, d_out.ptr + i * ob, op, op * oh_max) for i in range(5)]
+    tickets += az.apply_nv12_dev_n([d_in.ptr + i * sb for i in range(5, len(surfs))], w, h, w, [d_out.ptr + i * ob for i in range(5, len(surfs))], op, op * oh_max)
     assert tickets == list(range(len(surfs)))
     az.sync()
     got = d_out.download((len(surfs), oh_max * 3 // 2, op), np.uint8)

@@ -1347,3 +1347,32 @@ def test_config3_chain_4k_nv12_roll_stabilize_zoomcrop_against_oracle(gpu, oracl
         o.close()
     for b in (d_in, d_roll, d_stab, d_zoom):
         b.free()
+
+
+def test_push_dev_n_equals_the_pushes(gpu):
+    """vs_stab_push_dev_n: n consecutive pushes with one trip through the binding; the j-th result that becomes due lands in
+    d_outs[j]."""
+    clip = synth.make_clip(synth.SEED_CONFIG1 + 5, 320, 240, 12)
+    fb = clip[0].nbytes
+    n = 40
+    order = [i % 12 if (i // 12) % 2 == 0 else 11 - i % 12 for i in range(n)]
+    d_in = capi.DevBuf(gpu, fb * 12)
+    for i, f in enumerate(clip):
+        d_in.upload(f, i * fb)
+    res = []
+    for form in (0, 1):
+        s = gpu.stabilizer(gpu.params(smoothing_radius=6))
+        s.set_batch(8)
+        s.set_zero_copy(True)
+        d_out = capi.DevBuf(gpu, fb * (n + 1))
+        if form == 0:
+            k = 0
+            for i in order:
+                k += s.push_dev(d_in.ptr + i * fb, 320, 240, 960, capi.FMT_BGR8, d_out.ptr + k * fb, 960)
+        else:
+            k = s.push_dev_n([d_in.ptr + i * fb for i in order[:17]], 320, 240, 960, capi.FMT_BGR8, [d_out.ptr + j * fb for j in range(17)], 960)
+            k += s.push_dev_n([d_in.ptr + i * fb for i in order[17:]], 320, 240, 960, capi.FMT_BGR8, [d_out.ptr + (k + j) * fb for j in range(n - 17)], 960)
+        s.sync()
+        res.append((k, d_out.download((k, 240, 320, 3), np.uint8)))
+        s.close()
+    assert res[0][0] == res[1][0] == n - 5 and np.array_equal(res[0][1], res[1][1])

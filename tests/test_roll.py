@@ -332,3 +332,30 @@ def test_roll_correct_nv12_async_when_the_edge_growth_needs_many_passes(gpu, ora
     for i in range(6):
         assert np.array_equal(got[i], ro.correct_nv12(surf, w, h)), i
     assert ro.state() == rg.state() and ro.state()[2] > 4
+
+
+@pytest.mark.gpu
+def test_roll_correct_nv12_array_form_equals_the_calls(gpu, oracle):
+    """vs_roll_correct_nv12_dev_n: n surfaces with one trip through the binding = n calls."""
+    from vsamd.capi import DevBuf
+    from vsamd import synth
+    w, h, n = 640, 360, 19
+    surfs = np.stack([synth.bgr_to_nv12(roll_scene.horizon_frame(w, h, 40 + i, seed=i, offset=i % 5 - 2)) for i in range(n)])
+    sb = surfs[0].nbytes
+    d_in = DevBuf.from_array(gpu, surfs)
+    outs = []
+    for form in (0, 1):
+        rg = gpu.roll_correction()
+        d_out = DevBuf(gpu, surfs.nbytes)
+        if form == 0:
+            for i in range(n):
+                rg.correct_nv12_dev(d_in.ptr + i * sb, w, h, w, d_out.ptr + i * sb, w)
+        else:
+            rg.correct_nv12_dev_n([d_in.ptr + i * sb for i in range(n)], w, h, w, [d_out.ptr + i * sb for i in range(n)], w)
+        rg.sync()
+        outs.append((d_out.download(surfs.shape, np.uint8), rg.state()))
+        rg.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    ro = oracle.roll_correction()
+    for i in range(n):
+        assert np.array_equal(outs[1][0][i], ro.correct_nv12(surfs[i], w, h)), i

@@ -534,6 +534,17 @@ int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t
     return VS_OK;
 }
 
+// n surfaces of one layout in call order; tickets (optional) receives n tickets
+int vs_azc_apply_nv12_dev_n(vs_azc* a, const void* const* d_surfaces, void* const* d_outs, int n, int w, int h, size_t pitch, size_t uv_offset,
+                            size_t out_pitch, size_t out_uv_offset, int64_t* tickets) {
+    if (!a || !d_surfaces || !d_outs || n < 0) return VS_ERR_INVALID_ARG;
+    for (int i = 0; i < n; i++) {
+        const int rc = vs_azc_apply_nv12_dev(a, d_surfaces[i], w, h, pitch, uv_offset, d_outs[i], out_pitch, out_uv_offset, tickets ? tickets + i : nullptr);
+        if (rc != VS_OK) return rc;
+    }
+    return VS_OK;
+}
+
 // What ticket's frame became: waits for its host part (not for the pixels: vs_azc_sync).
 int vs_azc_result(vs_azc* a, int64_t ticket, int* out_w, int* out_h, int32_t* info8) {
     if (!a || ticket < 0) return VS_ERR_INVALID_ARG;

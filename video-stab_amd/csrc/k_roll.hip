@@ -982,6 +982,17 @@ int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, si
     return VS_OK;
 }
 
+// n surfaces of one layout in call order (what n calls of vs_roll_correct_nv12_dev do, without n trips through a binding)
+int vs_roll_correct_nv12_dev_n(vs_roll* r, const void* const* d_surfaces, void* const* d_outs, int n, int w, int h, size_t pitch, size_t uv_offset,
+                               size_t out_pitch, size_t out_uv_offset) {
+    if (!r || !d_surfaces || !d_outs || n < 0) return VS_ERR_INVALID_ARG;
+    for (int i = 0; i < n; i++) {
+        const int rc = vs_roll_correct_nv12_dev(r, d_surfaces[i], w, h, pitch, uv_offset, d_outs[i], out_pitch, out_uv_offset);
+        if (rc != VS_OK) return rc;
+    }
+    return VS_OK;
+}
+
 int vs_roll_sync(vs_roll* r) {
     if (!r) return VS_ERR_INVALID_ARG;
     R_HIP(r, hipSetDevice(r->device));

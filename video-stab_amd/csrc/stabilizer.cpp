@@ -1128,6 +1128,22 @@ int vs_stab_push_dev(vs_stab* s, const void* d_data, int w, int h, size_t stride
     return push_common(s, slot, nullptr, (uint8_t*)d_out, out_stride, produced, true);
 }
 
+// n consecutive pushes of one geometry: result j of them (in the order they become due) goes to d_outs[j]; *produced = how many
+// became due.  What n calls of vs_stab_push_dev do, without n trips through a binding.
+int vs_stab_push_dev_n(vs_stab* s, const void* const* d_frames, int n, int w, int h, size_t stride, int fmt, void* const* d_outs, size_t out_stride,
+                       int* produced) {
+    if (!s || !d_frames || !d_outs || !produced || n < 0) return VS_ERR_INVALID_ARG;
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        int now = 0;
+        const int rc = vs_stab_push_dev(s, d_frames[i], w, h, stride, fmt, d_outs[k], out_stride, &now);
+        if (rc != VS_OK) { *produced = k; return rc; }
+        k += now;
+    }
+    *produced = k;
+    return VS_OK;
+}
+
 static int flush_dev_impl(vs_stab* s, void* d_out, size_t out_stride, int* produced, bool may_defer_flush) {
     if (!s || !produced) return VS_ERR_INVALID_ARG;
     *produced = 0;

@@ -256,6 +256,10 @@ class VsLib:
         L.vs_roll_correct.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
         L.vs_roll_correct_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
         L.vs_roll_correct_nv12_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t]
+        L.vs_roll_correct_nv12_dev_n.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+        L.vs_azc_apply_nv12_dev_n.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                              C.POINTER(C.c_int64)]
+        L.vs_stab_push_dev_n.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.c_size_t, i32p]
         L.vs_azc_apply_nv12_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_int64)]
         L.vs_azc_result.argtypes = [vp, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), i32p]
         L.vs_roll_sync.argtypes = [vp]
@@ -588,6 +592,15 @@ class AutoZoomCrop:
         self._check(self.lib.vs_azc_apply_nv12_dev(self.h, d_in, w, h, pitch, uv_offset, d_out, out_pitch, out_uv_offset, C.byref(t)))
         return t.value
 
+    def apply_nv12_dev_n(self, d_ins, w, h, pitch, d_outs, out_pitch, out_uv_offset, uv_offset=0):
+        """n surfaces in call order, one trip through the binding; returns the tickets."""
+        n = len(d_ins)
+        a = (C.c_void_p * n)(*d_ins)
+        b = (C.c_void_p * n)(*d_outs)
+        t = (C.c_int64 * n)()
+        self._check(self.lib.vs_azc_apply_nv12_dev_n(self.h, a, b, n, w, h, pitch, uv_offset, out_pitch, out_uv_offset, t))
+        return list(t)
+
     def result(self, ticket):
         ow, oh = C.c_int(), C.c_int()
         info = np.zeros(8, np.int32)
@@ -811,6 +824,13 @@ class RollCorrection:
     def correct_dev(self, d_in, w, h, stride, d_out, out_stride):
         self._check(self.lib.vs_roll_correct_dev(self.h, d_in, w, h, stride, d_out, out_stride))
 
+    def correct_nv12_dev_n(self, d_ins, w, h, pitch, d_outs, out_pitch, uv_offset=0, out_uv_offset=0):
+        """n surfaces in call order (lists of device pointers), one trip through the binding."""
+        n = len(d_ins)
+        a = (C.c_void_p * n)(*d_ins)
+        b = (C.c_void_p * n)(*d_outs)
+        self._check(self.lib.vs_roll_correct_nv12_dev_n(self.h, a, b, n, w, h, pitch, uv_offset, out_pitch, out_uv_offset))
+
     def correct_nv12_dev(self, d_in, w, h, pitch, d_out, out_pitch, uv_offset=0, out_uv_offset=0):
         """Asynchronous (vs_roll_correct_nv12_dev): the result is complete after sync()."""
         self._check(self.lib.vs_roll_correct_nv12_dev(self.h, d_in, w, h, pitch, uv_offset, d_out, out_pitch, out_uv_offset))
@@ -886,6 +906,15 @@ class Stabilizer:
         produced = C.c_int32(0)
         self.vs.check(self.lib.vs_stab_push_dev(self.h, d_in, w, h, stride, fmt, d_out, out_stride,
                                                 C.byref(produced)), self.h)
+        return produced.value
+
+    def push_dev_n(self, d_ins, w, h, stride, fmt, d_outs, out_stride):
+        """len(d_ins) consecutive pushes in one call; the j-th result that becomes due goes to d_outs[j].  Returns how many did."""
+        n = len(d_ins)
+        a = (C.c_void_p * n)(*d_ins)
+        b = (C.c_void_p * n)(*d_outs)
+        produced = C.c_int32(0)
+        self.vs.check(self.lib.vs_stab_push_dev_n(self.h, a, n, w, h, stride, fmt, b, out_stride, C.byref(produced)), self.h)
         return produced.value
 
     def flush_dev(self, d_out, out_stride):
