@@ -1,0 +1,17 @@
+"""The configs[2] chain alone (bench.py's config2_chain, without the rest of the bench line):
+python scratch/chain_only.py [timed chunks] [warm chunks]"""
+import json, os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import bench
+from vsamd import capi
+vs = capi.load(os.environ.get("VS_LIB"))
+p = bench.make_params(vs, max_corners=400)
+import resource, time
+u0, w0 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+r = bench.config2_chain(vs, 0, p, 3840, 2160, int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+u1, w1 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+r["whole_run"] = {"wall_s": round(w1 - w0, 2), "user_s": round(u1.ru_utime - u0.ru_utime, 2), "sys_s": round(u1.ru_stime - u0.ru_stime, 2),
+                  "cores_busy": round((u1.ru_utime - u0.ru_utime + u1.ru_stime - u0.ru_stime) / (w1 - w0), 2)}
+r.pop("what")
+print(json.dumps(r))

@@ -359,3 +359,23 @@ def test_roll_correct_nv12_array_form_equals_the_calls(gpu, oracle):
     ro = oracle.roll_correction()
     for i in range(n):
         assert np.array_equal(outs[1][0][i], ro.correct_nv12(surfs[i], w, h)), i
+
+
+@pytest.mark.gpu
+def test_roll_correct_nv12_async_full_size_analysis(gpu, oracle):
+    """scale_factor 1 at 1920 x 1080: the batched line search on an analysis image of 30 words x 18 hysteresis bands per frame
+    (two workgroups side by side per band), nine frames = a batch of eight and one of one."""
+    from vsamd.capi import DevBuf
+    from vsamd import synth
+    w, h, n = 1920, 1080, 9
+    kw = dict(scale_factor=1.0, hough_threshold=300)
+    ro, rg = oracle.roll_correction(oracle.roll_params(**kw)), gpu.roll_correction(gpu.roll_params(**kw))
+    surfs = np.stack([synth.bgr_to_nv12(roll_scene.horizon_frame(w, h, 30 + 2 * i, seed=i, offset=i - 4)) for i in range(n)])
+    d_in, d_out = DevBuf.from_array(gpu, surfs), DevBuf(gpu, surfs.nbytes)
+    sb = surfs[0].nbytes
+    rg.correct_nv12_dev_n([d_in.ptr + i * sb for i in range(n)], w, h, w, [d_out.ptr + i * sb for i in range(n)], w)
+    rg.sync()
+    got = d_out.download(surfs.shape, np.uint8)
+    for i in range(n):
+        assert np.array_equal(got[i], ro.correct_nv12(surfs[i], w, h)), i
+    assert ro.state() == rg.state() and ro.state()[0] != 0.0

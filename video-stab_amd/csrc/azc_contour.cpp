@@ -92,46 +92,55 @@ static int trace_largest(const BitFrame& bf, CropScratch& S, std::vector<Box>* b
     };
 
     const int wpr = P - 2;
+    S.begins.assign((size_t)wpr + 4, 0);           // (+ 4: the scan below looks at four words at a time)
+    uint64_t* B = S.begins.data();
     for (int y = 0; y < h; y++) {
         const size_t r = (size_t)(y + 1) * P + 1;
+        // The mask pixels with background to their west, for the whole row first: one streaming pass over the mask words without
+        // dependencies between them (the compiler vectorises it), and most rows of a dark picture end here.
+        uint64_t any = 0;
+        {
+            const uint64_t* Fr = F + r;
+            for (int k = 0; k < wpr; k++) { B[k] = Fr[k] & ~((Fr[k] << 1) | (Fr[k - 1] >> 63)); any |= B[k]; }
+        }
+        if (!any) continue;
         // kind of the last mark on this row before the scan position (0 none, 1 ML, 2 MR), brought up to date only
         // when a candidate asks for it: most rows have none, and then the mark planes are not read at all
         int last_mark = 0, marks_upto = 0;           // words [0, marks_upto) are accounted for in last_mark
-        uint64_t west = 0;                       // the pixel left of the word (bit 0)
-        for (int k = 0; k < wpr; k++) {
-            const uint64_t f = F[r + k];
-            if (f == 0) { west = 0; continue; }          // no pixels, hence no marks
-            const uint64_t begins = f & ~((f << 1) | west);    // mask pixels with background to their west
-            west = f >> 63;
-            if (begins == 0) continue;
-            uint64_t cand = begins & ~(ML[r + k] | MR[r + k]);
-            while (cand) {
-                for (; marks_upto < k; marks_upto++) {
-                    const uint64_t ml = ML[r + marks_upto], mr = MR[r + marks_upto];
-                    if (ml | mr) last_mark = ml > mr ? 1 : 2;     // the higher bit is the later pixel
-                }
-                const int b = __builtin_ctzll(cand);
-                const uint64_t below = (1ull << b) - 1;
-                const uint64_t ml = ML[r + k] & below, mr = MR[r + k] & below;
-                int kind = last_mark;
-                if (ml | mr) kind = ml > mr ? 1 : 2;
-                if (kind != 1) {
-                    ++n_contours;
-                    follow(k * 64 + b, y);
-                    if (boxes) {
-                        Box bx{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
-                        for (const int c : S.chain_cur) {
-                            const int cx = c & 0xFFFF, cy = c >> 16;
-                            bx.x0 = std::min(bx.x0, cx); bx.x1 = std::max(bx.x1, cx);
-                            bx.y0 = std::min(bx.y0, cy); bx.y1 = std::max(bx.y1, cy);
-                        }
-                        boxes->push_back(bx);
+        for (int k4 = 0; k4 < wpr; k4 += 4) {
+            if (!(B[k4] | B[k4 + 1] | B[k4 + 2] | B[k4 + 3])) continue;
+            for (int k = k4; k < k4 + 4; k++) {
+                const uint64_t begins = B[k];
+                if (begins == 0) continue;
+                uint64_t cand = begins & ~(ML[r + k] | MR[r + k]);
+                while (cand) {
+                    for (; marks_upto < k; marks_upto++) {
+                        const uint64_t ml = ML[r + marks_upto], mr = MR[r + marks_upto];
+                        if (ml | mr) last_mark = ml > mr ? 1 : 2;     // the higher bit is the later pixel
                     }
-                    if (S.cur.size() >= S.best.size()) { S.best.swap(S.cur); S.chain_best.swap(S.chain_cur); }
+                    const int b = __builtin_ctzll(cand);
+                    const uint64_t below = (1ull << b) - 1;
+                    const uint64_t ml = ML[r + k] & below, mr = MR[r + k] & below;
+                    int kind = last_mark;
+                    if (ml | mr) kind = ml > mr ? 1 : 2;
+                    if (kind != 1) {
+                        ++n_contours;
+                        follow(k * 64 + b, y);
+                        if (boxes) {
+                            Box bx{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
+                            for (const int c : S.chain_cur) {
+                                const int cx = c & 0xFFFF, cy = c >> 16;
+                                bx.x0 = std::min(bx.x0, cx); bx.x1 = std::max(bx.x1, cx);
+                                bx.y0 = std::min(bx.y0, cy); bx.y1 = std::max(bx.y1, cy);
+                            }
+                            boxes->push_back(bx);
+                        }
+                        if (S.cur.size() >= S.best.size()) { S.best.swap(S.cur); S.chain_best.swap(S.chain_cur); }
+                    }
+                    // the planes may have changed under the scan: look again at what is left of the word
+                    const uint64_t above = b == 63 ? 0 : ~((2ull << b) - 1);
+                    cand = begins & ~(ML[r + k] | MR[r + k]) & above;
                 }
-                // the planes may have changed under the scan: look again at what is left of the word
-                const uint64_t above = b == 63 ? 0 : ~((2ull << b) - 1);
-                cand = begins & ~(ML[r + k] | MR[r + k]) & above;
             }
         }
     }
@@ -169,10 +178,17 @@ static void fill_spans(int w, int h, CropScratch& S, std::vector<uint8_t>* dump)
     S.rows.resize(h); S.spans.resize(h);
     for (int y = 0; y < h; y++) { S.rows[y].clear(); S.spans[y].clear(); }
     const size_t n = S.chain_best.size();
+    int run_y = -1;
+    Span* run = nullptr;                 // the span the chain is drawing on row run_y: a border running along a row is one span
     for (size_t i = 0; i < n; i++) {
         const int a = S.chain_best[i], b = S.chain_best[i + 1 < n ? i + 1 : 0];
         const int ay = a >> 16, ax = a & 0xFFFF, by = b >> 16, bx = b & 0xFFFF;
-        S.spans[ay].push_back(Span{ax, ax});
+        if (ay == run_y && ax >= run->a - 1 && ax <= run->b + 1) {
+            run->a = std::min(run->a, ax); run->b = std::max(run->b, ax);
+        } else {
+            S.spans[ay].push_back(Span{ax, ax});
+            run = &S.spans[ay].back(); run_y = ay;
+        }
         if (ay == by) continue;
         if (ay < by) S.rows[ay].push_back(ax); else S.rows[by].push_back(bx);
     }

@@ -17,6 +17,7 @@ struct CropScratch {
     std::vector<uint64_t> bits;       // the mask as a BitFrame when it arrives as bytes
     std::vector<uint64_t> ml, mr;     // marks on followed border pixels (same layout)
     std::vector<size_t> touched;      // words of ml / mr that hold marks
+    std::vector<uint64_t> begins;     // one row's mask pixels with background to their west
     std::vector<P2> best, cur;        // SIMPLE points of the largest / current contour
     std::vector<int> chain_best, chain_cur;   // every border pixel (y << 16 | x) of the same
     struct Span { int a, b; };                // filled pixels a..b (inclusive) of one row

@@ -43,13 +43,15 @@ __device__ __forceinline__ unsigned content_bgr(uint32_t b, uint32_t g, uint32_t
 // Pass 1: BGR2GRAY + threshold as a bit plane T (64 pixels per word, wpr words per row, bits past the width 0).
 // A lane takes 4 pixels (12 bytes, three dword loads when the rows allow), a workgroup 1024 pixels of one row;
 // the 4-bit results go through LDS and 16 lanes pack them into the 16 words.
+// (several pictures per launch: blockIdx.z selects the picture - its source from `srcs`, a kernel argument, its bit plane tfb
+// words behind T)
+constexpr int SRC_LIST_MAX = 8;
+struct SrcList { const uint8_t* p[SRC_LIST_MAX]; };
 template <int CN>
-// (several pictures per launch: blockIdx.z selects the picture - its source from `srcs`, its bit plane tfb words behind T)
 __global__ __launch_bounds__(256) void threshold_bits_kernel(const uint8_t* __restrict__ src, size_t stride, int w,
-                                                             int aligned, u64* __restrict__ T, int wpr,
-                                                             const uint8_t* const* __restrict__ srcs, size_t tfb) {
+                                                             int aligned, u64* __restrict__ T, int wpr, SrcList srcs, size_t tfb) {
     __shared__ __attribute__((aligned(16))) uint8_t nib[256];
-    if (srcs) { src = srcs[blockIdx.z]; T += (size_t)blockIdx.z * tfb; }
+    if (!src) { src = srcs.p[blockIdx.z]; T += (size_t)blockIdx.z * tfb; }
     const int tid = threadIdx.x, x = (blockIdx.x * 256 + tid) * 4, y = blockIdx.y;
     const uint8_t* row = src + (size_t)y * stride;
     unsigned n = 0;
@@ -140,19 +142,21 @@ __global__ __launch_bounds__(256) void expand_bits_kernel(const u64* __restrict_
 
 // d_T: scratch of ceil(w/64)*h words.  The closed mask goes to d_out with row pitch opitch words, shifted by
 // oframe rows and words (1 for a BitFrame whose frame is already zero, 0 for a plain bit plane).
-// d_srcs (optional): a device table of `frames` source pointers, one geometry and pitch; the pictures' bit planes / results lie
-// tfb / ofb words apart.
+// srcs (optional, d_src == nullptr): `frames` <= SRC_LIST_MAX source pointers on the HOST, one geometry and pitch; the pictures'
+// bit planes / results lie tfb / ofb words apart.
 int launch_content_bits(const uint8_t* d_src, size_t stride, int w, int h, int cn, u64* d_T, u64* d_out, int opitch,
-                        int oframe, hipStream_t st, const uint8_t* const* d_srcs = nullptr, int frames = 1, size_t tfb = 0, size_t ofb = 0,
+                        int oframe, hipStream_t st, const uint8_t* const* srcs = nullptr, int frames = 1, size_t tfb = 0, size_t ofb = 0,
                         int srcs_aligned = 0) {
-    if ((!d_src && !d_srcs) || !d_T || !d_out || w <= 0 || h <= 0 || (cn != 1 && cn != 3) || frames < 1) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
+    if ((!d_src && !srcs) || (!d_src && frames > SRC_LIST_MAX) || !d_T || !d_out || w <= 0 || h <= 0 || (cn != 1 && cn != 3) || frames < 1) { set_last_error("content_mask: invalid argument"); return VS_ERR_INVALID_ARG; }
     if (h > 65535) { set_last_error("content_mask: image too tall"); return VS_ERR_INVALID_ARG; }
     const int wpr = (w + 63) / 64;
     // (a table of sources: srcs_aligned = every one of them is 4-byte aligned)
-    const int aligned = d_srcs ? (srcs_aligned && (stride & 3) == 0) : ((((uintptr_t)d_src | stride) & 3) == 0);
+    const int aligned = !d_src ? (srcs_aligned && (stride & 3) == 0) : ((((uintptr_t)d_src | stride) & 3) == 0);
+    SrcList sl;
+    for (int i = 0; i < SRC_LIST_MAX; i++) sl.p[i] = !d_src ? srcs[i < frames ? i : 0] : nullptr;
     dim3 g1((w + 1023) / 1024, h, frames);
-    if (cn == 3) hipLaunchKernelGGL(threshold_bits_kernel<3>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr, d_srcs, tfb);
-    else hipLaunchKernelGGL(threshold_bits_kernel<1>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr, d_srcs, tfb);
+    if (cn == 3) hipLaunchKernelGGL(threshold_bits_kernel<3>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr, sl, tfb);
+    else hipLaunchKernelGGL(threshold_bits_kernel<1>, g1, dim3(256), 0, st, d_src, stride, w, aligned, d_T, wpr, sl, tfb);
     dim3 g2(wpr, (h + MC_ROWS - 1) / MC_ROWS, frames);
     hipLaunchKernelGGL(close5_bits_kernel, g2, dim3(64), 0, st, d_T, wpr, w, h, d_out, opitch, oframe, tfb, ofb);
     VS_HIP_TRY(hipGetLastError());
@@ -182,19 +186,21 @@ struct vs_azc {
     // to page-locked memory with one copy (a launch costs the host 6 - 7 us on this runtime: per frame they were half of the
     // chain's host time).  The contour logic - host work in the reference as well (AutoZoomCrop.cpp:141-147 downloads the mask for
     // cv::findContours) - runs on worker threads, a frame each (frames do not depend on each other; 0.3 ms per 4K frame and
-    // thread), and the worker then queues the crop-and-scale of both planes.  NBS batches in flight.
-    static constexpr int ZB = 8, NBS = 4, NRES = 1024;
+    // thread); the worker that finishes a batch's last contour queues the crop-and-scale of the batch's surfaces, both planes, as
+    // one launch.  NBS batches in flight.
+    static constexpr int ZB = 8, NBS = 4, NRES = 1024;      // (ZB <= SRC_LIST_MAX, 2 ZB <= WARP_JOBS_MAX)
     int nw = 8;                          // worker threads (VS_AZC_WORKERS, 1 .. 16)
     struct Frame { const uint8_t* src; uint8_t* dst; int w, h; size_t pitch, uv, opitch, ouv; long ticket; };
     struct BatchSlot {
         uint8_t* d_masks = nullptr;      // ZB BitFrames
         uint8_t* h_masks = nullptr;      // page-locked
         u64* d_tbits = nullptr;          // ZB thresholded bit planes, before the closing
-        const uint8_t** h_srcs = nullptr;    // page-locked table of the batch's luma planes
-        const uint8_t** d_srcs = nullptr;
         hipEvent_t ev = nullptr;
         int mw = 0, mh = 0;
-        int n = 0, left = 0;             // frames of the batch / of them not yet through their host part
+        int n = 0, left = 0;             // frames of the batch / n until the batch's crop-and-scale has been queued, then 0 (slot free)
+        int todo = 0, nwj = 0;           // host parts not yet through / crop-and-scale jobs collected (wj)
+        WarpJob wj[2 * ZB];
+        int arrived = 0;                 // the masks: 0 nobody has looked yet, 1 one worker waits for ev, 2 there, 3 the wait failed
         Frame fr[ZB];
     } bslot[NBS];
     struct Result { long ticket = -1; int out_w = 0, out_h = 0, rc = 0; int32_t info[8] = {0}; } results[NRES];
@@ -203,11 +209,14 @@ struct vs_azc {
     hipStream_t st_out = nullptr;
     std::vector<std::thread> workers;
     std::mutex mu;
-    std::condition_variable cv_job, cv_done;
+    std::condition_variable cv_job, cv_done, cv_masks;
     std::deque<std::pair<int, int>> jobs;    // (batch slot, frame of the batch)
     bool quit = false;
     long issued = 0, completed = 0;
+    int async_rc = 0;                    // first failure of a worker's launch (reported by vs_azc_sync)
 };
+
+static_assert(vs_azc::ZB <= SRC_LIST_MAX && 2 * vs_azc::ZB <= WARP_JOBS_MAX, "a batch's sources and warp jobs travel as kernel arguments");
 
 #define A_HIP(a, expr)                                                             \
     do {                                                                           \
@@ -271,8 +280,6 @@ void vs_azc_destroy(vs_azc* a) {
         if (q.d_masks) (void)hipFree(q.d_masks);
         if (q.h_masks) (void)hipHostFree(q.h_masks);
         if (q.d_tbits) (void)hipFree(q.d_tbits);
-        if (q.h_srcs) (void)hipHostFree((void*)q.h_srcs);
-        if (q.d_srcs) (void)hipFree((void*)q.d_srcs);
         if (q.ev) (void)hipEventDestroy(q.ev);
     }
     if (a->st) (void)hipStreamSynchronize(a->st);
@@ -303,8 +310,11 @@ int vs_azc_sync(vs_azc* a) {
         const int frc = azc_flush_pending(a, lk);
         if (frc != VS_OK) return frc;
         a->cv_done.wait(lk, [&] { return a->completed == a->issued; });
+        const int arc = a->async_rc;
+        a->async_rc = VS_OK;
         lk.unlock();
         A_HIP(a, hipStreamSynchronize(a->st_out));
+        if (arc != VS_OK) { a->err = "auto zoom/crop: a worker's launch failed"; set_last_error(a->err); return arc; }
     }
     A_HIP(a, hipStreamSynchronize(a->st));
     return VS_OK;
@@ -418,7 +428,22 @@ static void azc_worker(vs_azc* a) {
         vs_azc::Result res;
         res.ticket = q.ticket;
         int rc = VS_OK;
-        if (hipEventSynchronize(b.ev) != hipSuccess) rc = VS_ERR_HIP;
+        {   // ONE worker waits for the batch's masks (a blocking wait: no core spent on it), the others for that worker
+            std::unique_lock<std::mutex> lk(a->mu);
+            if (b.arrived == 0) {
+                b.arrived = 1;
+                lk.unlock();
+                const hipError_t e = hipEventSynchronize(b.ev);
+                lk.lock();
+                b.arrived = e == hipSuccess ? 2 : 3;
+                a->cv_masks.notify_all();
+            } else {
+                a->cv_masks.wait(lk, [&] { return b.arrived >= 2; });
+            }
+            if (b.arrived == 3) rc = VS_ERR_HIP;
+        }
+        WarpJob wj[2];
+        bool scaled = false;
         if (rc == VS_OK) {
             BitFrame bf;
             bf.w = q.w; bf.h = q.h; bf.pitch = BitFrame::pitch_for(q.w);
@@ -435,21 +460,40 @@ static void azc_worker(vs_azc* a) {
                 const int ux = cx / 2, uy = cy / 2, uw = std::max(1, cw / 2), uh = std::max(1, ch / 2);
                 const float My[6] = {(float)(640.0 / cw), 0.f, 0.f, 0.f, (float)(360.0 / ch), 0.f};
                 const float Mu[6] = {(float)(320.0 / uw), 0.f, 0.f, 0.f, (float)(180.0 / uh), 0.f};
-                double Iy[6], Iu[6];
-                warp_invert(My, Iy);
-                warp_invert(Mu, Iu);
-                rc = launch_warp_affine_inv(q.src + (size_t)cy * q.pitch + cx, q.pitch, cw, ch, q.dst, q.opitch, 640, 360, 1, Iy, VS_BORDER_BLACK, a->st_out);
-                if (rc == VS_OK)
-                    rc = launch_warp_affine_inv(q.src + q.uv + (size_t)uy * q.pitch + (size_t)ux * 2, q.pitch, uw, uh, q.dst + q.ouv, q.opitch, 320, 180, 2, Iu,
-                                                VS_BORDER_BLACK, a->st_out);
+                warp_invert(My, wj[0].m);
+                warp_invert(Mu, wj[1].m);
+                wj[0].src = q.src + (size_t)cy * q.pitch + cx; wj[0].dst = q.dst;
+                wj[0].sw = cw; wj[0].sh = ch; wj[0].dw = 640; wj[0].dh = 360; wj[0].cn = 1;
+                wj[1].src = q.src + q.uv + (size_t)uy * q.pitch + (size_t)ux * 2; wj[1].dst = q.dst + q.ouv;
+                wj[1].sw = uw; wj[1].sh = uh; wj[1].dw = 320; wj[1].dh = 180; wj[1].cn = 2;
+                for (WarpJob& w : wj) { w.sstride = (uint32_t)q.pitch; w.dstride = (uint32_t)q.opitch; w.border = VS_BORDER_BLACK; }
+                scaled = true;
             }
         }
         res.rc = rc;
+        // The crop-and-scale of the batch's frames is ONE launch (launch_warp_jobs), queued by the worker that finishes the batch's
+        // last contour; a frame counts as complete (vs_azc_sync) when that launch has been queued.
+        bool last;
+        int njobs = 0;
+        WarpJob all[2 * vs_azc::ZB];
         {
             std::lock_guard<std::mutex> g(a->mu);
             a->results[res.ticket % vs_azc::NRES] = res;
-            b.left--;
-            a->completed++;
+            if (scaled) { b.wj[b.nwj++] = wj[0]; b.wj[b.nwj++] = wj[1]; }
+            last = --b.todo == 0;
+            if (last) { njobs = b.nwj; memcpy(all, b.wj, sizeof(WarpJob) * njobs); }
+        }
+        a->cv_done.notify_all();          // (vs_azc_result waits for the host part only)
+        if (!last) continue;
+        int lrc = njobs ? launch_warp_jobs(all, njobs, a->st_out) : VS_OK;
+        {
+            std::lock_guard<std::mutex> g(a->mu);
+            if (lrc != VS_OK) {
+                a->async_rc = lrc;
+                for (int i = 0; i < b.n; i++) a->results[b.fr[i].ticket % vs_azc::NRES].rc = lrc;
+            }
+            a->completed += b.n;
+            b.left = 0;
         }
         a->cv_done.notify_all();
     }
@@ -472,25 +516,21 @@ static int azc_flush_pending(vs_azc* a, std::unique_lock<std::mutex>& lk) {
         A_HIP(a, hipMalloc((void**)&b.d_tbits, tw * 8 * vs_azc::ZB));
         A_HIP(a, hipHostMalloc((void**)&b.h_masks, mb * vs_azc::ZB, hipHostMallocDefault));
         A_HIP(a, hipMemsetAsync(b.d_masks, 0, mb * vs_azc::ZB, a->st));          // the frames of the BitFrames; the kernel rewrites the insides
-        if (!b.ev) {
-            A_HIP(a, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
-            A_HIP(a, hipHostMalloc((void**)&b.h_srcs, sizeof(void*) * vs_azc::ZB, hipHostMallocDefault));
-            A_HIP(a, hipMalloc((void**)&b.d_srcs, sizeof(void*) * vs_azc::ZB));
-        }
+        if (!b.ev) A_HIP(a, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming | hipEventBlockingSync));
         b.mw = w; b.mh = h;
     }
     int aligned = 1;
+    const uint8_t* srcs[vs_azc::ZB];
     for (int i = 0; i < n; i++) {
         b.fr[i] = a->pending[i];
-        b.h_srcs[i] = a->pending[i].src;
+        srcs[i] = a->pending[i].src;
         if ((uintptr_t)a->pending[i].src & 3) aligned = 0;
     }
-    A_HIP(a, hipMemcpyAsync((void*)b.d_srcs, (const void*)b.h_srcs, sizeof(void*) * n, hipMemcpyHostToDevice, a->st));
-    A_TRY(a, launch_content_bits(nullptr, a->pending[0].pitch, w, h, 1, b.d_tbits, (u64*)b.d_masks, BitFrame::pitch_for(w), 1, a->st, b.d_srcs, n, tw,
+    A_TRY(a, launch_content_bits(nullptr, a->pending[0].pitch, w, h, 1, b.d_tbits, (u64*)b.d_masks, BitFrame::pitch_for(w), 1, a->st, srcs, n, tw,
                                  mb / 8, aligned));                                                                              // :111-139 on the luma planes
     A_HIP(a, hipMemcpyAsync(b.h_masks, b.d_masks, mb * n, hipMemcpyDeviceToHost, a->st));                                          // :142-143
     A_HIP(a, hipEventRecord(b.ev, a->st));
-    b.n = n; b.left = n;
+    b.n = n; b.left = n; b.todo = n; b.nwj = 0; b.arrived = 0;
     for (int i = 0; i < n; i++) a->jobs.emplace_back((int)(a->nbatches % vs_azc::NBS), i);
     a->nbatches++;
     a->pending.clear();

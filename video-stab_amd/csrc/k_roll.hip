@@ -560,12 +560,37 @@ static int run_canny(RollWork& k, const uint8_t* d_gray, size_t stride, double l
     return d_edges ? canny_emit(k, d_edges, estride, st) : VS_OK;
 }
 
+// The Canny stages of a batch of frames for the roll stage's asynchronous path, the edge set left in k.E: counters and hysteresis
+// words of every frame cleared by ONE memset in front (run_hough is then told so), `passes` passes of the growth;
+// k.hflags[passes - 1] != 0 afterwards: still growing.
+// (All passes in one launch, the bands of a frame meeting at a barrier in global memory between passes - 72 workgroups at
+// 3840 x 2160 / 4, resident together - was built and measured in round 4: eleven launches less per batch, but every pass then pays
+// the barrier's round trip through memory and the growth runs to its end instead of twelve passes: 29.9 k frames/s for the roll
+// stage alone against 36.3 k, the chain 13.0 k against 15.1 - 15.6 k on the same box, gpurun_out/r04_y.  Not kept.)
+static int run_canny_batch(RollWork& k, const uint8_t* d_gray, size_t stride, double low_t, double high_t, hipStream_t st, int passes) {
+    if (low_t > high_t) std::swap(low_t, high_t);
+    const int low = (int)std::floor(low_t), high = (int)std::floor(high_t);
+    const int w = k.w, h = k.h;
+    VS_HIP_TRY(hipMemset2DAsync(k.counters, k.fb, 0, 128, k.frames, st));        // counters[16], hflags[16]
+    dim3 grid((w + NT - 1) / NT, h, k.frames);
+    hipLaunchKernelGGL(sobel_kernel, grid, dim3(NT), 0, st, d_gray, stride, w, h, k.dxy, k.mag, k.mw, k.fb);
+    hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(NT), 0, st, k.dxy, k.mag, w, h, k.mw, low, high, k.E, k.C, k.wpr, k.fb);
+    const int nwv = k.wpr < HB_WORDS ? k.wpr : HB_WORDS;
+    dim3 hg((k.wpr + nwv - 1) / nwv, (k.h + HB_ROWS - 1) / HB_ROWS, k.frames);
+    for (int p = 0; p < passes; p++)
+        hipLaunchKernelGGL(canny_hyst_band_kernel, hg, dim3(64 * nwv), 0, st, k.E, k.C, k.wpr, k.h, k.hflags + p,
+                           p ? k.hflags + p - 1 : (int*)nullptr, k.fb);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
 // cv::HoughLines(edges, lines, rho, theta, threshold) + the angle statistics of the roll stage
 static int run_hough(RollWork& k, const uint8_t* d_edges, size_t estride, int threshold, double amin, double amax,
-                     hipStream_t st) {
+                     hipStream_t st, bool counters_cleared = false) {
     const int w = k.w, h = k.h;
     if (w > 65535 || h > 32767) { set_last_error("hough: image too large"); return VS_ERR_INVALID_ARG; }
-    if (k.frames > 1) VS_HIP_TRY(hipMemset2DAsync(k.counters + 1, k.fb, 0, 60, k.frames, st));
+    if (counters_cleared) {}
+    else if (k.frames > 1) VS_HIP_TRY(hipMemset2DAsync(k.counters + 1, k.fb, 0, 60, k.frames, st));
     else VS_HIP_TRY(hipMemsetAsync(k.counters + 1, 0, 60, st));
     if (d_edges) {
         dim3 lgrid((w + NT * EL_PX - 1) / (NT * EL_PX), h);
@@ -614,10 +639,11 @@ struct vs_roll {
     // by one from the caller's thread they cost ~100 us of the runtime's launch path per frame (9 k frames/s; the same as a
     // captured graph, which the runtime replays node by node), and from eight threads, a frame each, still 80 us (12.5 k).  So the
     // searches of RB consecutive frames go through ONE launch per stage (blockIdx.z = frame, a work area per frame), queued by
-    // one of NWK worker threads on its own stream; when the batch's results (24 bytes per frame) have arrived the worker - in
+    // one of nwk worker threads on its own stream; when the batch's results (24 bytes per frame) have arrived the worker - in
     // frame order - advances the angle (EMA, clamp, decay) and queues each frame's rotation (both planes) on `st`.  The caller's
     // thread only hands the frames over.
-    static constexpr int NWK = 3, RB = 8, QMAX = 128;
+    static constexpr int NWK = 8, RB = 8, QMAX = 128;       // NWK: the most workers
+    int nwk = 3;                         // worker threads in use (VS_ROLL_WORKERS, 1 .. NWK)
     struct Job { const uint8_t* src; uint8_t* dst; int w, h; size_t pitch, uv, opitch, ouv; long seq; };
     struct Slot {
         RollWork wk;                     // RB frames
@@ -843,7 +869,7 @@ static int roll_worker_batch(vs_roll* r, vs_roll::Slot& q, const std::vector<vs_
     const vs_roll::Job& j0 = jobs[0];
     if (!q.st) {
         R_HIP(r, hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
-        R_HIP(r, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+        R_HIP(r, hipEventCreateWithFlags(&q.ev, hipEventDisableTiming | hipEventBlockingSync));   // (a worker waiting for its batch spends no core on it)
         R_HIP(r, hipHostMalloc((void**)&q.h_res, 320 * vs_roll::RB, hipHostMallocDefault));
         R_HIP(r, hipHostMalloc((void**)&q.h_pairs, sizeof(ImgPair) * vs_roll::RB, hipHostMallocDefault));
         R_HIP(r, hipMalloc((void**)&q.d_pairs, sizeof(ImgPair) * vs_roll::RB));
@@ -859,8 +885,8 @@ static int roll_worker_batch(vs_roll* r, vs_roll::Slot& q, const std::vector<vs_
     // (twelve hysteresis passes per batch - a pass whose predecessor changed nothing for its frame returns at once: with four, 40 % of
     // the bench clip's frames had to finish their growth one by one behind the batch, 30 us per frame)
     constexpr int PASSES = 12;
-    VS_TRY(run_canny(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, nullptr, 0, q.st, /*unchecked=*/true, PASSES));   // :54-61
-    VS_TRY(run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st));                          // :66-73, :106-119
+    VS_TRY(run_canny_batch(k, k.gray, sw, p.canny_threshold_low, p.canny_threshold_high, q.st, PASSES));                            // :54-61
+    VS_TRY(run_hough(k, nullptr, 0, p.hough_threshold, p.angle_filter_min, p.angle_filter_max, q.st, /*counters_cleared=*/true));  // :66-73, :106-119
     // per frame: counters (64 B), hysteresis flags (64 B) and, 256 bytes on, the line statistics
     VS_HIP_TRY(hipMemcpy2DAsync(q.h_res, 320, k.counters, k.fb, 256 + sizeof(RollResult), n, hipMemcpyDeviceToHost, q.st));
     VS_HIP_TRY(hipEventRecord(q.ev, q.st));
@@ -944,8 +970,8 @@ static void roll_worker(vs_roll* r, int wi) {
 // (r->mu held) what has been handed over becomes a batch of the next worker
 static void roll_flush_pending(vs_roll* r) {
     if (r->pending.empty()) return;
-    r->slot[r->nbatches % vs_roll::NWK].batches.emplace_back();
-    r->slot[r->nbatches % vs_roll::NWK].batches.back().swap(r->pending);
+    r->slot[r->nbatches % r->nwk].batches.emplace_back();
+    r->slot[r->nbatches % r->nwk].batches.back().swap(r->pending);
     r->nbatches++;
 }
 
@@ -963,7 +989,8 @@ int vs_roll_correct_nv12_dev(vs_roll* r, const void* d_surface, int w, int h, si
     R_HIP(r, hipSetDevice(r->device));
     if (r->workers.empty()) {
         try {
-            for (int i = 0; i < vs_roll::NWK; i++) r->workers.emplace_back(roll_worker, r, i);
+            if (const char* e = std::getenv("VS_ROLL_WORKERS")) r->nwk = std::max(1, std::min(std::atoi(e), (int)vs_roll::NWK));
+            for (int i = 0; i < r->nwk; i++) r->workers.emplace_back(roll_worker, r, i);
         } catch (...) {
             r->err = "roll: cannot start worker threads"; set_last_error(r->err);
             return VS_ERR_HIP;

@@ -384,6 +384,33 @@ __global__ __launch_bounds__(NT) void warp_tables_kernel(WarpArgs a) {
                        a.use_list ? a.dsts[bz] : a.dst + (size_t)bz * a.dframe, j);
 }
 
+// The table blocks of up to NVT_MAX NV12 surfaces, both planes, from inverse maps given on the host, in ONE launch
+// (blockIdx.y = surface, blockIdx.z = plane): the rotations of a batch of roll-corrected surfaces.
+constexpr int NVT_MAX = 16;
+struct NvTabArgs {
+    int32_t* tabs;
+    int block, chroma;           // ints between the blocks of consecutive surfaces / offset of the chroma table inside a block
+    int w, h;
+    size_t src_uv, dst_uv;
+    const uint8_t* ys[NVT_MAX];
+    uint8_t* yd[NVT_MAX];
+    double my[NVT_MAX * 6], muv[NVT_MAX * 6];
+};
+
+__global__ __launch_bounds__(NT) void warp_tables_nv12_kernel(NvTabArgs a) {
+    const int bz = blockIdx.y, plane = blockIdx.z;
+    const int dw = plane ? a.w / 2 : a.w, dh = plane ? a.h / 2 : a.h;
+    TabLayout L = tab_layout(dw, dh);
+    L.stride = a.block;
+    double m[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) m[i] = plane ? a.muv[6 * bz + i] : a.my[6 * bz + i];
+    const int j = blockIdx.x * NT + threadIdx.x;
+    if (j < wt_entries(dw, dh))
+        wt_build_entry(a.tabs + (size_t)bz * a.block + (plane ? a.chroma : 0), L, m, dw, dh, plane ? a.ys[bz] + a.src_uv : a.ys[bz],
+                       plane ? a.yd[bz] + a.dst_uv : a.yd[bz], j);
+}
+
 template <int CN, bool TABS>
 __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LDS_PX];
@@ -515,6 +542,42 @@ __global__ __launch_bounds__(NT) void warp_affine_kernel(WarpArgs a) {
     if (CN == 3 && fast) emit_fast(a.c, dst, tile, obuf, lut, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, -(by0 * FPITCH + bx0a), tid);
     else if (use_lds) emit_rows<CN, true>(a.c, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw, tid);
     else emit_rows<CN, false>(a.c, src, dst, tile, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, bx0a, by0, bw, tid);
+}
+
+// ---- several small warps of different geometry in ONE launch --------------------------------------------------------------
+// AutoZoomCrop's crop-and-scale of a batch of NV12 surfaces (k_azc.hip): 2 x 8 jobs of 640 x 360 / 320 x 180 pixels, every one
+// with its own crop rectangle, as one launch instead of sixteen (a launch costs the host 6 - 7 us on this runtime).  The jobs
+// travel as kernel arguments; blockIdx.z = job, a job's tiles beyond its own size return at once.  Terms and taps as the
+// general kernel's direct path (no staging: a scale map spreads the taps of a tile over a box that no staging area holds).
+struct WarpJobsArg { WarpJob j[WARP_JOBS_MAX]; };
+
+__global__ __launch_bounds__(NT) void warp_jobs_kernel(WarpJobsArg a) {
+    __shared__ int s_ad[TW], s_bd[TW], s_x0[TH], s_y0[TH];
+    const WarpJob& j = a.j[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    if (x0 >= j.dw || y0 >= j.dh) return;                 // (workgroup-uniform)
+    const int x1 = min(x0 + TW, j.dw) - 1, y1 = min(y0 + TH, j.dh) - 1;
+    if (tid < TW) {
+        const double dv = (double)min(x0 + tid, x1);
+        s_ad[tid] = coord_term(j.m[0], 0.0, dv);
+        s_bd[tid] = coord_term(j.m[3], 0.0, dv);
+    } else if (tid < TW + TH) {
+        const double dv = (double)min(y0 + (tid - TW), y1);
+        s_x0[tid - TW] = coord_term(j.m[1], j.m[2], dv) + 16;
+        s_y0[tid - TW] = coord_term(j.m[4], j.m[5], dv) + 16;
+    }
+    __syncthreads();
+    WarpCore c;
+    c.sstride = j.sstride; c.dstride = j.dstride;
+    c.sw = j.sw; c.sh = j.sh; c.dw = j.dw; c.dh = j.dh;
+    c.src_aligned = 0;
+    const int galign = j.cn == 2 ? 8 : 4;
+    c.dst_aligned = ((uintptr_t)j.dst % galign == 0) && (j.dstride % galign == 0);
+    c.border = j.border;
+    if (j.cn == 1) emit_rows<1, false>(c, j.src, j.dst, nullptr, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, 0, 0, 0, tid);
+    else if (j.cn == 2) emit_rows<2, false>(c, j.src, j.dst, nullptr, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, 0, 0, 0, tid);
+    else emit_rows<3, false>(c, j.src, j.dst, nullptr, s_ad, s_bd, s_x0, s_y0, x0, y0, x1, y1, 0, 0, 0, tid);
 }
 
 // ---- tile building blocks shared by the table kernels ------------------------------------------------------------
@@ -1444,8 +1507,8 @@ int launch_warp_affine_list_inv(const uint8_t* const* srcs, uint8_t* const* dsts
 }
 
 // NV12 surfaces given one by one, inverse maps of both planes given on the host (6 doubles per frame and plane), selectable
-// border: four and more surfaces build their table blocks with a launch per plane and are warped in ONE grid (the rotations of a
-// batch of roll-corrected surfaces); fewer go plane by plane.
+// border: four and more surfaces build their table blocks with one launch (more than 16: one per plane) and are warped in ONE
+// grid (the rotations of a batch of roll-corrected surfaces); fewer go plane by plane.
 int launch_warp_nv12_list_inv(const uint8_t* const* ys, uint8_t* const* yd, int n, size_t sstride, size_t dstride, int w, int h, size_t src_uv,
                               size_t dst_uv, const double* h_MinvY, const double* h_MinvUV, int border, hipStream_t st) {
     if (n < 1 || n > MAXB || !ys || !yd || !h_MinvY || !h_MinvUV) { set_last_error("warp_nv12_list_inv: invalid argument"); return VS_ERR_INVALID_ARG; }
@@ -1460,7 +1523,14 @@ int launch_warp_nv12_list_inv(const uint8_t* const* ys, uint8_t* const* yd, int 
         const int block = nv12_tab_ints(w, h), sy = tab_layout(w, h).stride;
         int32_t* d_tabs = nullptr;
         VS_TRY(op_tabs(st, (size_t)block * n * sizeof(int32_t), &d_tabs));
-        for (int plane = 0; plane < 2; plane++) {
+        if (n <= NVT_MAX) {       // both planes' tables of every surface with one launch
+            NvTabArgs t;
+            t.tabs = d_tabs; t.block = block; t.chroma = sy; t.w = w; t.h = h; t.src_uv = src_uv; t.dst_uv = dst_uv;
+            for (int i = 0; i < NVT_MAX; i++) { t.ys[i] = ys[i < n ? i : 0]; t.yd[i] = yd[i < n ? i : 0]; }
+            for (int i = 0; i < NVT_MAX * 6; i++) { t.my[i] = i < 6 * n ? h_MinvY[i] : 0.; t.muv[i] = i < 6 * n ? h_MinvUV[i] : 0.; }
+            const int entries = w + h + (w + TW - 1) / TW + (h + TH - 1) / TH;
+            hipLaunchKernelGGL(warp_tables_nv12_kernel, dim3((entries + NT - 1) / NT, n, 2), dim3(NT), 0, st, t);
+        } else for (int plane = 0; plane < 2; plane++) {
             WarpArgs a;
             const int pw = plane ? w / 2 : w, ph = plane ? h / 2 : h;
             fill_common(a, plane ? us[0] : ys[0], sstride, 0, pw, ph, plane ? ud[0] : yd[0], dstride, 0, pw, ph, plane ? 2 : 1);
@@ -1500,6 +1570,28 @@ int launch_warp_affine_inv(const uint8_t* d_src, size_t sstride, int sw, int sh,
     for (int i = 0; i < MAXB * 6; i++) a.Minv_val[i] = i < 6 ? h_Minv[i] : 0.;
     dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH, 1);
     launch_cn(a, grid, cn, nullptr, st);
+    VS_HIP_TRY(hipGetLastError());
+    return VS_OK;
+}
+
+// n <= WARP_JOBS_MAX warps of any geometry (inverse maps in double on the host) as one launch.
+int launch_warp_jobs(const WarpJob* jobs, int n, hipStream_t st) {
+    if (!jobs || n < 1 || n > WARP_JOBS_MAX) { set_last_error("warp_jobs: invalid argument"); return VS_ERR_INVALID_ARG; }
+    WarpJobsArg a;
+    int gw = 1, gh = 1;
+    for (int i = 0; i < WARP_JOBS_MAX; i++) {
+        a.j[i] = jobs[i < n ? i : 0];
+        if (i >= n) continue;
+        const WarpJob& j = jobs[i];
+        if (bad_args(j.src, j.dst, j.m, j.sstride, j.sw, j.sh, j.dstride, j.dw, j.dh, j.cn, 1) ||
+            (j.border != VS_BORDER_BLACK && j.border != VS_BORDER_REPLICATE)) {
+            set_last_error("warp_jobs: invalid argument");
+            return VS_ERR_INVALID_ARG;
+        }
+        gw = std::max(gw, (j.dw + TW - 1) / TW);
+        gh = std::max(gh, (j.dh + TH - 1) / TH);
+    }
+    hipLaunchKernelGGL(warp_jobs_kernel, dim3(gw, gh, n), dim3(NT), 0, st, a);
     VS_HIP_TRY(hipGetLastError());
     return VS_OK;
 }

@@ -94,6 +94,16 @@ int launch_warp_affine(const uint8_t* d_src, size_t sstride, size_t sframe, int 
                        const double* d_Minv, int batch, int32_t* d_tabs, hipStream_t st);
 // what: the whole launch, or its two halves apart (tables of the frames now, the warp later from the same d_tabs).
 enum { VS_WARP_ALL = 0, VS_WARP_TABLES_ONLY = 1, VS_WARP_ONLY = 2 };
+// One warp of a multi-job launch (launch_warp_jobs, k_warp.hip): any geometry, inverse map in double on the host.
+struct WarpJob {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint32_t sstride, dstride;
+    int32_t sw, sh, dw, dh, cn, border;
+    double m[6];
+};
+constexpr int WARP_JOBS_MAX = 16;
+int launch_warp_jobs(const WarpJob* jobs, int n, hipStream_t st);
 // tab_stride: ints between the tables of consecutive frames in d_tabs (0: packed, warp_tabs_ints(dw, dh, 1))
 int launch_warp_affine_list(const uint8_t* const* srcs, uint8_t* const* dsts, int n, size_t sstride, int sw, int sh,
                             size_t dstride, int dw, int dh, int cn, const double* d_Minv, int minv_stride, int32_t* d_tabs,
