@@ -478,50 +478,83 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
                 busy[name] += time.perf_counter() - t
         return g
 
-    def roll_stage(c):                                                         # roll: chunk c
+    def roll_stage(c):
         rc.correct_nv12_dev_n([clip.ptr + ((c * CH + i) % NF) * sb for i in range(CH)], W, H, W,
                               [d_roll[c % R_RING].ptr + i * sb for i in range(CH)], W)
         rc.sync()
 
-    def stab_stage(c):
-        if c < 1:
-            return                                                             # stabilize: chunk c-1 (its rotations are complete)
-        produced[c - 1] = st.push_dev_n([d_roll[(c - 1) % R_RING].ptr + i * sb for i in range(CH)], W, H, W, capi.FMT_NV12,
-                                        [d_stab[(c - 1) % S_RING].ptr + j * sb for j in range(CH)], W)
+    def stab_stage(c):                                                         # (the rotations of chunk c are complete)
+        produced[c] = st.push_dev_n([d_roll[c % R_RING].ptr + i * sb for i in range(CH)], W, H, W, capi.FMT_NV12,
+                                    [d_stab[c % S_RING].ptr + j * sb for j in range(CH)], W)
         st.sync()
 
     def zoom_stage(c):
-        if c < 2:
-            return
-        k = produced[c - 2]                                                    # zoom/crop: what chunk c-2 yielded (complete)
+        k = produced[c]                                                        # what the stabilizer let go during chunk c (complete)
         if k:
-            tickets.extend(az.apply_nv12_dev_n([d_stab[(c - 2) % S_RING].ptr + j * sb for j in range(k)], W, H, W,
+            tickets.extend(az.apply_nv12_dev_n([d_stab[c % S_RING].ptr + j * sb for j in range(k)], W, H, W,
                                                [d_zoom[c % Z_RING].ptr + j * sb for j in range(k)], W, W * H))
         az.sync()
 
-    def step(c):
-        # one host thread per stage (a stage's calls queue a dozen launches per surface: three stages from one thread cost the sum
-        # of their host times, 0.21 ms per surface); the three join at the end of the chunk
-        ths = [threading.Thread(target=timed(n, f), args=(c,)) for n, f in (("roll", roll_stage), ("stab", stab_stage), ("zoom", zoom_stage))]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-    for c in range(chunks_warm):
-        step(c)
-    n0 = len(tickets)
-    timing[0] = True
-    t0 = time.perf_counter()
-    for c in range(chunks_warm, chunks_warm + chunks_timed):
-        step(c)
-    dt = time.perf_counter() - t0
-    n = len(tickets) - n0
+    # One host thread per stage (a stage's calls queue a dozen launches per surface: three stages from one thread cost the sum of
+    # their host times), free-running: a stage takes chunk c as soon as the stage before it has finished c and the ring slot it
+    # writes is no longer read - roll(c) after stab(c - 3) (the stabilizer reads a surface until radius + 16 pushes later), stab(c)
+    # after zoom(c - 3).  Timed: from the moment the zoom stage has finished chunk `chunks_warm - 1` to the moment it has finished
+    # chunk `chunks_warm + chunks_timed - 1`, while the earlier stages keep working on two more chunks behind (the timed chunks run
+    # in a full pipeline from end to end).
+    total = chunks_warm + chunks_timed + 2
+    done = {"roll": -1, "stab": -1, "zoom": -1}
+    stamp = {}
+    marks = {}
+    cond = threading.Condition()
+    failed = []
+    import resource
+
+    def wait_for(stage, c):
+        with cond:
+            cond.wait_for(lambda: done[stage] >= c or failed)
+        return not failed
+
+    def stage_loop(name, f, before, after, lag):
+        try:
+            g = timed(name, f)
+            for c in range(total):
+                if before and not wait_for(before, c):
+                    return
+                if after and not wait_for(after, c - lag):
+                    return
+                g(c)
+                with cond:
+                    done[name] = c
+                    if name == "zoom" and c in (chunks_warm - 1, chunks_warm + chunks_timed - 1):
+                        stamp[c] = time.perf_counter()
+                        marks[c] = (len(tickets), resource.getrusage(resource.RUSAGE_SELF))
+                        timing[0] = c == chunks_warm - 1
+                    cond.notify_all()
+        except BaseException as e:          # (a failed stage must not leave the others waiting)
+            with cond:
+                failed.append(e)
+                cond.notify_all()
+
+    ths = [threading.Thread(target=stage_loop, args=a) for a in (("roll", roll_stage, None, "stab", 3), ("stab", stab_stage, "roll", "zoom", 3),
+                                                                 ("zoom", zoom_stage, "stab", None, 0))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if failed:
+        raise failed[0]
+    c0, c1 = chunks_warm - 1, chunks_warm + chunks_timed - 1
+    dt = stamp[c1] - stamp[c0]
+    n0, u0 = marks[c0]
+    n1, u1 = marks[c1]
+    n = n1 - n0
     ow, oh, info = az.result(tickets[-1])
     res = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n, 1) * 1e3, 4), "frames": n,
            "last_result": [ow, oh], "last_crop": [int(v) for v in info[2:6]], "chunk": CH,
            "stage_thread_ms_per_chunk": {k: round(v / chunks_timed * 1e3, 3) for k, v in busy.items()},
+           "host_cores_busy": round((u1.ru_utime - u0.ru_utime + u1.ru_stime - u0.ru_stime) / dt, 2),
            "what": "vs_roll_correct_nv12_dev -> vs_stab_push_dev (batch 64, zero-copy) -> vs_azc_apply_nv12_dev on 3840x2160 NV12 surfaces "
-                   "resident in HBM, chunks of %d, one host thread per stage, the three stages overlapped on the device, one host wait per stage and chunk; every "
+                   "resident in HBM, chunks of %d, one free-running host thread per stage (a stage takes a chunk when the stage before it has finished it), one host wait per stage and chunk; every "
                    "surface goes through all three stages (640x360 NV12 out)" % CH}
     st.close()
     rc.close()

@@ -195,6 +195,8 @@ struct vs_azc {
         uint8_t* d_masks = nullptr;      // ZB BitFrames
         uint8_t* h_masks = nullptr;      // page-locked
         u64* d_tbits = nullptr;          // ZB thresholded bit planes, before the closing
+        hipStream_t st = nullptr;        // the batch's mask kernels and mask copy: a stream per slot, so that the next batch's kernels
+                                         // do not queue behind this batch's 8 MB on the way to the host
         hipEvent_t ev = nullptr;
         int mw = 0, mh = 0;
         int n = 0, left = 0;             // frames of the batch / n until the batch's crop-and-scale has been queued, then 0 (slot free)
@@ -277,6 +279,7 @@ void vs_azc_destroy(vs_azc* a) {
     }
     if (a->st_out) { (void)hipStreamSynchronize(a->st_out); (void)hipStreamDestroy(a->st_out); }
     for (auto& q : a->bslot) {
+        if (q.st) { (void)hipStreamSynchronize(q.st); (void)hipStreamDestroy(q.st); }
         if (q.d_masks) (void)hipFree(q.d_masks);
         if (q.h_masks) (void)hipHostFree(q.h_masks);
         if (q.d_tbits) (void)hipFree(q.d_tbits);
@@ -507,6 +510,10 @@ static int azc_flush_pending(vs_azc* a, std::unique_lock<std::mutex>& lk) {
     const int n = (int)a->pending.size();
     const int w = a->pending[0].w, h = a->pending[0].h;
     const size_t mb = BitFrame::words_for(w, h) * 8, tw = (size_t)((w + 63) / 64) * h;
+    if (!b.ev) {
+        A_HIP(a, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming | hipEventBlockingSync));
+        A_HIP(a, hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking));
+    }
     if (b.mw != w || b.mh != h) {
         if (b.d_masks) (void)hipFree(b.d_masks);
         if (b.h_masks) (void)hipHostFree(b.h_masks);
@@ -515,8 +522,7 @@ static int azc_flush_pending(vs_azc* a, std::unique_lock<std::mutex>& lk) {
         A_HIP(a, hipMalloc((void**)&b.d_masks, mb * vs_azc::ZB));
         A_HIP(a, hipMalloc((void**)&b.d_tbits, tw * 8 * vs_azc::ZB));
         A_HIP(a, hipHostMalloc((void**)&b.h_masks, mb * vs_azc::ZB, hipHostMallocDefault));
-        A_HIP(a, hipMemsetAsync(b.d_masks, 0, mb * vs_azc::ZB, a->st));          // the frames of the BitFrames; the kernel rewrites the insides
-        if (!b.ev) A_HIP(a, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming | hipEventBlockingSync));
+        A_HIP(a, hipMemsetAsync(b.d_masks, 0, mb * vs_azc::ZB, b.st));          // the frames of the BitFrames; the kernel rewrites the insides
         b.mw = w; b.mh = h;
     }
     int aligned = 1;
@@ -526,10 +532,10 @@ static int azc_flush_pending(vs_azc* a, std::unique_lock<std::mutex>& lk) {
         srcs[i] = a->pending[i].src;
         if ((uintptr_t)a->pending[i].src & 3) aligned = 0;
     }
-    A_TRY(a, launch_content_bits(nullptr, a->pending[0].pitch, w, h, 1, b.d_tbits, (u64*)b.d_masks, BitFrame::pitch_for(w), 1, a->st, srcs, n, tw,
+    A_TRY(a, launch_content_bits(nullptr, a->pending[0].pitch, w, h, 1, b.d_tbits, (u64*)b.d_masks, BitFrame::pitch_for(w), 1, b.st, srcs, n, tw,
                                  mb / 8, aligned));                                                                              // :111-139 on the luma planes
-    A_HIP(a, hipMemcpyAsync(b.h_masks, b.d_masks, mb * n, hipMemcpyDeviceToHost, a->st));                                          // :142-143
-    A_HIP(a, hipEventRecord(b.ev, a->st));
+    A_HIP(a, hipMemcpyAsync(b.h_masks, b.d_masks, mb * n, hipMemcpyDeviceToHost, b.st));                                          // :142-143
+    A_HIP(a, hipEventRecord(b.ev, b.st));
     b.n = n; b.left = n; b.todo = n; b.nwj = 0; b.arrived = 0;
     for (int i = 0; i < n; i++) a->jobs.emplace_back((int)(a->nbatches % vs_azc::NBS), i);
     a->nbatches++;
