@@ -549,9 +549,11 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
     n1, u1 = marks[c1]
     n = n1 - n0
     ow, oh, info = az.result(tickets[-1])
+    wt = az.worker_times()
     res = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n, 1) * 1e3, 4), "frames": n,
            "last_result": [ow, oh], "last_crop": [int(v) for v in info[2:6]], "chunk": CH,
            "stage_thread_ms_per_chunk": {k: round(v / chunks_timed * 1e3, 3) for k, v in busy.items()},
+           "zoom_worker_us_per_frame": {k: round(v / max(wt[0], 1) * 1e6, 1) for k, v in zip(("idle", "masks", "contour", "publish"), wt[1:])},
            "host_cores_busy": round((u1.ru_utime - u0.ru_utime + u1.ru_stime - u0.ru_stime) / dt, 2),
            "what": "vs_roll_correct_nv12_dev -> vs_stab_push_dev (batch 64, zero-copy) -> vs_azc_apply_nv12_dev on 3840x2160 NV12 surfaces "
                    "resident in HBM, chunks of %d, one free-running host thread per stage (a stage takes a chunk when the stage before it has finished it), one host wait per stage and chunk; every "

@@ -25,3 +25,5 @@ for rep in range(3):
     t2 = time.perf_counter()
     print("zoom : enqueue %.1f us/frame, total %.1f us/frame (%.0f f/s)" % ((t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6, N / (t2 - t0)))
 print("last zoom result", az.result(N * 3 - 1)[:2])
+wt = az.worker_times()
+print("zoom workers, us per frame: idle %.1f masks %.1f contour %.1f publish %.1f" % tuple(v / wt[0] * 1e6 for v in wt[1:]))

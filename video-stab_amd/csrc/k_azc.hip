@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "azc_contour.h"
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <thread>
@@ -216,6 +217,9 @@ struct vs_azc {
     bool quit = false;
     long issued = 0, completed = 0;
     int async_rc = 0;                    // first failure of a worker's launch (reported by vs_azc_sync)
+    // where the workers' time goes (vs_azc_worker_times): frames, and seconds waiting for a job / for a batch's masks / in the
+    // contour logic / queueing launches and publishing
+    double wt[5] = {0, 0, 0, 0, 0};
 };
 
 static_assert(vs_azc::ZB <= SRC_LIST_MAX && 2 * vs_azc::ZB <= WARP_JOBS_MAX, "a batch's sources and warp jobs travel as kernel arguments");
@@ -417,8 +421,11 @@ int vs_azc_apply(vs_azc* a, const uint8_t* data, int w, int h, size_t stride, in
 static void azc_worker(vs_azc* a) {
     (void)hipSetDevice(a->device);
     CropScratch scratch;
+    typedef std::chrono::steady_clock clk;
+    auto secs = [](clk::time_point p, clk::time_point q) { return std::chrono::duration<double>(q - p).count(); };
     for (;;) {
         std::pair<int, int> job;
+        const clk::time_point t_idle = clk::now();
         {
             std::unique_lock<std::mutex> lk(a->mu);
             a->cv_job.wait(lk, [&] { return a->quit || !a->jobs.empty(); });
@@ -431,6 +438,7 @@ static void azc_worker(vs_azc* a) {
         vs_azc::Result res;
         res.ticket = q.ticket;
         int rc = VS_OK;
+        const clk::time_point t_job = clk::now();
         {   // ONE worker waits for the batch's masks (a blocking wait: no core spent on it), the others for that worker
             std::unique_lock<std::mutex> lk(a->mu);
             if (b.arrived == 0) {
@@ -447,11 +455,14 @@ static void azc_worker(vs_azc* a) {
         }
         WarpJob wj[2];
         bool scaled = false;
+        const clk::time_point t_masks = clk::now();
+        clk::time_point t_contour = t_masks;
         if (rc == VS_OK) {
             BitFrame bf;
             bf.w = q.w; bf.h = q.h; bf.pitch = BitFrame::pitch_for(q.w);
             bf.F = (const uint64_t*)(b.h_masks + (size_t)job.second * BitFrame::words_for(q.w, q.h) * 8);
             crop_from_mask(bf, scratch, res.info, nullptr);                                                // :146-228
+            t_contour = clk::now();
             if (!res.info[7]) {                                                                            // :149-152, :238-249
                 res.out_w = q.w; res.out_h = q.h;
                 if (hipMemcpy2DAsync(q.dst, q.opitch, q.src, q.pitch, (size_t)q.w, q.h, hipMemcpyDeviceToDevice, a->st_out) != hipSuccess ||
@@ -487,10 +498,13 @@ static void azc_worker(vs_azc* a) {
             if (last) { njobs = b.nwj; memcpy(all, b.wj, sizeof(WarpJob) * njobs); }
         }
         a->cv_done.notify_all();          // (vs_azc_result waits for the host part only)
-        if (!last) continue;
-        int lrc = njobs ? launch_warp_jobs(all, njobs, a->st_out) : VS_OK;
+        int lrc = last && njobs ? launch_warp_jobs(all, njobs, a->st_out) : VS_OK;
         {
             std::lock_guard<std::mutex> g(a->mu);
+            const clk::time_point t_end = clk::now();
+            a->wt[0] += 1; a->wt[1] += secs(t_idle, t_job); a->wt[2] += secs(t_job, t_masks); a->wt[3] += secs(t_masks, t_contour);
+            a->wt[4] += secs(t_contour, t_end);
+            if (!last) continue;
             if (lrc != VS_OK) {
                 a->async_rc = lrc;
                 for (int i = 0; i < b.n; i++) a->results[b.fr[i].ticket % vs_azc::NRES].rc = lrc;
@@ -588,6 +602,15 @@ int vs_azc_apply_nv12_dev_n(vs_azc* a, const void* const* d_surfaces, void* cons
         const int rc = vs_azc_apply_nv12_dev(a, d_surfaces[i], w, h, pitch, uv_offset, d_outs[i], out_pitch, out_uv_offset, tickets ? tickets + i : nullptr);
         if (rc != VS_OK) return rc;
     }
+    return VS_OK;
+}
+
+// Diagnostics of the asynchronous path: frames through the workers so far and the seconds the workers spent, summed over the
+// threads, waiting for a job / waiting for a batch's masks / in the contour logic / queueing launches and publishing.
+int vs_azc_worker_times(vs_azc* a, double* out5) {
+    if (!a || !out5) return VS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(a->mu);
+    for (int i = 0; i < 5; i++) out5[i] = a->wt[i];
     return VS_OK;
 }
 

@@ -277,6 +277,7 @@ class VsLib:
         L.vs_azc_apply_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, C.c_size_t,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vs_azc_sync.argtypes = [vp]
+        L.vs_azc_worker_times.argtypes = [vp, C.POINTER(C.c_double)]
         L.vs_azc_get_info.argtypes = [vp, i32p]
         L.vs_op_content_mask.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.vs_azc_crop_from_mask.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, i32p, u8p]
@@ -615,6 +616,12 @@ class AutoZoomCrop:
 
     def sync(self):
         self._check(self.lib.vs_azc_sync(self.h))
+
+    def worker_times(self):
+        """(frames, s waiting for a job, s waiting for masks, s in the contour logic, s queueing / publishing), summed over the workers"""
+        out = (C.c_double * 5)()
+        self._check(self.lib.vs_azc_worker_times(self.h, out))
+        return tuple(out)
 
     def info(self):
         info = np.zeros(8, np.int32)
