@@ -463,7 +463,7 @@ int vs_roll_sync(vs_roll* r);
  * (:141-149, BORDER_REPLICATE) is applied to the luma plane and, with the translation halved, to the half-size interleaved
  * chroma plane.  uv_offset / out_uv_offset: where the chroma plane starts (0 = h * pitch).  The call hands the frame over and
  * returns (it waits only when 128 frames are pending): eight consecutive frames form a batch whose line searches a worker
- * thread queues as ONE launch per stage on its own stream; when the batch's results (24 bytes per frame) have arrived the
+ * thread (five of them; environment VS_ROLL_WORKERS: 1 .. 8) queues as ONE launch per stage on its own stream; when the batch's results (24 bytes per frame) have arrived the
  * smoothed angle advances - in call order, on the host - and the rotations are queued.  Results are complete after
  * vs_roll_sync (which closes an incomplete batch); surfaces and result buffers must stay untouched until then.
  * vs_roll_get_state (after vs_roll_sync) reports the last frame. */
@@ -513,9 +513,10 @@ int vs_azc_sync(vs_azc* a);
  * unchanged w x h surface: out_pitch >= max(w, 640), out_uv_offset >= max(h, 360) * out_pitch.  The call hands the frame over
  * and returns a ticket; eight consecutive frames of one geometry form a batch whose mask kernels are one launch each and
  * whose bit masks reach the host with one copy; the contour logic runs on the object's worker threads (it is host work in the
- * reference too, :141-147), a frame each, which then queue the crop-and-scale.  vs_azc_result(ticket) waits for that
- * frame's host part and tells what came out, vs_azc_sync completes the pixels (both close an incomplete batch).  Four
- * batches in flight, eight worker threads (environment VS_AZC_WORKERS: 1 .. 16), results of the last 1024 tickets kept. */
+ * reference too, :141-147), a frame each; the worker that finishes a batch's last contour queues the crop-and-scale of the
+ * batch as one launch.  vs_azc_result(ticket) waits for that frame's host part and tells what came out, vs_azc_sync completes
+ * the pixels (both close an incomplete batch).  Four batches in flight, twelve worker threads (environment VS_AZC_WORKERS:
+ * 1 .. 16), results of the last 1024 tickets kept. */
 int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t pitch, size_t uv_offset,
                           void* d_out, size_t out_pitch, size_t out_uv_offset, int64_t* ticket);
 int vs_azc_apply_nv12_dev_n(vs_azc* a, const void* const* d_surfaces, void* const* d_outs, int n, int w, int h,

@@ -643,7 +643,9 @@ struct vs_roll {
     // frame order - advances the angle (EMA, clamp, decay) and queues each frame's rotation (both planes) on `st`.  The caller's
     // thread only hands the frames over.
     static constexpr int NWK = 8, RB = 8, QMAX = 128;       // NWK: the most workers
-    int nwk = 3;                         // worker threads in use (VS_ROLL_WORKERS, 1 .. NWK)
+    int nwk = 5;                         // worker threads in use (VS_ROLL_WORKERS, 1 .. NWK): alone three are as fast as eight (36 - 38 k
+                                         // frames/s); beside a stabilizer on the same GPU a batch's launches wait behind its workgroups, and five
+                                         // batches in flight keep the stage at 3.4 ms per 128 surfaces where three need 5.5 (gpurun_out/r04_ai)
     struct Job { const uint8_t* src; uint8_t* dst; int w, h; size_t pitch, uv, opitch, ouv; long seq; };
     struct Slot {
         RollWork wk;                     // RB frames
