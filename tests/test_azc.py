@@ -316,14 +316,15 @@ def test_roll_then_zoom_chain(gpu, oracle):
 
 
 @pytest.mark.gpu
-def test_auto_zoom_crop_nv12_async_matches_oracle(gpu, oracle):
+@pytest.mark.parametrize("size", [(800, 450), (808, 454)], ids=["rows_of_16_pixel_groups", "ragged_rows"])
+def test_auto_zoom_crop_nv12_async_matches_oracle(gpu, oracle, size):
     """vs_azc_apply_nv12_dev: the mask kernels of a frame are queued by the call, the contour logic runs on worker threads (four
     frames at a time), which queue the crop-and-scale of both planes.  Twelve surfaces - rotated content in black corners at
     several angles and sizes of the black object, an all-black one (no contour: the surface comes back unchanged), an all-content
     one - pushed without waiting; tickets, rectangles and planes against the oracle."""
     from vsamd.capi import DevBuf
     from vsamd import synth
-    w, h = 800, 450
+    w, h = size              # (a width of 16-pixel groups takes the mask's wide-load kernel, the other one the general kernel)
     frames = [rotated_frame(oracle, w, h, deg, seed=i) for i, deg in enumerate([4.0, -2.5, 1.0, 7.5, -6.0, 0.5, 3.0, -1.0, 2.0, -4.5])]
     frames.insert(3, np.zeros((h, w, 3), np.uint8))
     frames.insert(8, np.full((h, w, 3), 200, np.uint8))
@@ -331,7 +332,7 @@ def test_auto_zoom_crop_nv12_async_matches_oracle(gpu, oracle):
     for s, f in zip(surfs, frames):
         s[:h][(f == 0).all(axis=2)] = 0              # (BT.601 black is 16; the warp's black border in an NV12 stream is 0)
     sb = w * h * 3 // 2
-    op, oh_max = 800, 450
+    op, oh_max = w, h
     ob = op * oh_max * 3 // 2
     d_in = DevBuf.from_array(gpu, np.stack(surfs))
     d_out = DevBuf(gpu, ob * len(surfs))
