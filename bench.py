@@ -553,7 +553,8 @@ def config2_chain(vs, device, p, W, H, chunks_timed=10, chunks_warm=5):
     res = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / max(n, 1) * 1e3, 4), "frames": n,
            "last_result": [ow, oh], "last_crop": [int(v) for v in info[2:6]], "chunk": CH,
            "stage_thread_ms_per_chunk": {k: round(v / chunks_timed * 1e3, 3) for k, v in busy.items()},
-           "zoom_worker_us_per_frame": {k: round(v / max(wt[0], 1) * 1e6, 1) for k, v in zip(("idle", "masks", "contour", "publish"), wt[1:])},
+           "zoom_worker_us_per_frame": {k: round(v / max(wt[0], 1) * 1e6, 1) for k, v in zip(("idle", "masks", "contour", "publish"), wt[1:5])},
+           "zoom_batch_us": {k: round(v / max(wt[5], 1) * 1e6, 1) for k, v in zip(("launch_to_masks", "masks_to_crop", "caller_waits_for_slot"), wt[6:9])},
            "host_cores_busy": round((u1.ru_utime - u0.ru_utime + u1.ru_stime - u0.ru_stime) / dt, 2),
            "what": "vs_roll_correct_nv12_dev -> vs_stab_push_dev (batch 64, zero-copy) -> vs_azc_apply_nv12_dev on 3840x2160 NV12 surfaces "
                    "resident in HBM, chunks of %d, one free-running host thread per stage (a stage takes a chunk when the stage before it has finished it), one host wait per stage and chunk; every "

@@ -522,9 +522,11 @@ int vs_azc_apply_nv12_dev(vs_azc* a, const void* d_surface, int w, int h, size_t
 int vs_azc_apply_nv12_dev_n(vs_azc* a, const void* const* d_surfaces, void* const* d_outs, int n, int w, int h,
                             size_t pitch, size_t uv_offset, size_t out_pitch, size_t out_uv_offset, int64_t* tickets);
 int vs_azc_result(vs_azc* a, int64_t ticket, int* out_w, int* out_h, int32_t* info8);
-/* Diagnostics of the asynchronous path: out5 = {frames through the worker threads, seconds (summed over the threads) waiting
- * for a job, waiting for a batch's masks, in the contour logic, queueing launches and publishing}. */
-int vs_azc_worker_times(vs_azc* a, double* out5);
+/* Diagnostics of the asynchronous path: out9 = {frames through the worker threads; seconds, summed over the threads: without a
+ * frame to work on, waiting for the masks of the batches on their way (one worker at a time does), in the contour logic, queueing
+ * launches and publishing; batches; seconds, summed over the batches: from a batch's launches to the arrival of its masks on the
+ * host, from there to its crop-and-scale launch; seconds the caller waited for a free batch slot}. */
+int vs_azc_worker_times(vs_azc* a, double* out9);
 /* info8 = {n_contours, contour_points, crop_x, crop_y, crop_w, crop_h, iterations, cropped} */
 int vs_azc_get_info(const vs_azc* a, int32_t* info8);
 /* cvtColor + threshold(gray,1,255,BINARY) + morphologyEx(MORPH_CLOSE, 5x5 ellipse) -

@@ -26,4 +26,4 @@ for rep in range(3):
     print("zoom : enqueue %.1f us/frame, total %.1f us/frame (%.0f f/s)" % ((t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6, N / (t2 - t0)))
 print("last zoom result", az.result(N * 3 - 1)[:2])
 wt = az.worker_times()
-print("zoom workers, us per frame: idle %.1f masks %.1f contour %.1f publish %.1f" % tuple(v / wt[0] * 1e6 for v in wt[1:]))
+print("zoom workers, us per frame: idle %.1f masks %.1f contour %.1f publish %.1f" % tuple(v / wt[0] * 1e6 for v in wt[1:5]), "; per batch us: launch->masks %.1f masks->crop %.1f caller waits for slot %.1f" % tuple(v / wt[5] * 1e6 for v in wt[6:9]))

@@ -231,7 +231,8 @@ struct vs_azc {
         int n = 0, left = 0;             // frames of the batch / n until the batch's crop-and-scale has been queued, then 0 (slot free)
         int todo = 0, nwj = 0;           // host parts not yet through / crop-and-scale jobs collected (wj)
         WarpJob wj[2 * ZB];
-        int arrived = 0;                 // the masks: 0 nobody has looked yet, 1 one worker waits for ev, 2 there, 3 the wait failed
+        int arrived = 0;                 // the masks: 0 on their way, 2 there, 3 the wait for them failed
+        std::chrono::steady_clock::time_point t_issue, t_arrive;
         Frame fr[ZB];
     } bslot[NBS];
     struct Result { long ticket = -1; int out_w = 0, out_h = 0, rc = 0; int32_t info[8] = {0}; } results[NRES];
@@ -240,14 +241,18 @@ struct vs_azc {
     hipStream_t st_out = nullptr;
     std::vector<std::thread> workers;
     std::mutex mu;
-    std::condition_variable cv_job, cv_done, cv_masks;
-    std::deque<std::pair<int, int>> jobs;    // (batch slot, frame of the batch)
+    std::condition_variable cv_job, cv_done;
+    std::deque<std::pair<int, int>> jobs;    // (batch slot, frame of the batch): the masks are there
+    std::deque<int> on_the_way;              // batch slots whose masks are on their way, oldest first
+    bool waiting = false;                    // a worker waits for the oldest of them
     bool quit = false;
     long issued = 0, completed = 0;
     int async_rc = 0;                    // first failure of a worker's launch (reported by vs_azc_sync)
     // where the workers' time goes (vs_azc_worker_times): frames, and seconds waiting for a job / for a batch's masks / in the
     // contour logic / queueing launches and publishing
     double wt[5] = {0, 0, 0, 0, 0};
+    double bt[4] = {0, 0, 0, 0};         // batches; seconds from a batch's launches to its masks' arrival / from there to its crop launch /
+                                         // the caller waited for a free batch slot
 };
 
 static_assert(vs_azc::ZB <= SRC_LIST_MAX && 2 * vs_azc::ZB <= WARP_JOBS_MAX, "a batch's sources and warp jobs travel as kernel arguments");
@@ -454,10 +459,36 @@ static void azc_worker(vs_azc* a) {
     for (;;) {
         std::pair<int, int> job;
         const clk::time_point t_idle = clk::now();
+        clk::time_point t_job = t_idle;
         {
+            // A frame becomes a job when its batch's masks have arrived.  The batches on their way are waited for in order by ONE
+            // worker at a time - whichever has nothing else to do (a blocking wait: no core spent on it) - so that the others
+            // stay free for the frames of the batches that are there: with a wait per frame the workers stood in front of the
+            // copy engine most of the time (12 workers: 22 k frames/s where 48 k fit, scratch/README.md).
             std::unique_lock<std::mutex> lk(a->mu);
-            a->cv_job.wait(lk, [&] { return a->quit || !a->jobs.empty(); });
-            if (a->jobs.empty()) return;
+            for (;;) {
+                if (!a->jobs.empty()) break;
+                if (!a->on_the_way.empty() && !a->waiting) {
+                    const int slot = a->on_the_way.front();
+                    a->on_the_way.pop_front();
+                    a->waiting = true;
+                    lk.unlock();
+                    const clk::time_point t0 = clk::now();
+                    const hipError_t e = hipEventSynchronize(a->bslot[slot].ev);
+                    const clk::time_point t1 = clk::now();
+                    lk.lock();
+                    a->waiting = false;
+                    a->wt[2] += secs(t0, t1);
+                    t_job = t_job + (t1 - t0);                      // (not idle time)
+                    a->bslot[slot].arrived = e == hipSuccess ? 2 : 3;
+                    a->bslot[slot].t_arrive = t1;
+                    for (int i = 0; i < a->bslot[slot].n; i++) a->jobs.emplace_back(slot, i);
+                    a->cv_job.notify_all();
+                    continue;
+                }
+                if (a->quit) return;
+                a->cv_job.wait(lk);
+            }
             job = a->jobs.front();
             a->jobs.pop_front();
         }
@@ -465,26 +496,12 @@ static void azc_worker(vs_azc* a) {
         const vs_azc::Frame q = b.fr[job.second];
         vs_azc::Result res;
         res.ticket = q.ticket;
-        int rc = VS_OK;
-        const clk::time_point t_job = clk::now();
-        {   // ONE worker waits for the batch's masks (a blocking wait: no core spent on it), the others for that worker
-            std::unique_lock<std::mutex> lk(a->mu);
-            if (b.arrived == 0) {
-                b.arrived = 1;
-                lk.unlock();
-                const hipError_t e = hipEventSynchronize(b.ev);
-                lk.lock();
-                b.arrived = e == hipSuccess ? 2 : 3;
-                a->cv_masks.notify_all();
-            } else {
-                a->cv_masks.wait(lk, [&] { return b.arrived >= 2; });
-            }
-            if (b.arrived == 3) rc = VS_ERR_HIP;
-        }
+        int rc = b.arrived == 3 ? VS_ERR_HIP : VS_OK;
         WarpJob wj[2];
         bool scaled = false;
         const clk::time_point t_masks = clk::now();
         clk::time_point t_contour = t_masks;
+        t_job = t_job > t_masks ? t_masks : t_job;
         if (rc == VS_OK) {
             BitFrame bf;
             bf.w = q.w; bf.h = q.h; bf.pitch = BitFrame::pitch_for(q.w);
@@ -530,7 +547,7 @@ static void azc_worker(vs_azc* a) {
         {
             std::lock_guard<std::mutex> g(a->mu);
             const clk::time_point t_end = clk::now();
-            a->wt[0] += 1; a->wt[1] += secs(t_idle, t_job); a->wt[2] += secs(t_job, t_masks); a->wt[3] += secs(t_masks, t_contour);
+            a->wt[0] += 1; a->wt[1] += secs(t_idle, t_masks) - secs(t_idle, t_job); a->wt[3] += secs(t_masks, t_contour);
             a->wt[4] += secs(t_contour, t_end);
             if (!last) continue;
             if (lrc != VS_OK) {
@@ -539,6 +556,7 @@ static void azc_worker(vs_azc* a) {
             }
             a->completed += b.n;
             b.left = 0;
+            a->bt[0] += 1; a->bt[1] += secs(b.t_issue, b.t_arrive); a->bt[2] += secs(b.t_arrive, t_end);
         }
         a->cv_done.notify_all();
     }
@@ -548,7 +566,11 @@ static void azc_worker(vs_azc* a) {
 static int azc_flush_pending(vs_azc* a, std::unique_lock<std::mutex>& lk) {
     if (a->pending.empty()) return VS_OK;
     vs_azc::BatchSlot& b = a->bslot[a->nbatches % vs_azc::NBS];
-    a->cv_done.wait(lk, [&] { return b.left == 0; });
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        a->cv_done.wait(lk, [&] { return b.left == 0; });
+        a->bt[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
     const int n = (int)a->pending.size();
     const int w = a->pending[0].w, h = a->pending[0].h;
     const size_t mb = BitFrame::words_for(w, h) * 8, tw = (size_t)((w + 63) / 64) * h;
@@ -578,8 +600,9 @@ static int azc_flush_pending(vs_azc* a, std::unique_lock<std::mutex>& lk) {
                                  mb / 8, aligned));                                                                              // :111-139 on the luma planes
     A_HIP(a, hipMemcpyAsync(b.h_masks, b.d_masks, mb * n, hipMemcpyDeviceToHost, b.st));                                          // :142-143
     A_HIP(a, hipEventRecord(b.ev, b.st));
+    b.t_issue = std::chrono::steady_clock::now();
     b.n = n; b.left = n; b.todo = n; b.nwj = 0; b.arrived = 0;
-    for (int i = 0; i < n; i++) a->jobs.emplace_back((int)(a->nbatches % vs_azc::NBS), i);
+    a->on_the_way.push_back((int)(a->nbatches % vs_azc::NBS));
     a->nbatches++;
     a->pending.clear();
     a->cv_job.notify_all();
@@ -634,11 +657,13 @@ int vs_azc_apply_nv12_dev_n(vs_azc* a, const void* const* d_surfaces, void* cons
 }
 
 // Diagnostics of the asynchronous path: frames through the workers so far and the seconds the workers spent, summed over the
-// threads, waiting for a job / waiting for a batch's masks / in the contour logic / queueing launches and publishing.
-int vs_azc_worker_times(vs_azc* a, double* out5) {
+// threads, without a frame / waiting for the masks on their way / in the contour logic / queueing launches and publishing; then
+// batches and, summed over them, the seconds from launches to masks, from masks to the crop launch, and the caller's waits for a slot.
+int vs_azc_worker_times(vs_azc* a, double* out5) {      // (nine values: include/vs_stab.h)
     if (!a || !out5) return VS_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(a->mu);
     for (int i = 0; i < 5; i++) out5[i] = a->wt[i];
+    for (int i = 0; i < 4; i++) out5[5 + i] = a->bt[i];
     return VS_OK;
 }
 

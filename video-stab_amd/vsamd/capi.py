@@ -618,8 +618,9 @@ class AutoZoomCrop:
         self._check(self.lib.vs_azc_sync(self.h))
 
     def worker_times(self):
-        """(frames, s waiting for a job, s waiting for masks, s in the contour logic, s queueing / publishing), summed over the workers"""
-        out = (C.c_double * 5)()
+        """(frames, s without a frame, s waiting for masks, s in the contour logic, s queueing / publishing - summed over the workers;
+        batches, s from launches to masks, s from masks to the crop launch - summed over the batches; s the caller waited for a slot)"""
+        out = (C.c_double * 9)()
         self._check(self.lib.vs_azc_worker_times(self.h, out))
         return tuple(out)
 
