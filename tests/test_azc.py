@@ -353,4 +353,6 @@ def test_auto_zoom_crop_nv12_async_matches_oracle(gpu, oracle, size):
         assert np.array_equal(got[i, oh_max:oh_max + oh // 2, :ow], ref[oh:]), i
         cropped += int(info[7])
     assert 9 <= cropped <= 11
+    wt = az.worker_times()               # diagnostics: every frame went through a worker, in two batches (8 + 4)
+    assert wt[0] == len(surfs) and wt[5] == 2 and wt[3] > 0 and all(v >= 0 for v in wt)
     az.close()
