@@ -379,3 +379,37 @@ def test_roll_correct_nv12_async_full_size_analysis(gpu, oracle):
     for i in range(n):
         assert np.array_equal(got[i], ro.correct_nv12(surfs[i], w, h)), i
     assert ro.state() == rg.state() and ro.state()[0] != 0.0
+
+
+@pytest.mark.gpu
+def test_roll_and_zoom_async_objects_survive_a_change_of_geometry(gpu, oracle):
+    """One vs_roll and one vs_azc object fed 640 x 360 surfaces, then 800 x 450, then 640 x 360 again without a sync in between:
+    a batch closes when the geometry changes, work areas and mask buffers are rebuilt per size, state carries over; against the
+    oracle objects fed the same sequence."""
+    from vsamd.capi import DevBuf
+    from vsamd import synth
+    seq = [(640, 360)] * 5 + [(800, 450)] * 11 + [(640, 360)] * 3
+    surfs = [synth.bgr_to_nv12(roll_scene.horizon_frame(w, h, 30 + 3 * i, seed=i, offset=i % 7 - 3)) for i, (w, h) in enumerate(seq)]
+    kw = dict(hough_threshold=60)
+    ro, rg = oracle.roll_correction(oracle.roll_params(**kw)), gpu.roll_correction(gpu.roll_params(**kw))
+    az = gpu.auto_zoom_crop()
+    d_in = [DevBuf.from_array(gpu, s) for s in surfs]
+    d_rot = [DevBuf(gpu, s.nbytes) for s in surfs]
+    d_zoom = [DevBuf(gpu, max(s.nbytes, 640 * 360 * 3 // 2)) for s in surfs]
+    for (w, h), a, b in zip(seq, d_in, d_rot):
+        rg.correct_nv12_dev(a.ptr, w, h, w, b.ptr, w)
+    rg.sync()
+    tickets = [az.apply_nv12_dev(b.ptr, w, h, w, c.ptr, max(w, 640), max(w, 640) * max(h, 360)) for (w, h), b, c in zip(seq, d_rot, d_zoom)]
+    az.sync()
+    for i, ((w, h), s) in enumerate(zip(seq, surfs)):
+        rot = ro.correct_nv12(s, w, h)
+        assert np.array_equal(d_rot[i].download(s.shape, np.uint8), rot), i
+        ref, info = oracle.auto_zoom_crop_nv12(rot, w, h)
+        ow, oh, ginfo = az.result(tickets[i])
+        assert ginfo.tolist() == info.tolist() and (ow, oh) == ((640, 360) if info[7] else (w, h)), i
+        op = max(w, 640)
+        got = d_zoom[i].download((max(h, 360) * 3 // 2, op), np.uint8)
+        assert np.array_equal(got[:oh, :ow], ref[:oh]) and np.array_equal(got[max(h, 360):max(h, 360) + oh // 2, :ow], ref[oh:]), i
+    assert ro.state() == rg.state()
+    rg.close()
+    az.close()
