@@ -447,8 +447,9 @@ int vs_azc_apply(vs_azc* a, const uint8_t* data, int w, int h, size_t stride, in
 }
 
 // ---- NV12, asynchronous ----------------------------------------------------------------------------------------------------
-// One frame's host part, on a worker thread: wait for its mask, contour logic, queue crop-and-scale (or the copy of the
-// fall-back paths) of both planes on st_out.  The content mask is taken from the luma plane (gray > 1, :121-127 on a picture
+// One frame's host part, on a worker thread: the contour logic on the frame's mask once its batch's masks have arrived, then its
+// crop-and-scale job (or, at once, the copy of the fall-back paths) for both planes on st_out; the worker that finishes a batch's
+// last frame queues the batch's jobs as one launch.  The content mask is taken from the luma plane (gray > 1, :121-127 on a picture
 // that is gray already); the crop rectangle applies to the luma plane as it is and, halved, to the half-size chroma plane;
 // each plane is scaled to its share of 640 x 360 by the reference's scale matrix (:261-270).
 static void azc_worker(vs_azc* a) {
@@ -463,8 +464,9 @@ static void azc_worker(vs_azc* a) {
         {
             // A frame becomes a job when its batch's masks have arrived.  The batches on their way are waited for in order by ONE
             // worker at a time - whichever has nothing else to do (a blocking wait: no core spent on it) - so that the others
-            // stay free for the frames of the batches that are there: with a wait per frame the workers stood in front of the
-            // copy engine most of the time (12 workers: 22 k frames/s where 48 k fit, scratch/README.md).
+            // stay free for the frames of the batches that are there.  (With a wait per frame the workers stood in front of the
+            // copy engine 250 - 330 us per frame; that time is idle time now - beside a stabilizer the stage is bound by the latency
+            // of its device part, scratch/README.md.)
             std::unique_lock<std::mutex> lk(a->mu);
             for (;;) {
                 if (!a->jobs.empty()) break;

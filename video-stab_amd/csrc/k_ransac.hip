@@ -434,8 +434,9 @@ struct TailSeg { int first, n; float* M_out; TrajState* traj; vs_debug_frame* db
 
 __global__ __launch_bounds__(1024) void ransac_tail_batch_kernel(const RansacArgs* __restrict__ table, TailItem* __restrict__ tail,
                                                                  const TailSeg* __restrict__ segs, const TailIn* __restrict__ tin) {
-    // (Beside the detector's NMS launch of the next batch this kernel takes 85 us, alone 10 - 25; s_setprio(3) for its waves
-    // changes nothing: measured, not kept.)
+    // (Launched as sixteen waves this kernel took 85 - 110 us beside the detector's and the pyramid's launches of the next batch,
+    // alone 10 - 25, and s_setprio(3) for its waves changed nothing: the time went into waiting for a compute unit with room for
+    // the whole workgroup.  As four waves: 32 us beside them - launch_ransac_tail_group.)
     const TailSeg sg = segs[blockIdx.x];
     table += sg.first; tail += sg.first; tin += sg.first;
     const int n = sg.n;
@@ -690,7 +691,10 @@ int launch_ransac_tail_group(const void* d_table, const void* d_tail, const void
         set_last_error("ransac_tail_group: invalid argument");
         return VS_ERR_INVALID_ARG;
     }
-    const int threads = 64 * (max_n > 16 ? 16 : max_n);
+    // Four waves, one per SIMD: the workgroup then fits a compute unit that the detector's and the pyramid's launches of the next batch
+    // keep nearly full (with sixteen waves - a quarter of a unit's registers and 22 KB of LDS at once - it waited for one to drain:
+    // 60 - 110 us on `main` beside them against 10 - 25 alone); its ordered part is one lane's work either way.
+    const int threads = 64 * (max_n > 4 ? 4 : max_n);
     const RansacArgs* tb = static_cast<const RansacArgs*>(d_table);
     TailItem* tl = static_cast<TailItem*>(const_cast<void*>(d_tail));
     const TailSeg* sg = static_cast<const TailSeg*>(d_segs);
