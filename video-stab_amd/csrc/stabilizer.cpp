@@ -129,8 +129,6 @@ struct vs_stab {
     hipStream_t st_det = nullptr;
     hipStream_t st_warp = nullptr;  // deferred (batched) warps, high priority
     bool shared_streams = false;    // the four streams belong to the per-device pool
-    hipEvent_t ev_dev_warp = nullptr;   // the pool's: recorded behind the last batched warp of ANY instance on this device
-    std::atomic<bool>* dev_warp_valid = nullptr;
     std::string err;
     // geometry, fixed by the first frame
     bool allocated = false;
@@ -987,9 +985,8 @@ int create_events(vs_stab* s) {
 namespace {
 struct StreamPool {
     hipStream_t st = nullptr, pre = nullptr, det = nullptr, warp = nullptr;
-    hipEvent_t ev_warp = nullptr;       // behind the last batched warp of any instance
-    std::atomic<bool> warp_valid{false};    // (instances sharing the pool are driven from ONE host thread - INTEGRATION.md; the flag
-                                            //  alone is safe to read from another)
+    // (the batched warps of every schedule on the device run on `pre`, in the order they were issued: instances sharing the pool are
+    //  driven from ONE host thread - INTEGRATION.md)
     int refs = 0;
 };
 std::mutex g_pool_mutex;
@@ -1013,12 +1010,9 @@ hipError_t acquire_streams(vs_stab* s) {
     if (p.refs == 0) {
         hipError_t e = make_streams(&p.st, &p.pre, &p.det, &p.warp);
         if (e != hipSuccess) return e;
-        if (hipEventCreateWithFlags(&p.ev_warp, hipEventDisableTiming) != hipSuccess) p.ev_warp = nullptr;
-        p.warp_valid.store(false);
     }
     p.refs++;
     s->st = p.st; s->st_pre = p.pre; s->st_det = p.det; s->st_warp = p.warp;
-    s->ev_dev_warp = p.ev_warp; s->dev_warp_valid = &p.warp_valid;
     s->shared_streams = true;
     return hipSuccess;
 }
@@ -1029,8 +1023,7 @@ void release_streams(vs_stab* s) {
     StreamPool& p = g_pools[s->device];
     if (--p.refs == 0) {
         (void)hipStreamDestroy(p.st); (void)hipStreamDestroy(p.pre); (void)hipStreamDestroy(p.det); (void)hipStreamDestroy(p.warp);
-        if (p.ev_warp) (void)hipEventDestroy(p.ev_warp);
-        p.st = p.pre = p.det = p.warp = nullptr; p.ev_warp = nullptr; p.warp_valid.store(false); p.refs = 0;
+        p.st = p.pre = p.det = p.warp = nullptr; p.refs = 0;
     }
 }
 }  // namespace
@@ -1269,7 +1262,8 @@ int vs_stab_push(vs_stab* s, const uint8_t* data, int w, int h, size_t stride, i
             return fail(s, VS_ERR_INVALID_ARG, "push: output buffer/stride too small");
         }
         const int orows = fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh;
-        S_HIP(s, hipStreamSynchronize(s->st_warp));   // batch mode: the warp ran on the warp stream
+        S_HIP(s, hipStreamSynchronize(s->st_warp));   // (per-frame pipeline: the warp ran on the warp stream)
+        if (s->batch_active) S_HIP(s, hipStreamSynchronize(s->st_pre));     // batch mode: the warps run on `pre` (group_launch_ready)
         S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_out, orow, orow, orows, hipMemcpyDeviceToHost, s->st));
     }
     // the caller's frame must be consumed and its result delivered before returning
@@ -1306,6 +1300,7 @@ int vs_stab_flush(vs_stab* s, uint8_t* out, size_t out_stride, int* produced) {
     if (rc != VS_OK) return rc;
     const int orows = s->fmt == VS_FMT_NV12 ? oh * 3 / 2 : oh;
     S_HIP(s, hipStreamSynchronize(s->st_warp));
+    if (s->batch_active) S_HIP(s, hipStreamSynchronize(s->st_pre));         // batch mode: the warps run on `pre`
     S_HIP(s, hipMemcpy2DAsync(out, out_stride, s->d_out, orow, orow, orows, hipMemcpyDeviceToHost, s->st));
     S_HIP(s, hipStreamSynchronize(s->st));
     return VS_OK;
@@ -1503,7 +1498,7 @@ struct vs_batch {
     bool own = false;                       // the private schedule of one standalone instance
     std::vector<vs_stab*> m;
     std::string err;
-    hipStream_t st = nullptr, st_pre = nullptr, st_det = nullptr;
+    hipStream_t st = nullptr, st_pre = nullptr, st_det = nullptr, st_up = nullptr;      // st_up: the table uploads (the pool's warp stream: idle in batch mode)
     bool allocated = false;
     // Host images of the argument tables of a step, in page-locked memory so that their uploads are asynchronous (from pageable
     // memory hipMemcpyAsync holds the host until the stream gets to the copy, and the host then no longer runs ahead of the
@@ -1514,16 +1509,18 @@ struct vs_batch {
     uint8_t* d_all = nullptr;
     uint8_t *d_lk[2] = {nullptr, nullptr}, *d_rs[2] = {nullptr, nullptr}, *d_tail[2] = {nullptr, nullptr}, *d_seg[2] = {nullptr, nullptr}, *d_gf = nullptr;
     uint8_t* d_tin[2] = {nullptr, nullptr};         // per frame of a step: what the selection leaves for the tail
-    ImgPair* d_pairs = nullptr;
+    ImgPair* d_pairs[2] = {nullptr, nullptr};     // (per table set: a step's pair table goes up with its other tables, one copy)
+    size_t up_bytes = 0;                 // bytes of a table set that go to the device: pairs, tracker, scoring, tail, segments
+    int pre_rel_step = -1;               // the latest step whose tail `pre` has waited for (through the event of its warps' maps)
     double* d_MinvB[2] = {nullptr, nullptr};        // inverse maps of the due frames of a step, 12 doubles each; two sets
     int32_t* d_tabs[2] = {nullptr, nullptr};        // coordinate tables of those frames (warp_tab.h), tab_ints per frame; two sets
     int tab_ints = 0;                               // one plane's table, or an NV12 surface's block of two
-    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {}, ev_warp[2] = {};
-    bool bdet_valid[4] = {false, false, false, false}, warp_valid[2] = {false, false};
+    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {}, ev_warp[2] = {}, ev_rel[2] = {}, ev_up[2] = {};
+    bool bdet_valid[4] = {false, false, false, false}, warp_valid[2] = {false, false}, rel_valid[2] = {false, false};
     int last_det_batch = -1, last_warp_set = -1, batch_id = 0, pend_set = 0;
     struct Ready {
         bool valid = false, tabs_built = false;
-        int n = 0, set = 0;
+        int n = 0, set = 0, step = -1;         // step: the group_run that analysed these frames
         size_t stride = 0;
         std::vector<const uint8_t*> srcs;
         std::vector<uint8_t*> dsts;
@@ -1559,7 +1556,7 @@ void group_free(vs_batch* g) {
 
 bool group_make_events(vs_batch* g) {
     auto mk = [&](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
-    bool ok = mk(g->ev_bpre) && mk(g->ev_bgray) && mk(g->ev_bnms) && mk(g->ev_warp[0]) && mk(g->ev_warp[1]);
+    bool ok = mk(g->ev_bpre) && mk(g->ev_bgray) && mk(g->ev_bnms) && mk(g->ev_warp[0]) && mk(g->ev_warp[1]) && mk(g->ev_rel[0]) && mk(g->ev_rel[1]) && mk(g->ev_up[0]) && mk(g->ev_up[1]);
     for (auto& e : g->ev_bdet) ok = ok && mk(e);
     for (auto& e : g->ev_blk) ok = ok && mk(e);
     return ok;
@@ -1583,12 +1580,17 @@ int group_allocate(vs_batch* g) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_gf = take(gftt_item_bytes() * ngf);
-    const size_t o_lk[2] = {take(lk_item_bytes() * cap), take(lk_item_bytes() * cap)};
-    const size_t o_rs[2] = {take(ransac_item_bytes() * cap), take(ransac_item_bytes() * cap)};
-    const size_t o_tl[2] = {take(tail_item_bytes() * cap), take(tail_item_bytes() * cap)};
-    const size_t o_sg[2] = {take(tail_seg_bytes() * g->S), take(tail_seg_bytes() * g->S)};
+    // a table set on the device = its image on the host (pairs, tracker items, scoring items, tail items, segments: ONE upload per step)
+    size_t ho = 0;
+    auto htake = [&](size_t bytes) { size_t o = ho; ho += (bytes + 255) & ~(size_t)255; return o; };
+    g->ho_pairs = htake(sizeof(ImgPair) * cap * (2 + 2 * MAX_PYR));
+    g->ho_lk = htake(lk_item_bytes() * cap); g->ho_rs = htake(ransac_item_bytes() * cap);
+    g->ho_tail = htake(tail_item_bytes() * cap); g->ho_seg = htake(tail_seg_bytes() * g->S);
+    g->up_bytes = ho;
+    g->ho_gf = htake(gftt_item_bytes() * ngf);
+    g->h_set_bytes = ho;
+    const size_t o_set[2] = {take(g->up_bytes), take(g->up_bytes)};
     const size_t o_ti[2] = {take(tail_in_bytes() * cap), take(tail_in_bytes() * cap)};
-    const size_t o_pairs = take(sizeof(ImgPair) * cap * (2 + 2 * MAX_PYR));
     const size_t o_minv[2] = {take((size_t)cap * 96), take((size_t)cap * 96)};
     int tow, toh;
     out_size(s0, s0->w, s0->h, &tow, &toh);
@@ -1600,17 +1602,12 @@ int group_allocate(vs_batch* g) {
     uint8_t* b = g->d_all;
     g->d_gf = b + o_gf;
     for (int i = 0; i < 2; i++) {
-        g->d_lk[i] = b + o_lk[i]; g->d_rs[i] = b + o_rs[i]; g->d_tail[i] = b + o_tl[i]; g->d_seg[i] = b + o_sg[i]; g->d_tin[i] = b + o_ti[i];
+        uint8_t* ds = b + o_set[i];
+        g->d_pairs[i] = (ImgPair*)(ds + g->ho_pairs);
+        g->d_lk[i] = ds + g->ho_lk; g->d_rs[i] = ds + g->ho_rs; g->d_tail[i] = ds + g->ho_tail; g->d_seg[i] = ds + g->ho_seg; g->d_tin[i] = b + o_ti[i];
         g->d_MinvB[i] = (double*)(b + o_minv[i]);
     }
-    g->d_pairs = (ImgPair*)(b + o_pairs);
     for (int i = 0; i < 2; i++) g->d_tabs[i] = (int32_t*)(b + o_tabs[i]);
-    size_t ho = 0;
-    auto htake = [&](size_t bytes) { size_t o = ho; ho += (bytes + 255) & ~(size_t)255; return o; };
-    g->ho_pairs = htake(sizeof(ImgPair) * cap * (2 + 2 * MAX_PYR));
-    g->ho_lk = htake(lk_item_bytes() * cap); g->ho_rs = htake(ransac_item_bytes() * cap);
-    g->ho_tail = htake(tail_item_bytes() * cap); g->ho_gf = htake(gftt_item_bytes() * ngf); g->ho_seg = htake(tail_seg_bytes() * g->S);
-    g->h_set_bytes = ho;
     G_HIP(g, hipHostMalloc((void**)&g->h_tables, 4 * ho));
     memset(g->h_tables, 0, 4 * ho);
     G_HIP(g, hipStreamSynchronize(g->st));
@@ -1633,11 +1630,10 @@ WarpEnds warp_ends(const vs_stab* o, const uint8_t* frame, uint8_t* d_out, int p
 // The warps of the step whose tails were queued last, 32 frames per launch (`what` = VS_WARP_ONLY / VS_WARP_ALL), or only their
 // coordinate tables (VS_WARP_TABLES_ONLY: steps whose release workgroups have not built them - a Kalman stream's releases stay
 // inside its tail workgroup).  The frames' tables lie tab_ints apart in d_tabs[set].
-int group_ready_launches(vs_batch* g, int what) {
+int group_ready_launches(vs_batch* g, int what, hipStream_t st) {
     vs_batch::Ready& R = g->ready;
     const vs_stab* s0 = g->m[0];
     const vs_params_c& p = s0->p;
-    hipStream_t st = g->st;
     const int bsz = p.border_size;
     const bool pad = bsz > 0 && !p.crop_n_zoom;                                                       // Stabilizer.cpp:981-990
     const bool crop = bsz > 0 && p.crop_n_zoom && s0->w - 2 * bsz > 0 && s0->h - 2 * bsz > 0;          // :1108-1124
@@ -1703,18 +1699,26 @@ int group_ready_launches(vs_batch* g, int what) {
     return rc;
 }
 
+// The warps of the step in g->ready.  They run on `pre`, behind the gray / pyramid work of the step that issues them and in front of
+// the next step's: the cycle warps -> gray -> pyramid -> warps that sets the step time is then the order of ONE stream (as launches
+// on `main` with events in both directions - the pyramid's to `main`, the warps' back to `pre` - every period paid two event hand-overs,
+// 2 x 25 us of 545).  Their maps and tables come from the tail on `main`: ev_rel.
 int group_launch_ready(vs_batch* g) {
     vs_batch::Ready& R = g->ready;
     if (!R.valid) return VS_OK;
-    hipStream_t st = g->st;
+    hipStream_t st = g->st_pre;
     vs_stab* s0 = g->m[0];
     int rc;
+    if (g->rel_valid[R.set]) {
+        if (hipStreamWaitEvent(st, g->ev_rel[R.set], 0) != hipSuccess) return gfail(g, VS_ERR_HIP, "hipStreamWaitEvent failed");
+        g->rel_valid[R.set] = false;
+        g->pre_rel_step = std::max(g->pre_rel_step, R.step);
+    }
     {
         StageScope t(s0, VS_STAGE_WARP, st);       // (stage times of a group are booked on its first member)
-        rc = group_ready_launches(g, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL);
+        rc = group_ready_launches(g, R.tabs_built ? VS_WARP_ONLY : VS_WARP_ALL, st);
     }
     if (hipEventRecord(g->ev_warp[R.set], st) == hipSuccess) { g->warp_valid[R.set] = true; g->last_warp_set = R.set; }
-    if (s0->ev_dev_warp && hipEventRecord(s0->ev_dev_warp, st) == hipSuccess) s0->dev_warp_valid->store(true, std::memory_order_release);
     for (int i = 0; i < R.n; i++) {
         const int slot = R.slots[i];
         vs_stab* o = R.owner[i];
@@ -1754,17 +1758,16 @@ int group_run(vs_batch* g) {
     uint8_t *h_lk = hset + g->ho_lk, *h_rs = hset + g->ho_rs, *h_tail = hset + g->ho_tail, *h_gf = hset + g->ho_gf, *h_seg = hset + g->ho_seg;
     const int dset = k & 1;
     // ---- pre: gray images and pyramids of all frames of the step, one launch per stage and level
-    if (k >= 2) {
-        // ring reuse: these pyramid slots were read by the analysis two steps ago (npyr = 2 * batch + 2)
+    if (k >= 2 && g->pre_rel_step < k - 2) {
+        // ring reuse: these pyramid slots were read by the analysis two steps ago (npyr = 2 * batch + 2).  (When that step had
+        // outputs this stream has waited for its tail already, in front of its warps: nothing to wait for.)
         G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_blk[(k - 2) % 4], 0));
         if (g->bdet_valid[(k - 2) % 4]) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_bdet[(k - 2) % 4], 0));
     }
-    // keep the HBM-bound warp alone on the GPU even when the host runs steps ahead: this step's gray / pyramid / detection
-    // kernels start after the warps issued during the previous step.  Several schedules share the device's streams: the last
-    // batched warp of ANY of them (their launches interleave in the shared queues, so that is the one in front of this step's
-    // kernels).  (Without the guard: 99.0 - 102.4 k frames/s against 112.4 - 114.2 k, warps 182 us instead of 86, round 3.)
-    if (s0->ev_dev_warp && s0->dev_warp_valid->load(std::memory_order_acquire)) G_HIP(g, hipStreamWaitEvent(g->st_pre, s0->ev_dev_warp, 0));
-    else if (g->last_warp_set >= 0) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_warp[g->last_warp_set], 0));
+    // (The HBM-bound warps stay alone on the GPU although the host runs steps ahead: they are launches on this stream, behind the
+    // pyramid of the step that issues them and in front of the next step's gray kernels - group_launch_ready.  Round 3 had them on
+    // `main` and an event from there that this stream waited for; without that guard 99.0 - 102.4 k frames/s against 112.4 - 114.2 k,
+    // warps 182 us instead of 86.)
     // ---- argument tables of the tracker, the scoring and the tail (segment = stream): filled here (they do not depend on this
     // step's images), uploaded in the middle of `pre`; which outputs become due and where their maps go is known on the host
     const int set = g->pend_set;
@@ -1848,32 +1851,36 @@ int group_run(vs_batch* g) {
                 for (int l = 0; l <= L; l++) h_pairs[(size_t)(L + 1 + l) * n + i] = ImgPair{P.img[l], P.der[l]};
                 i++;
             }
-        G_HIP(g, hipMemcpyAsync(g->d_pairs, h_pairs, sizeof(ImgPair) * n * (2 * L + 2), hipMemcpyHostToDevice, g->st_pre));
+        // ONE upload per step: the pair tables of the gray / pyramid launches and, behind them in the set, the tables of the tracker,
+        // the scoring and the tail (all filled above).  (As five copies - the four small ones in the middle of `pre`, which had slack
+        // while the warps ran on `main` - they stood 46 us on what is the step's longest chain since the warps run on this stream.)
+        // The copy runs on a stream of its own: the host is a step or two ahead of the GPU, so the tables are there long before `pre`
+        // gets to this step (as a copy on `pre` it stood between the warps and the gray kernels: 26 us of hand-over to the copy engine
+        // and back on the step's longest chain).  The set was last used by step k - 2: its tail must have run.
+        ImgPair* const d_pairs = g->d_pairs[dset];
+        if (k >= 2) G_HIP(g, hipStreamWaitEvent(g->st_up, g->ev_blk[(k - 2) % 4], 0));
+        G_HIP(g, hipMemcpyAsync(g->d_pairs[dset], hset, g->up_bytes, hipMemcpyHostToDevice, g->st_up));
+        G_HIP(g, hipEventRecord(g->ev_up[dset], g->st_up));
+        G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_up[dset], 0));
         {
             StageScope t(g->m[0], VS_STAGE_GRAY, g->st_pre);
             // NV12: the Y plane is the gray image (no reference path; same policy as the per-frame pipeline)
             const int gfmt = s0->fmt == VS_FMT_NV12 ? VS_FMT_GRAY8 : s0->fmt;
             const int n_a = (n_detect > 0 && n_detect < n) ? n_detect : n;
-            G_TRY(g, launch_resize_gray_batch(g->d_pairs, n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));  // :448-450
+            G_TRY(g, launch_resize_gray_batch(d_pairs, n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));  // :448-450
             G_HIP(g, hipEventRecord(g->ev_bgray, g->st_pre));      // the detector needs the analysis images of its frames only
             if (n_a < n)
-                G_TRY(g, launch_resize_gray_batch(g->d_pairs + n_a, n - n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));
+                G_TRY(g, launch_resize_gray_batch(d_pairs + n_a, n - n_a, s0->src_pitch, s0->w, s0->h, gfmt, s0->aw, s0->aw, s0->ah, aligned, g->st_pre));
         }
-        // the tracker / scoring / tail tables go up here, in the middle of `pre` (which has slack): on `main` they sat between
-        // the tail of the step before and its warps; in front of the gray stage they delayed the detector; at the end of
-        // `pre` they delayed the event the warps wait for
-        G_HIP(g, hipMemcpyAsync(g->d_lk[dset], h_lk, lk_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
-        G_HIP(g, hipMemcpyAsync(g->d_rs[dset], h_rs, ransac_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
-        G_HIP(g, hipMemcpyAsync(g->d_tail[dset], h_tail, tail_item_bytes() * n, hipMemcpyHostToDevice, g->st_pre));
-        G_HIP(g, hipMemcpyAsync(g->d_seg[dset], h_seg, tail_seg_bytes() * nseg, hipMemcpyHostToDevice, g->st_pre));
         StageScope t(g->m[0], VS_STAGE_PYRAMID, g->st_pre);
         // One launch per level (pyr_level_kernel): derivatives of level l and the image of level l+1 from one staged read of
         // level l.  (83.0 k -> 92.2 k frames/s at 1080p against the two stencils as separate launches, round 2.)
         for (int l = 0; l <= L; l++)
-            G_TRY(g, launch_pyr_level_batch(g->d_pairs + (size_t)(L + 1 + l) * n, l < L ? g->d_pairs + (size_t)(l + 1) * n : nullptr, n, s0->lw[l], s0->lw[l],
+            G_TRY(g, launch_pyr_level_batch(d_pairs + (size_t)(L + 1 + l) * n, l < L ? d_pairs + (size_t)(l + 1) * n : nullptr, n, s0->lw[l], s0->lw[l],
                                             s0->lh[l], l < L ? s0->lw[l + 1] : 0, g->st_pre));
     }
-    G_HIP(g, hipEventRecord(g->ev_bpre, g->st_pre));
+    // (`main` waits for the event behind this step's warps when there are any: it covers the pyramid, which lies in front of them)
+    if (!g->ready.valid) G_HIP(g, hipEventRecord(g->ev_bpre, g->st_pre));
     // ---- det: every frame of the step that re-detects, one launch per GFTT stage
     int ndet = 0;
     for (vs_stab* s : act) {
@@ -1913,17 +1920,23 @@ int group_run(vs_batch* g) {
     g->bdet_valid[k % 4] = ndet > 0;
     // ---- main: tracking and hypothesis scoring of all frames, one launch each
     hipStream_t st = g->st;
-    G_HIP(g, hipStreamWaitEvent(st, g->ev_bpre, 0));
-    for (vs_stab* s : act)
-        if (s->pts_pending[0]) { G_HIP(g, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
     const bool wait_det = g->last_det_batch >= 0 && g->last_det_batch >= k - 1;
     const bool early = wait_det && g->last_det_batch == k;
-    if (early) G_HIP(g, hipStreamWaitEvent(st, g->ev_bnms, 0));
-    else if (wait_det) G_HIP(g, hipStreamWaitEvent(st, g->ev_bdet[g->last_det_batch % 4], 0));
-    // `main` has waited for this step's gray / pyramid work and the wide launches of its detection: the warps of the PREVIOUS
-    // step go out here, before this step's tracking, with nothing but the corner selection (a workgroup per image) beside them
+    // The warps of the PREVIOUS step go out here, on `pre` behind this step's pyramid, once the wide launches of this step's
+    // detection are through: nothing but the corner selection (a workgroup per image) runs beside them.
+    const bool warps_go = g->ready.valid;
+    if (warps_go) {
+        if (early) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_bnms, 0));
+        else if (wait_det) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_bdet[g->last_det_batch % 4], 0));
+    }
     G_TRY(g, group_launch_ready(g));
-    if (early) G_HIP(g, hipStreamWaitEvent(st, g->ev_bdet[g->last_det_batch % 4], 0));       // the tracker needs the selected corners
+    // ---- main: waits for this step's gray / pyramid work, its corners and - the tracker takes every vector register of every SIMD,
+    // beside it the warps would crawl - the warps just issued
+    if (warps_go && g->last_warp_set >= 0) G_HIP(g, hipStreamWaitEvent(st, g->ev_warp[g->last_warp_set], 0));
+    else G_HIP(g, hipStreamWaitEvent(st, g->ev_bpre, 0));
+    for (vs_stab* s : act)
+        if (s->pts_pending[0]) { G_HIP(g, hipStreamWaitEvent(st, s->pts_event[0], 0)); s->pts_pending[0] = false; }
+    if (wait_det) G_HIP(g, hipStreamWaitEvent(st, g->ev_bdet[g->last_det_batch % 4], 0));       // the tracker needs the selected corners
     {
         StageScope t(g->m[0], VS_STAGE_LK, st);
         G_TRY(g, launch_pyr_lk_batch(g->d_lk[dset], n, n_max, s0->p.lk_win_size, st));
@@ -1949,15 +1962,17 @@ int group_run(vs_batch* g) {
     G_HIP(g, hipEventRecord(g->ev_blk[k % 4], st));
     // the warps of this step wait for the next one (or a drain); their maps exist once the tail has run: the coordinate tables
     // are built right behind it
-    R.n = npend; R.set = set; R.stride = pend_stride; R.valid = npend > 0; R.tabs_built = all_apart != 0;
+    R.n = npend; R.set = set; R.stride = pend_stride; R.valid = npend > 0; R.tabs_built = all_apart != 0; R.step = k;
     std::swap(g->ready, g->next);            // (the previous step's warps have been issued: g->ready was free)
     if (g->ready.valid) {
         g->pend_set = set ^ 1;
         if (!g->ready.tabs_built) {          // (a Kalman stream in the step: the tables as a launch behind the tail)
             StageScope t(g->m[0], VS_STAGE_WARP_TABLES, st);
-            G_TRY(g, group_ready_launches(g, VS_WARP_TABLES_ONLY));
+            G_TRY(g, group_ready_launches(g, VS_WARP_TABLES_ONLY, st));
             g->ready.tabs_built = true;
         }
+        G_HIP(g, hipEventRecord(g->ev_rel[set], st));          // maps and tables of this step's warps exist
+        g->rel_valid[set] = true;
     }
     for (vs_stab* s : act) {
         const vs_stab::BFrame& lb = s->bq.back();
@@ -1982,7 +1997,7 @@ void group_delete(vs_batch* g) {
     if (!g) return;
     group_free(g);
     auto kill = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };
-    kill(g->ev_bpre); kill(g->ev_bgray); kill(g->ev_bnms); kill(g->ev_warp[0]); kill(g->ev_warp[1]);
+    kill(g->ev_bpre); kill(g->ev_bgray); kill(g->ev_bnms); kill(g->ev_warp[0]); kill(g->ev_warp[1]); kill(g->ev_rel[0]); kill(g->ev_rel[1]); kill(g->ev_up[0]); kill(g->ev_up[1]);
     for (auto& e : g->ev_bdet) kill(e);
     for (auto& e : g->ev_blk) kill(e);
     delete g;
@@ -1994,7 +2009,7 @@ vs_batch* group_new_own(vs_stab* s) {
     if (!g) { set_last_error("out of host memory"); return nullptr; }
     g->device = s->device; g->S = 1; g->B = s->batch; g->cap = s->batch; g->own = true;
     g->m.push_back(s);
-    g->st = s->st; g->st_pre = s->st_pre; g->st_det = s->st_det;
+    g->st = s->st; g->st_pre = s->st_pre; g->st_det = s->st_det; g->st_up = s->st_warp;
     if (!group_make_events(g)) { set_last_error("hipEventCreate failed"); group_delete(g); return nullptr; }
     return g;
 }
@@ -2039,7 +2054,7 @@ static int batch_create(int device, int n_streams, const vs_params_c* params, in
         s->group = g; s->member = true;
         g->m.push_back(s);
     }
-    g->st = g->m[0]->st; g->st_pre = g->m[0]->st_pre; g->st_det = g->m[0]->st_det;
+    g->st = g->m[0]->st; g->st_pre = g->m[0]->st_pre; g->st_det = g->m[0]->st_det; g->st_up = g->m[0]->st_warp;
     if (!group_make_events(g)) { set_last_error("vs_batch_create: hipEventCreate failed"); vs_batch_destroy(g); return VS_ERR_HIP; }
     *out = g;
     return VS_OK;
