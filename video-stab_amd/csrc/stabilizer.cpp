@@ -1515,7 +1515,7 @@ struct vs_batch {
     double* d_MinvB[2] = {nullptr, nullptr};        // inverse maps of the due frames of a step, 12 doubles each; two sets
     int32_t* d_tabs[2] = {nullptr, nullptr};        // coordinate tables of those frames (warp_tab.h), tab_ints per frame; two sets
     int tab_ints = 0;                               // one plane's table, or an NV12 surface's block of two
-    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {}, ev_warp[2] = {}, ev_rel[2] = {}, ev_up[2] = {};
+    hipEvent_t ev_bpre = nullptr, ev_bgray = nullptr, ev_bnms = nullptr, ev_bdet[4] = {}, ev_blk[4] = {}, ev_warp[2] = {}, ev_rel[2] = {}, ev_up[2] = {}, ev_go = nullptr;
     bool bdet_valid[4] = {false, false, false, false}, warp_valid[2] = {false, false}, rel_valid[2] = {false, false};
     int last_det_batch = -1, last_warp_set = -1, batch_id = 0, pend_set = 0;
     struct Ready {
@@ -1556,7 +1556,7 @@ void group_free(vs_batch* g) {
 
 bool group_make_events(vs_batch* g) {
     auto mk = [&](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
-    bool ok = mk(g->ev_bpre) && mk(g->ev_bgray) && mk(g->ev_bnms) && mk(g->ev_warp[0]) && mk(g->ev_warp[1]) && mk(g->ev_rel[0]) && mk(g->ev_rel[1]) && mk(g->ev_up[0]) && mk(g->ev_up[1]);
+    bool ok = mk(g->ev_bpre) && mk(g->ev_bgray) && mk(g->ev_bnms) && mk(g->ev_warp[0]) && mk(g->ev_warp[1]) && mk(g->ev_rel[0]) && mk(g->ev_rel[1]) && mk(g->ev_up[0]) && mk(g->ev_up[1]) && mk(g->ev_go);
     for (auto& e : g->ev_bdet) ok = ok && mk(e);
     for (auto& e : g->ev_blk) ok = ok && mk(e);
     return ok;
@@ -1703,16 +1703,23 @@ int group_ready_launches(vs_batch* g, int what, hipStream_t st) {
 // the next step's: the cycle warps -> gray -> pyramid -> warps that sets the step time is then the order of ONE stream (as launches
 // on `main` with events in both directions - the pyramid's to `main`, the warps' back to `pre` - every period paid two event hand-overs,
 // 2 x 25 us of 545).  Their maps and tables come from the tail on `main`: ev_rel.
-int group_launch_ready(vs_batch* g) {
+int group_launch_ready(vs_batch* g, hipEvent_t det_done = nullptr) {
     vs_batch::Ready& R = g->ready;
     if (!R.valid) return VS_OK;
     hipStream_t st = g->st_pre;
     vs_stab* s0 = g->m[0];
     int rc;
-    if (g->rel_valid[R.set]) {
-        if (hipStreamWaitEvent(st, g->ev_rel[R.set], 0) != hipSuccess) return gfail(g, VS_ERR_HIP, "hipStreamWaitEvent failed");
+    // what the warps wait for - the step's maps and tables (ev_rel), the wide launches of the detector (det_done) - is gathered on the
+    // upload stream into ONE event: one packet in front of the warps on `pre` instead of two
+    if (g->rel_valid[R.set] || det_done) {
+        hipError_t e = hipSuccess;
+        if (det_done) e = hipStreamWaitEvent(g->st_up, det_done, 0);
+        if (e == hipSuccess && g->rel_valid[R.set]) e = hipStreamWaitEvent(g->st_up, g->ev_rel[R.set], 0);
+        if (e == hipSuccess) e = hipEventRecord(g->ev_go, g->st_up);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, g->ev_go, 0);
+        if (e != hipSuccess) return gfail(g, VS_ERR_HIP, "hipStreamWaitEvent failed");
+        if (g->rel_valid[R.set]) g->pre_rel_step = std::max(g->pre_rel_step, R.step);
         g->rel_valid[R.set] = false;
-        g->pre_rel_step = std::max(g->pre_rel_step, R.step);
     }
     {
         StageScope t(s0, VS_STAGE_WARP, st);       // (stage times of a group are booked on its first member)
@@ -1925,11 +1932,7 @@ int group_run(vs_batch* g) {
     // The warps of the PREVIOUS step go out here, on `pre` behind this step's pyramid, once the wide launches of this step's
     // detection are through: nothing but the corner selection (a workgroup per image) runs beside them.
     const bool warps_go = g->ready.valid;
-    if (warps_go) {
-        if (early) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_bnms, 0));
-        else if (wait_det) G_HIP(g, hipStreamWaitEvent(g->st_pre, g->ev_bdet[g->last_det_batch % 4], 0));
-    }
-    G_TRY(g, group_launch_ready(g));
+    G_TRY(g, group_launch_ready(g, early ? g->ev_bnms : (wait_det ? g->ev_bdet[g->last_det_batch % 4] : (hipEvent_t) nullptr)));
     // ---- main: waits for this step's gray / pyramid work, its corners and - the tracker takes every vector register of every SIMD,
     // beside it the warps would crawl - the warps just issued
     if (warps_go && g->last_warp_set >= 0) G_HIP(g, hipStreamWaitEvent(st, g->ev_warp[g->last_warp_set], 0));
@@ -1997,7 +2000,7 @@ void group_delete(vs_batch* g) {
     if (!g) return;
     group_free(g);
     auto kill = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };
-    kill(g->ev_bpre); kill(g->ev_bgray); kill(g->ev_bnms); kill(g->ev_warp[0]); kill(g->ev_warp[1]); kill(g->ev_rel[0]); kill(g->ev_rel[1]); kill(g->ev_up[0]); kill(g->ev_up[1]);
+    kill(g->ev_bpre); kill(g->ev_bgray); kill(g->ev_bnms); kill(g->ev_warp[0]); kill(g->ev_warp[1]); kill(g->ev_rel[0]); kill(g->ev_rel[1]); kill(g->ev_up[0]); kill(g->ev_up[1]); kill(g->ev_go);
     for (auto& e : g->ev_bdet) kill(e);
     for (auto& e : g->ev_blk) kill(e);
     delete g;
